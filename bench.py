@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CTC fwd+bwd frames/s at B=256 T=1000 V=29 S<=200 fp32 per GPU
+(BASELINE.json configs[1], the LibriSpeech-char shape), synthetic logits.
+
+A step = one pass of the hot path over one batch already resident in HBM: the fused
+log-softmax + alpha/beta lattice + gradient launch of libe2e_ctc.so (C ABI
+e2e_ctc_loss_fwd_bwd, raw logits in, per-utterance losses and d loss/d logits out), plus the
+batch-mean reduction; with N>1 ranks each GPU gets its own 256 utterances (weak scaling, no
+data-path collective) and the scalar loss is all-reduced over RCCL.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM peak with
+ALGORITHMIC bytes (2*V*4 B per frame: logits read once, gradient written once);
+`cpu_baseline` times the reference's own C++ engine (oracle/_ref, kind "reference") or, if
+that is absent, the C restatement (kind "port") on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+
+WORKLOAD = dict(name="ctc_fwd_bwd_B256_T1000_V29_S200_f32", B=256, T=1000, V=29, S=200)
+
+
+def make_batch(seed, B, T, V, S, device):
+    """logits randn, targets in [1,V), target lengths in [S/2,S], full-length inputs."""
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(B, T, V, generator=g)
+    targets = torch.randint(1, V, (B, S), generator=g)
+    t_len = torch.randint(S // 2, S + 1, (B,), generator=g)
+    x_len = torch.full((B,), T, dtype=torch.long)
+    host = (logits, targets, x_len, t_len)
+    return host, tuple(t.to(device) for t in host)
+
+
+class HotPath:
+    """Pre-bound C-ABI call (no per-step allocation, graph-capturable)."""
+
+    def __init__(self, dev_batch, blank=0):
+        from end2end_amd import _lib
+        self.lib = _lib
+        self.L = _lib.load()
+        self.x, self.targets, self.x_len, self.t_len = dev_batch
+        self.dev = self.x.device
+        B, T, V = self.x.shape
+        self.B, self.T, self.V, self.S = B, T, V, self.targets.shape[1]
+        self.losses = torch.empty(B, dtype=torch.float32, device=self.dev)
+        self.grads = torch.empty((B, T, V), dtype=torch.float32, device=self.dev)
+        n = self.L.e2e_ctc_loss_workspace_bytes(B, T, V, self.S, _lib.F32, _lib.ALGO_AUTO)
+        self.ws = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        self.blank = blank
+        self.mean = torch.zeros((), dtype=torch.float32, device=self.dev)
+
+    def step(self):
+        sB, sT, sV = self.x.stride()
+        self.lib.check(self.L.e2e_ctc_loss_fwd_bwd(
+            self.x.data_ptr(), self.lib.F32, 0, sB, sT, sV,
+            self.targets.data_ptr(), self.targets.stride(0), self.x_len.data_ptr(), self.t_len.data_ptr(),
+            self.B, self.T, self.V, self.S, self.blank,
+            self.losses.data_ptr(), self.grads.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+            self.lib.ALGO_AUTO, self.lib.stream_ptr(self.dev)))
+        torch.mean(self.losses, dim=0, out=self.mean)
+        return self.mean
+
+
+def cpu_baseline(host_batch, frames):
+    """The reference path on host cores: log_softmax + engine.compute + backward, as
+    pytorch_end2end/modules/ctc_loss.py:25-57 and functions/forward_backward.py:18-35 do it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    logits, targets, x_len, t_len = host_batch
+    ref = O.load_reference_engine()
+    kind = "reference" if ref is not None else "port"
+
+    if ref is not None:
+        eng = ref.CTCLossEngine(0)
+
+        def engine(lp, tg, xl, tl):
+            return eng.compute(lp, tg, xl, tl)
+    else:
+        def engine(lp, tg, xl, tl):
+            l, g = O.ctc_loss(lp.double().numpy(), tg.numpy(), xl.numpy(), tl.numpy(), 0, n_threads=0)
+            return torch.from_numpy(l).float(), torch.from_numpy(g).float()
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, lp, tg, xl, tl):
+            loss, grads = engine(lp.detach(), tg, xl, tl)
+            ctx.grads = grads
+            return loss
+
+        @staticmethod
+        def backward(ctx, go):
+            return ctx.grads * go.view(-1, 1, 1), None, None, None
+
+    def one(n):
+        x = logits[:n].clone().requires_grad_()
+        t0 = time.perf_counter()
+        loss = Fn.apply(torch.log_softmax(x, 2), targets[:n], x_len[:n], t_len[:n]).mean()
+        loss.backward()
+        return time.perf_counter() - t0
+
+    B = logits.shape[0]
+    one(min(B, 16))                       # warm-up (thread pool, allocator)
+    n = B
+    times = [one(n) for _ in range(2)]
+    best = min(times)
+    per_frame = frames * n / B
+    return {"value": per_frame / best, "unit": "frames/s", "cores": os.cpu_count(), "kind": kind,
+            "sample": "full %d-utterance batch of the same workload, best of 2 after a 16-utterance warm-up, "
+                      "one thread per utterance as the reference does (%.2f s per pass)" % (n, best)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    n_gpus = world if distributed else 1
+
+    w = WORKLOAD
+    host_batch, dev_batch = make_batch(1000 + rank, w["B"], w["T"], w["V"], w["S"], dev)
+    frames = int(host_batch[2].sum().item())
+    hp = HotPath(dev_batch)
+
+    def step():
+        m = hp.step()
+        if distributed:
+            dist.all_reduce(m, op=dist.ReduceOp.SUM)     # the one scalar exchange of the sharded path
+        return m
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+
+    # dominant kernel duration: HIP events on the launch stream around each of K launches (second pass,
+    # kernel only, so that the mean/all-reduce tail is not attributed to it)
+    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sB, sT, sV = hp.x.stride()
+    for a, b in kev:
+        a.record()
+        hp.lib.check(hp.L.e2e_ctc_loss_fwd_bwd(
+            hp.x.data_ptr(), hp.lib.F32, 0, sB, sT, sV, hp.targets.data_ptr(), hp.targets.stride(0),
+            hp.x_len.data_ptr(), hp.t_len.data_ptr(), hp.B, hp.T, hp.V, hp.S, 0,
+            hp.losses.data_ptr(), hp.grads.data_ptr(), hp.ws.data_ptr(), hp.ws.numel(),
+            hp.lib.ALGO_AUTO, hp.lib.stream_ptr(dev)))
+        b.record()
+    torch.cuda.synchronize()
+    kernel_ms = sum(a.elapsed_time(b) for a, b in kev) / len(kev)
+
+    if rank == 0:
+        total_frames = frames * n_gpus
+        ms_per_step = wall * 1e3 / args.steps
+        algo_bytes = 2.0 * w["V"] * 4 * frames          # per launch (one GPU's batch)
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "ctc_fwd_bwd_frames_per_sec", "value": total_frames * args.steps / wall, "unit": "frames/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["name"], "B_per_gpu": w["B"], "T": w["T"], "V": w["V"], "S_max": w["S"],
+                       "input": "raw logits (log-softmax fused)", "api": "C ABI e2e_ctc_loss_fwd_bwd + mean"
+                       + (" + RCCL all_reduce(scalar)" if distributed else ""),
+                       "sharding": "utterances, %d per GPU" % w["B"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
+            "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host_batch, frames)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

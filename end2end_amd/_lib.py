@@ -1,0 +1,116 @@
+"""ctypes binding of libe2e_ctc.so (the C ABI in include/e2e_ctc.h).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible
+the product raises.  Nothing here touches oracle/.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libe2e_ctc.so")
+
+F32, F64 = 0, 1
+ALGO_AUTO, ALGO_EXACT, ALGO_FAST = 0, 1, 2
+ABI_VERSION = 1
+
+_lib = None
+_lock = threading.Lock()
+
+
+class E2EError(RuntimeError):
+    """An error reported by the native library (message from e2e_last_error())."""
+
+
+def load():
+    """Load libe2e_ctc.so once; raise loudly if it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "end2end_amd: native library %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C end2end_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i64, i64p = C.c_void_p, C.c_int64, C.c_void_p
+        L.e2e_ctc_abi_version.restype = C.c_int
+        L.e2e_last_error.restype = C.c_char_p
+        L.e2e_ctc_loss_workspace_bytes.restype = C.c_size_t
+        L.e2e_ctc_loss_workspace_bytes.argtypes = [C.c_int] * 6
+        L.e2e_ctc_loss_fwd_bwd.restype = C.c_int
+        L.e2e_ctc_loss_fwd_bwd.argtypes = [vp, C.c_int, C.c_int, i64, i64, i64, i64p, i64, i64p, i64p,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           vp, vp, vp, C.c_size_t, C.c_int, vp]
+        L.e2e_ctc_scale_grads.restype = C.c_int
+        L.e2e_ctc_scale_grads.argtypes = [vp, C.c_int, vp, C.c_int, i64, vp]
+        L.e2e_ctc_greedy.restype = C.c_int
+        L.e2e_ctc_greedy.argtypes = [vp, C.c_int, i64, i64, i64, i64p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     i64p, i64p, vp]
+        L.e2e_lm_load_arpa.restype = C.c_int
+        L.e2e_lm_load_arpa.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(vp)]
+        L.e2e_lm_free.argtypes = [vp]
+        L.e2e_lm_order.restype = C.c_int
+        L.e2e_lm_order.argtypes = [vp]
+        L.e2e_lm_word_index.restype = C.c_uint32
+        L.e2e_lm_word_index.argtypes = [vp, C.c_char_p]
+        L.e2e_lm_score.restype = C.c_double
+        L.e2e_lm_score.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, C.c_uint32]
+        L.e2e_ctc_beam_workspace_bytes.restype = C.c_size_t
+        L.e2e_ctc_beam_workspace_bytes.argtypes = [C.c_int] * 4
+        L.e2e_ctc_beam.restype = C.c_int
+        L.e2e_ctc_beam.argtypes = [vp, C.c_int, i64, i64, i64, i64p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_double,
+                                   i64p, i64, i64p, vp, C.c_size_t, vp]
+        if L.e2e_ctc_abi_version() != ABI_VERSION:
+            raise ImportError("end2end_amd: %s has ABI %d, expected %d" % (LIB_PATH, L.e2e_ctc_abi_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise E2EError("libe2e_ctc: %s (code %d)" % (load().e2e_last_error().decode(errors="replace"), rc))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("end2end_amd needs an AMD GPU (MI355X / gfx950) visible to PyTorch-ROCm; "
+                           "there is no CPU fallback in this package")
+
+
+def compute_device(t):
+    """Device the kernels run on for tensor t: its own if it is on a GPU, else the current GPU."""
+    if t.is_cuda:
+        return t.device
+    require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.float64:
+        return F64
+    raise TypeError("unsupported dtype %s" % dt)
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes):
+    """A cached per-(device, stream) scratch buffer of at least nbytes (grown geometrically)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,276 @@
+// Exact CTC forward-backward: f64 log-domain lattice, the reference's own
+// arithmetic (src/losses/ctc_loss.cpp:15-118), one workgroup per utterance.
+//
+// This is the always-correct path: it takes f64 inputs (gradcheck), -inf
+// log-probs, infeasible alignments (loss=+inf, grads=NaN, quirk Q2) and any
+// utterance the fast scaled path flags as out of range.  It is not the
+// throughput path -- f64 exp/log dominate -- see ctc_loss_fast.hip.
+//
+// HBM layout: alpha rows go to the workspace as [b][t][j] doubles (row stride
+// Lmax = 2*Smax+1) so that a time step is one coalesced row write in the alpha
+// sweep and one coalesced row read in the beta sweep.  LDS holds the extended
+// label row, the previous lattice row (double-buffered), the per-label
+// posterior accumulator post[V] and the label-sorted cell order.
+#include "common.h"
+
+namespace e2e {
+namespace {
+
+constexpr int kThreads = 512;   // 8 waves: L <= 512 cells take one cell per lane
+
+struct ExactParams {
+  const void* x; int64_t sB, sT, sV; int logprobs;
+  const int64_t* targets; int64_t tgt_stride;
+  const int64_t* x_len; const int64_t* t_len;
+  int B, T, V, Smax, Lmax, blank;
+  void* losses; void* grads;
+  double* ws_alpha;   // [B][T][Lmax]
+  double* ws_lse;     // [B][T] row log-sum-exp (logits mode)
+};
+
+__device__ __forceinline__ double neg_inf() { return -__builtin_huge_val(); }
+
+// src/utils/math_utils.h:8-16 (log(1.0 + x), not log1p)
+__device__ __forceinline__ double lse2(double a, double b) {
+  if (a == neg_inf()) return b;
+  if (b == neg_inf()) return a;
+  if (a > b) return a + log(1.0 + exp(b - a));
+  return b + log(1.0 + exp(a - b));
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <typename IO>
+__global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int V = p.V, Tmax = p.T, Lmax = p.Lmax, Smax = p.Smax, blank = p.blank;
+
+  double* buf0 = reinterpret_cast<double*>(smem);          // [Lmax]
+  double* buf1 = buf0 + Lmax;                              // [Lmax]
+  double* psorted = buf1 + Lmax;                           // [Smax] label-sorted posteriors
+  double* post = psorted + (Smax > 0 ? Smax : 1);          // [V]
+  double* red = post + V;                                  // [16]
+  int* ext = reinterpret_cast<int*>(red + 16);             // [Lmax]
+  int* rank = ext + Lmax;                                  // [Smax] rank of target i in label order
+  int* sorted_lab = rank + (Smax > 0 ? Smax : 1);          // [Smax] label at sorted position r
+
+  const IO* x = reinterpret_cast<const IO*>(p.x) + (int64_t)b * p.sB;
+  IO* grads = reinterpret_cast<IO*>(p.grads) + (size_t)b * (size_t)Tmax * (size_t)V;
+  IO* losses = reinterpret_cast<IO*>(p.losses);
+  double* wa = p.ws_alpha + (size_t)b * (size_t)Tmax * (size_t)Lmax;
+  double* wl = p.ws_lse + (size_t)b * (size_t)Tmax;
+
+  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
+  if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > Smax) {        // invalid lengths: poison, do not crash
+    const double qnan = __builtin_nan("");
+    if (tid == 0) losses[b] = (IO)qnan;
+    for (size_t i = tid; i < (size_t)Tmax * V; i += kThreads) grads[i] = (IO)qnan;
+    return;
+  }
+  const int T = (int)Tq, S = (int)Sq, L = 2 * S + 1;
+
+  // ---- P0: extended targets (ctc_loss.cpp:25-31), label order, row lse ----
+  for (int j = tid; j < L; j += kThreads)
+    ext[j] = (j & 1) ? (int)p.targets[(int64_t)b * p.tgt_stride + (j >> 1)] : blank;
+  for (int v = tid; v < V; v += kThreads) post[v] = 0.0;
+  if (tid == 0) red[8] = 0.0;
+  __syncthreads();
+  // stable rank of target i among the S targets by label value (same-label cells keep increasing j,
+  // so the per-label sums below run in the reference's order, ctc_loss.cpp:109-114)
+  for (int i = tid; i < S; i += kThreads) {
+    const int li = ext[2 * i + 1];
+    int r = 0;
+    for (int k = 0; k < S; k++) {
+      const int lk = ext[2 * k + 1];
+      r += (lk < li) || (lk == li && k < i);
+    }
+    rank[i] = r;
+    sorted_lab[r] = li;
+  }
+  if (!p.logprobs) {
+    for (int t = wid; t < Tmax; t += kThreads / 64) {
+      const IO* row = x + (int64_t)t * p.sT;
+      double m = neg_inf();
+      for (int v = lane; v < V; v += 64) m = fmax(m, (double)row[(int64_t)v * p.sV]);
+      m = wave_max(m);
+      double s = 0.0;
+      for (int v = lane; v < V; v += 64) s += exp((double)row[(int64_t)v * p.sV] - m);
+      s = wave_sum(s);
+      if (lane == 0) wl[t] = m + log(s);
+    }
+  }
+  __syncthreads();
+  // make the row-lse values written by other waves visible (global memory, same workgroup)
+  __threadfence_block();
+
+  auto lp = [&](int t, int v) -> double {
+    double r = (double)x[(int64_t)t * p.sT + (int64_t)v * p.sV];
+    return p.logprobs ? r : r - wl[t];
+  };
+
+  // ---- P1: alpha sweep, ctc_loss.cpp:33-61 ----
+  for (int j = tid; j < L; j += kThreads) {
+    double a = neg_inf();
+    if (j == 0 && (T > 1 || L == 1)) a = lp(0, ext[0]);
+    if (j == 1) a = lp(0, ext[1]);
+    buf0[j] = a;
+    wa[j] = a;
+  }
+  __syncthreads();
+  for (int t = 1; t < T; t++) {
+    const double* prev = (t & 1) ? buf0 : buf1;
+    double* cur = (t & 1) ? buf1 : buf0;
+    const int start = max(0, L - 2 * (T - t)), end = min(2 * t + 2, L);
+    double* warow = wa + (size_t)t * Lmax;
+    for (int j = tid; j < L; j += kThreads) {
+      double a = neg_inf();
+      if (j >= start && j < end) {
+        const int cl = ext[j];
+        a = prev[j];
+        if (j > 0) {
+          a = lse2(a, prev[j - 1]);
+          if (cl != blank && j >= 2 && ext[j - 2] != cl) a = lse2(a, prev[j - 2]);
+        }
+        a += lp(t, cl);
+      }
+      cur[j] = a;
+      warow[j] = a;
+    }
+    __syncthreads();
+  }
+
+  // ---- P2: loss, ctc_loss.cpp:63-70 ----
+  const double* last = ((T - 1) & 1) ? buf1 : buf0;
+  const double logZ = (L > 1) ? lse2(last[L - 1], last[L - 2]) : last[L - 1];
+  if (tid == 0) losses[b] = (IO)(-logZ);
+  __syncthreads();
+
+  if (logZ == neg_inf()) {
+    // infeasible alignment: the reference's exp(-inf - (-inf)) poisons the whole slab (Q2)
+    const double qnan = __builtin_nan("");
+    for (size_t i = tid; i < (size_t)Tmax * V; i += kThreads) grads[i] = (IO)qnan;
+    return;
+  }
+
+  // ---- P3: beta sweep (ctc_loss.cpp:72-100) fused with the gradient (:102-117) ----
+  // be[j] holds beta[j][t+1] + lp[t+1][ext[j]], the quantity the three-way sum reads.
+  for (int t = T - 1; t >= 0; t--) {
+    const double* be_next = (t & 1) ? buf0 : buf1;   // written at step t+1
+    double* be_cur = (t & 1) ? buf1 : buf0;
+    const int start = max(0, L - 2 * (T - t)), end = min(2 * t + 2, L);
+    const double* warow = wa + (size_t)t * Lmax;
+    double blank_part = 0.0;
+    for (int j = tid; j < L; j += kThreads) {
+      const int cl = ext[j];
+      double bt = neg_inf();
+      if (t == T - 1) {
+        if (j == L - 1 && (T > 1 || L == 1)) bt = 0.0;
+        if (j == L - 2) bt = 0.0;
+      } else if (j >= start && j < end) {
+        bt = be_next[j];
+        if (j < L - 1) {
+          bt = lse2(bt, be_next[j + 1]);
+          if (cl != blank && j + 2 < L && ext[j + 2] != cl) bt = lse2(bt, be_next[j + 2]);
+        }
+      }
+      be_cur[j] = bt + lp(t, cl);
+      const double pj = exp(warow[j] + bt - logZ);   // posterior of cell (j,t); exp(-inf)=0
+      if (j & 1) psorted[rank[j >> 1]] = pj; else blank_part += pj;
+    }
+    blank_part = wave_sum(blank_part);
+    if (lane == 0) red[wid] = blank_part;
+    __syncthreads();
+    // per-label sums in increasing-j order
+    for (int r = tid; r < S; r += kThreads) {
+      const int lab = sorted_lab[r];
+      if (r == 0 || sorted_lab[r - 1] != lab) {
+        double s = psorted[r];
+        for (int q = r + 1; q < S && sorted_lab[q] == lab; q++) s += psorted[q];
+        // a target equal to the blank id shares the blank column (ctc_loss.cpp:109-113 keys on the label)
+        if (lab != blank) post[lab] = s; else red[8] = s;
+      }
+    }
+    if (tid == kThreads - 1) {
+      double s = 0.0;
+      for (int w = 0; w < kThreads / 64; w++) s += red[w];
+      red[9] = s;
+    }
+    __syncthreads();
+    {
+      IO* grow = grads + (size_t)t * V;
+      const IO* xrow = x + (int64_t)t * p.sT;
+      const double rl = p.logprobs ? 0.0 : wl[t];
+      for (int v = tid; v < V; v += kThreads) {
+        // blank column = even cells (+ target cells whose label equals the blank id, red[8])
+        const double pv = (v == blank) ? red[9] + red[8] : post[v];
+        grow[v] = (IO)(exp((double)xrow[(int64_t)v * p.sV] - rl) - pv);
+      }
+    }
+    // next iteration's writes to psorted/red/post happen after its own first barrier or touch
+    // buffers nobody reads here (be_cur of t-1 is be_next of t, last read before the barrier above)
+    __syncthreads();
+  }
+
+  // ---- padded frames t >= T: exp(lp) in log-prob mode (Q1), 0 for fused logits ----
+  for (size_t i = (size_t)T * V + tid; i < (size_t)Tmax * V; i += kThreads) {
+    const int t = (int)(i / V), v = (int)(i % V);
+    grads[i] = p.logprobs ? (IO)exp((double)x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : (IO)0;
+  }
+}
+
+size_t exact_lds_bytes(int V, int Smax) {
+  const size_t Lmax = 2 * (size_t)Smax + 1, S1 = Smax > 0 ? Smax : 1;
+  return sizeof(double) * (2 * Lmax + S1 + (size_t)V + 16) + sizeof(int) * (Lmax + 2 * S1);
+}
+
+}  // namespace
+
+size_t exact_workspace_bytes(int B, int T, int V, int Smax) {
+  (void)V;
+  const size_t Lmax = 2 * (size_t)Smax + 1;
+  return align_up((size_t)B * T * Lmax * sizeof(double), 256) + align_up((size_t)B * T * sizeof(double), 256);
+}
+
+int launch_exact(const LossArgs& a) {
+  const size_t lds = exact_lds_bytes(a.V, a.Smax);
+  if (lds > 160 * 1024) {
+    set_error("exact CTC kernel: V=%d, Smax=%d need %zu B of LDS (> 160 KiB)", a.V, a.Smax, lds);
+    return E2E_ERR_UNSUPPORTED;
+  }
+  const size_t need = exact_workspace_bytes(a.B, a.T, a.V, a.Smax);
+  if (a.ws_bytes < need || !a.ws) {
+    set_error("workspace too small: %zu < %zu", a.ws_bytes, need);
+    return E2E_ERR_WORKSPACE;
+  }
+  ExactParams p;
+  p.x = a.x; p.sB = a.sB; p.sT = a.sT; p.sV = a.sV; p.logprobs = a.logprobs;
+  p.targets = a.targets; p.tgt_stride = a.tgt_stride; p.x_len = a.x_len; p.t_len = a.t_len;
+  p.B = a.B; p.T = a.T; p.V = a.V; p.Smax = a.Smax; p.Lmax = 2 * a.Smax + 1; p.blank = a.blank;
+  p.losses = a.losses; p.grads = a.grads;
+  p.ws_alpha = reinterpret_cast<double*>(a.ws);
+  p.ws_lse = reinterpret_cast<double*>(reinterpret_cast<char*>(a.ws) +
+                                       align_up((size_t)a.B * a.T * p.Lmax * sizeof(double), 256));
+  if (a.B == 0) return E2E_OK;
+  if (a.dtype == E2E_F32) {
+    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_exact_kernel<float>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+    hipLaunchKernelGGL(ctc_exact_kernel<float>, dim3(a.B), dim3(kThreads), lds, a.stream, p);
+  } else {
+    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_exact_kernel<double>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+    hipLaunchKernelGGL(ctc_exact_kernel<double>, dim3(a.B), dim3(kThreads), lds, a.stream, p);
+  }
+  E2E_HIP_CHECK(hipGetLastError(), "ctc_exact_kernel launch");
+  return E2E_OK;
+}
+
+}  // namespace e2e

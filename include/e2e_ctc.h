@@ -1,0 +1,142 @@
+/*
+ * e2e_ctc.h -- C ABI of the MI355X-native CTC loss-and-decode library
+ * (libe2e_ctc.so, built from end2end_amd/csrc/ with hipcc --offload-arch=gfx950).
+ *
+ * This is the drop-in boundary for the hot path of artbataev/end2end: every
+ * entry point replaces one method of the reference's pybind11 engines
+ * (citations are file:line in the reference tree).  Plain pointers and sizes
+ * only; no torch / pybind types.  All data pointers are DEVICE pointers on the
+ * current HIP device unless a parameter says "host".  Every call is
+ * asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null
+ * stream), allocates nothing and never synchronises, so it can be captured in
+ * a hipGraph; the caller owns every buffer.
+ *
+ * Return value: 0 on success, a negative E2E_ERR_* code otherwise;
+ * e2e_last_error() then returns a thread-local message.  No C++ exception
+ * crosses this boundary.
+ */
+#ifndef E2E_CTC_H
+#define E2E_CTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E2E_CTC_ABI_VERSION 1
+
+/* element types of the logits / log-prob tensor (losses and grads use the same) */
+#define E2E_F32 0
+#define E2E_F64 1
+
+#define E2E_OK 0
+#define E2E_ERR_ARG (-1)          /* bad argument (null pointer, bad size/dtype) */
+#define E2E_ERR_UNSUPPORTED (-2)  /* shape outside what the kernels support */
+#define E2E_ERR_WORKSPACE (-3)    /* workspace too small */
+#define E2E_ERR_HIP (-4)          /* a HIP launch / runtime call failed */
+#define E2E_ERR_IO (-5)           /* LM file could not be read / parsed (host) */
+
+/* which CTC loss algorithm to run */
+#define E2E_ALGO_AUTO 0    /* fast scaled path for f32 where valid, exact otherwise */
+#define E2E_ALGO_EXACT 1   /* f64 log-domain lattice, the reference's arithmetic */
+#define E2E_ALGO_FAST 2    /* scaled linear-domain lattice, flags invalid utterances */
+
+int e2e_ctc_abi_version(void);
+const char* e2e_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * CTC loss forward + backward.
+ * Replaces cpp_ctc_loss.CTCLossEngine(blank_idx).compute(logits, targets,
+ * logits_lengths, targets_lengths) -> (losses[B], grads[B,T,V])
+ *   src/losses/ctc_loss_py.cpp:8-16, src/losses/forward_backward.cpp:7-59,
+ *   src/losses/ctc_loss.cpp:15-118.
+ *
+ *   x            (B,T,V) tensor with element strides sB,sT,sV (a time-major
+ *                permuted view is fine); dtype E2E_F32 / E2E_F64
+ *   input_is_logprobs
+ *                1: x holds log-probabilities -- exactly the reference engine:
+ *                   grads = exp(x) - posterior over the full (T,V) slab, rows
+ *                   t >= x_len[b] come out as exp(x) (reference quirk Q1);
+ *                0: x holds raw logits; log_softmax(dim=V) is fused in and
+ *                   grads are d loss / d logits (= softmax - posterior for
+ *                   t < x_len[b], 0 for padded rows), i.e. what
+ *                   pytorch_end2end/modules/ctc_loss.py:37-40 + autograd give.
+ *   targets      (B,*) int64, row stride tgt_stride, first t_len[b] entries used
+ *   x_len,t_len  (B) int64 (1 <= x_len[b] <= T, 0 <= t_len[b] <= Smax)
+ *   losses       (B)  same dtype as x;  +inf for an infeasible alignment (Q2)
+ *   grads        (B,T,V) contiguous, same dtype as x; NaN slab when infeasible
+ *   workspace    >= e2e_ctc_loss_workspace_bytes(...) bytes, 256-B aligned
+ *   algo         E2E_ALGO_*
+ */
+size_t e2e_ctc_loss_workspace_bytes(int B, int T, int V, int Smax, int dtype, int algo);
+
+int e2e_ctc_loss_fwd_bwd(const void* x, int dtype, int input_is_logprobs,
+                         int64_t sB, int64_t sT, int64_t sV,
+                         const int64_t* targets, int64_t tgt_stride,
+                         const int64_t* x_len, const int64_t* t_len,
+                         int B, int T, int V, int Smax, int blank,
+                         void* losses, void* grads,
+                         void* workspace, size_t workspace_bytes,
+                         int algo, void* stream);
+
+/* grads[b,:,:] *= scale[b]  in place (the multiply of
+ * pytorch_end2end/functions/forward_backward.py:34 without a second tensor). */
+int e2e_ctc_scale_grads(void* grads, int dtype, const void* scale /* (B) same dtype */,
+                        int B, int64_t row_elems /* T*V */, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Greedy decode.  Replaces cpp_ctc_decoder.CTCDecoder.decode_greedy
+ *   src/decoders/ctc_decoder.cpp:443-490 (argmax + blank/repeat collapse).
+ *   x        (B,T,V) logits or log-probs, strides sB,sT,sV, f32/f64
+ *   x_len    (B) int64
+ *   out      (B,T) int64, written zero-padded on the right (quirk Q5)
+ *   out_len  (B) int64
+ */
+int e2e_ctc_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV,
+                   const int64_t* x_len, int B, int T, int V, int blank,
+                   int64_t* out, int64_t* out_len, void* stream);
+
+/* ------------------------------------------------------------------------
+ * n-gram language model (stands where KenLM's ProbingModel stands in the
+ * reference: src/decoders/ctc_decoder.cpp:60-71 load, :77-88 get_idx,
+ * :275-278,:291-294 BaseScore).  Host-side ARPA reader (plain or .gz) that
+ * builds a device-resident hash table.  `labels` are the decoder's V label
+ * strings (UTF-8): words are spelled with them.
+ */
+typedef struct e2e_lm e2e_lm;
+int e2e_lm_load_arpa(const char* path /* host */, const char* const* labels /* host */, int V,
+                     int case_sensitive, e2e_lm** out);
+void e2e_lm_free(e2e_lm* lm);
+int e2e_lm_order(const e2e_lm* lm);
+/* host-side scoring helpers (testing / print_scores_for_sentence,
+ * src/decoders/ctc_decoder.cpp:141-151): word index (0 = <unk>) and
+ * log10 p(word | most-recent-first context ids). */
+uint32_t e2e_lm_word_index(const e2e_lm* lm, const char* word /* host */);
+double e2e_lm_score(const e2e_lm* lm, const uint32_t* ctx /* host */, int ctx_len, uint32_t word);
+
+/* ------------------------------------------------------------------------
+ * Prefix beam search.  Replaces cpp_ctc_decoder.CTCDecoder.decode
+ *   src/decoders/ctc_decoder.cpp:153-201 (driver), :353-441 (decode_sentence),
+ *   :247-312 (get_next_prefix), :314-318 (score).
+ *   lp        (B,T,V) LOG-PROBABILITIES, strides sB,sT,sV, f32/f64
+ *   space_id  index of " " among the labels, or -1 (:55-59)
+ *   lm        NULL for none (lmwt then counts as 0, :72-74)
+ *   out       (B,max_out) int64, zero-filled; out_len (B) int64.  When the
+ *             empty prefix wins the result is the single id -1 (quirk Q6).
+ *   workspace >= e2e_ctc_beam_workspace_bytes(...)
+ */
+size_t e2e_ctc_beam_workspace_bytes(int B, int T, int V, int beam_width);
+
+int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, int64_t sV,
+                 const int64_t* x_len, int B, int T, int V, int blank,
+                 int beam_width, int space_id, const e2e_lm* lm,
+                 double lmwt, double wip, double oov_penalty,
+                 int64_t* out, int64_t max_out, int64_t* out_len,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E2E_CTC_H */

@@ -1,0 +1,69 @@
+"""Helpers for the -m gpu parity tests: raw C-ABI calls on device tensors."""
+import numpy as np
+import torch
+
+from end2end_amd import _lib
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_AUTO):
+    """x: torch tensor (B,T,V) on any device with any strides (moved to the GPU keeping its layout)."""
+    L = _lib.load()
+    d = dev()
+    if not x.is_cuda:
+        # keep the stride pattern: move the underlying storage then re-view
+        base = x
+        x = torch.empty_strided(base.shape, base.stride(), dtype=base.dtype, device=d)
+        x.copy_(base)
+    B, T, V = x.shape
+    targets = torch.as_tensor(np.asarray(targets)).to(d, torch.long).reshape(B, -1).contiguous()
+    if targets.shape[1] == 0:
+        targets = torch.zeros((B, 1), dtype=torch.long, device=d)
+    xl = torch.as_tensor(np.asarray(x_len)).to(d, torch.long)
+    tl = torch.as_tensor(np.asarray(t_len)).to(d, torch.long)
+    Smax = targets.shape[1]
+    losses = torch.full((B,), 7.0, dtype=x.dtype, device=d)
+    grads = torch.full((B, T, V), 7.0, dtype=x.dtype, device=d)
+    code = _lib.dtype_code(x.dtype)
+    n = L.e2e_ctc_loss_workspace_bytes(B, T, V, Smax, code, algo)
+    ws = torch.empty(n, dtype=torch.uint8, device=d)
+    sB, sT, sV = x.stride()
+    _lib.check(L.e2e_ctc_loss_fwd_bwd(x.data_ptr(), code, 1 if logprobs else 0, sB, sT, sV,
+                                      targets.data_ptr(), targets.stride(0), xl.data_ptr(), tl.data_ptr(),
+                                      B, T, V, Smax, blank, losses.data_ptr(), grads.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), algo, _lib.stream_ptr(d)))
+    torch.cuda.synchronize()
+    return losses.cpu().numpy(), grads.cpu().numpy()
+
+
+def c_abi_greedy(x, x_len, blank=0):
+    L = _lib.load()
+    d = dev()
+    if not x.is_cuda:
+        base = x
+        x = torch.empty_strided(base.shape, base.stride(), dtype=base.dtype, device=d)
+        x.copy_(base)
+    B, T, V = x.shape
+    xl = torch.as_tensor(np.asarray(x_len)).to(d, torch.long)
+    out = torch.full((B, T), -7, dtype=torch.long, device=d)
+    out_len = torch.full((B,), -7, dtype=torch.long, device=d)
+    sB, sT, sV = x.stride()
+    _lib.check(L.e2e_ctc_greedy(x.data_ptr(), _lib.dtype_code(x.dtype), sB, sT, sV, xl.data_ptr(),
+                                B, T, V, blank, out.data_ptr(), out_len.data_ptr(), _lib.stream_ptr(d)))
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), out_len.cpu().numpy()
+
+
+def assert_same(got, want, rtol, atol, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), what + ": NaN pattern differs"
+    inf = np.isinf(want)
+    assert np.array_equal(np.isinf(got), inf), what + ": inf pattern differs"
+    assert np.array_equal(got[inf], want[inf]), what
+    ok = ~(np.isnan(want) | inf)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=rtol, atol=atol, err_msg=what)

@@ -1,0 +1,143 @@
+"""-m gpu: HIP CTC loss/grad through the C ABI against the golden fixtures and the oracle.
+
+Tolerances: north_star asks for 1e-4 relative in fp32; f64 inputs must track the reference's f64
+arithmetic (gradcheck, tests/test_ctc.py:168-191) and are held to 1e-9.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+import oracle_lib as O
+import gpu_util as U
+from end2end_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+F32_RTOL, F32_ATOL = 1e-4, 2e-6
+F64_RTOL, F64_ATOL = 1e-9, 1e-12
+ALGOS = [_lib.ALGO_AUTO, _lib.ALGO_EXACT]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("m", G.meta()["engine"], ids=lambda m: m["name"])
+def test_engine_fixtures(m, algo):
+    c = G.engine_case(m["name"])
+    lp = torch.from_numpy(c["lp"])
+    if m["name"].startswith("permuted_view"):
+        lp = lp.permute(1, 0, 2).contiguous().permute(1, 0, 2)     # non-contiguous (B,T,V) view
+    losses, grads = U.c_abi_loss(lp, c["targets"], c["x_len"], c["t_len"], m["blank"], True, algo)
+    rt, at = (F64_RTOL, F64_ATOL) if m["dtype"] == "float64" else (F32_RTOL, F32_ATOL)
+    U.assert_same(losses, c["losses"], rt, at, m["name"] + " losses")
+    U.assert_same(grads, c["grads"], rt, at, m["name"] + " grads")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("case", G.known_answers()["loss"], ids=lambda c: c["name"])
+def test_known_answer_costs(case, algo):
+    lp, tg, xl, tl, blank, cost = G.known_loss_inputs(case)
+    losses, _ = U.c_abi_loss(torch.from_numpy(lp.astype(np.float32)), tg, xl, tl, blank, True, algo)
+    assert round(abs(float(losses.astype(np.float64).sum()) - cost), 5) == 0
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_fused_logits_equals_logsoftmax_then_engine(dtype, algo):
+    g = torch.Generator().manual_seed(21)
+    B, T, V, S = 5, 61, 13, 14
+    x = torch.randn(B, T, V, generator=g, dtype=torch.float64).to(dtype)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl = torch.tensor([61, 50, 33, 61, 29])
+    tl = torch.tensor([14, 9, 0, 11, 14])
+    losses, grads = U.c_abi_loss(x, tg, xl, tl, 0, False, algo)
+    lp = torch.log_softmax(x.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0.0            # what autograd through log_softmax leaves on padded frames
+    rt, at = (F64_RTOL, F64_ATOL) if dtype == torch.float64 else (F32_RTOL, F32_ATOL)
+    U.assert_same(losses, l_o, rt, at, "losses")
+    U.assert_same(grads, g_o, rt, at, "grads")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_c2_shape_sample_against_oracle(algo):
+    # the headline shape (T=1000, V=29, S in [100,200]) on a few utterances the oracle finishes in seconds
+    g = torch.Generator().manual_seed(0)
+    B, T, V, S = 6, 1000, 29, 200
+    x = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tl = torch.randint(S // 2, S + 1, (B,), generator=g)
+    tl[0] = S
+    xl = torch.tensor([T, T, T - 37, T, 640, T])
+    losses, grads = U.c_abi_loss(x, tg, xl, tl, 0, False, algo)
+    lp = torch.log_softmax(x.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0.0
+    U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_wide_alphabet_sample_against_oracle(algo):
+    # C5-like: V=8000, S<=64, T=256 on two utterances
+    g = torch.Generator().manual_seed(5)
+    B, T, V, S = 2, 256, 8000, 64
+    x = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tg[1, 3] = tg[1, 4]       # a repeat
+    tl = torch.tensor([64, 40])
+    xl = torch.tensor([256, 200])
+    losses, grads = U.c_abi_loss(x, tg, xl, tl, 0, False, algo)
+    lp = torch.log_softmax(x.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0.0
+    U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads, g_o, F32_RTOL, 1e-7, "grads")
+
+
+def test_full_c2_properties():
+    # full BASELINE size: size-independent properties (the oracle would take minutes here)
+    g = torch.Generator().manual_seed(0)
+    B, T, V, S = 256, 1000, 29, 200
+    x = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tl = torch.randint(S // 2, S + 1, (B,), generator=g)
+    xl = torch.randint(T // 2, T + 1, (B,), generator=g)
+    xl[:128] = T
+    losses, grads = U.c_abi_loss(x, tg, xl, tl, 0, False)
+    assert np.isfinite(losses).all() and (losses > 0).all()
+    # rows of softmax - posterior sum to zero on valid frames and are exactly zero on padded frames
+    rs = np.abs(grads.astype(np.float64).sum(-1))
+    assert rs.max() < 5e-5
+    for b in (0, 130, 200, 255):
+        assert not grads[b, xl[b]:].any()
+    # the posterior mass of the blank+labels is one per frame and never negative beyond rounding
+    sm = torch.softmax(x.double(), -1).numpy()
+    post = sm - grads
+    for b in (0, 130, 255):
+        n = int(xl[b])
+        assert post[b, :n].min() > -1e-5
+        np.testing.assert_allclose(post[b, :n].sum(-1), 1.0, atol=1e-4)
+    # spot check eight utterances against the oracle
+    idx = [0, 1, 127, 128, 129, 200, 254, 255]
+    lp = torch.log_softmax(x[idx].double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg[idx].numpy(), xl[idx].numpy(), tl[idx].numpy(), 0)
+    for k, b in enumerate(idx):
+        g_o[k, xl[b]:] = 0.0
+    U.assert_same(losses[idx], l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads[idx], g_o, F32_RTOL, F32_ATOL, "grads")
+
+
+def test_invalid_lengths_poison_not_crash():
+    x = torch.randn(3, 5, 4)
+    losses, grads = U.c_abi_loss(x, [[1, 2], [1, 2], [1, 2]], [5, 0, 9], [2, 2, 2], 0, False)
+    assert np.isfinite(losses[0]) and np.isnan(losses[1]) and np.isnan(losses[2])
+    assert np.isnan(grads[1]).all() and np.isnan(grads[2]).all() and np.isfinite(grads[0]).all()
+
+
+def test_argument_errors_are_reported():
+    L = _lib.load()
+    rc = L.e2e_ctc_loss_fwd_bwd(None, 5, 1, 1, 1, 1, None, 0, None, None, 1, 1, 1, 0, 0, None, None, None, 0, 0, None)
+    assert rc == -1 and b"dtype" in L.e2e_last_error()
