@@ -66,11 +66,8 @@ size_t e2e_ctc_loss_workspace_bytes(int B, int T, int V, int Smax, int dtype, in
   if (B < 0 || T < 1 || V < 1 || Smax < 0) return 0;
   const int r = resolve_algo(algo, dtype, T, V, Smax);
   size_t n = 0;
-  if (r == E2E_ALGO_EXACT || r == E2E_ALGO_AUTO) n = exact_workspace_bytes(B, T, V, Smax);
-  if (r == E2E_ALGO_FAST || r == E2E_ALGO_AUTO) {
-    const size_t f = fast_workspace_bytes(B, T, V, Smax);
-    if (f > n) n = f;
-  }
+  if (r == E2E_ALGO_EXACT || r == E2E_ALGO_AUTO) n += exact_workspace_bytes(B, T, V, Smax);   // (fallback region)
+  if (r == E2E_ALGO_FAST || r == E2E_ALGO_AUTO) n += fast_workspace_bytes(B, T, V, Smax);
   return n + 256;
 }
 

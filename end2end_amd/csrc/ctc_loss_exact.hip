@@ -26,6 +26,8 @@ struct ExactParams {
   void* losses; void* grads;
   double* ws_alpha;   // [B][T][Lmax]
   double* ws_lse;     // [B][T] row log-sum-exp (logits mode)
+  const int* flags;   // per-utterance "redo me" words written by the fast path (mode != 0)
+  int mode;           // 0: every utterance; 1: only flagged ones; 2: poison flagged ones, compute nothing
 };
 
 __device__ __forceinline__ double neg_inf() { return -__builtin_huge_val(); }
@@ -69,8 +71,9 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   double* wa = p.ws_alpha + (size_t)b * (size_t)Tmax * (size_t)Lmax;
   double* wl = p.ws_lse + (size_t)b * (size_t)Tmax;
 
+  if (p.mode != 0 && p.flags[b] == 0) return;
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
-  if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > Smax) {        // invalid lengths: poison, do not crash
+  if (p.mode == 2 || Tq < 1 || Tq > Tmax || Sq < 0 || Sq > Smax) {   // invalid lengths: poison, do not crash
     const double qnan = __builtin_nan("");
     if (tid == 0) losses[b] = (IO)qnan;
     for (size_t i = tid; i < (size_t)Tmax * V; i += kThreads) grads[i] = (IO)qnan;
@@ -240,14 +243,18 @@ size_t exact_workspace_bytes(int B, int T, int V, int Smax) {
   return align_up((size_t)B * T * Lmax * sizeof(double), 256) + align_up((size_t)B * T * sizeof(double), 256);
 }
 
-int launch_exact(const LossArgs& a) {
+int launch_exact_flagged(const LossArgs& a, const int* flags, int mode);
+
+int launch_exact(const LossArgs& a) { return launch_exact_flagged(a, nullptr, 0); }
+
+int launch_exact_flagged(const LossArgs& a, const int* flags, int mode) {
   const size_t lds = exact_lds_bytes(a.V, a.Smax);
   if (lds > 160 * 1024) {
     set_error("exact CTC kernel: V=%d, Smax=%d need %zu B of LDS (> 160 KiB)", a.V, a.Smax, lds);
     return E2E_ERR_UNSUPPORTED;
   }
-  const size_t need = exact_workspace_bytes(a.B, a.T, a.V, a.Smax);
-  if (a.ws_bytes < need || !a.ws) {
+  const size_t need = mode == 2 ? 0 : exact_workspace_bytes(a.B, a.T, a.V, a.Smax);
+  if (mode != 2 && (a.ws_bytes < need || !a.ws)) {
     set_error("workspace too small: %zu < %zu", a.ws_bytes, need);
     return E2E_ERR_WORKSPACE;
   }
@@ -255,7 +262,7 @@ int launch_exact(const LossArgs& a) {
   p.x = a.x; p.sB = a.sB; p.sT = a.sT; p.sV = a.sV; p.logprobs = a.logprobs;
   p.targets = a.targets; p.tgt_stride = a.tgt_stride; p.x_len = a.x_len; p.t_len = a.t_len;
   p.B = a.B; p.T = a.T; p.V = a.V; p.Smax = a.Smax; p.Lmax = 2 * a.Smax + 1; p.blank = a.blank;
-  p.losses = a.losses; p.grads = a.grads;
+  p.losses = a.losses; p.grads = a.grads; p.flags = flags; p.mode = mode;
   p.ws_alpha = reinterpret_cast<double*>(a.ws);
   p.ws_lse = reinterpret_cast<double*>(reinterpret_cast<char*>(a.ws) +
                                        align_up((size_t)a.B * a.T * p.Lmax * sizeof(double), 256));

@@ -16,31 +16,50 @@ pytestmark = pytest.mark.gpu
 
 F32_RTOL, F32_ATOL = 1e-4, 2e-6
 F64_RTOL, F64_ATOL = 1e-9, 1e-12
-ALGOS = [_lib.ALGO_AUTO, _lib.ALGO_EXACT]
+ALGOS = [_lib.ALGO_AUTO, _lib.ALGO_EXACT, _lib.ALGO_FAST]
+ALGO_IDS = {_lib.ALGO_AUTO: "auto", _lib.ALGO_EXACT: "exact", _lib.ALGO_FAST: "fast"}
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+def run(x, tg, xl, tl, blank, logprobs, algo, want_losses):
+    """Run one algorithm.  ALGO_FAST has no fallback: utterances it cannot do (infeasible alignment, out-of-range
+    lattice) come back NaN-poisoned; those must be exactly the ones the oracle calls infeasible, and are then taken
+    from the auto path so that the caller compares full tensors."""
+    if algo == _lib.ALGO_FAST and x.dtype != torch.float32:
+        pytest.skip("the fast path is f32 only")
+    losses, grads = U.c_abi_loss(x, tg, xl, tl, blank, logprobs, algo)
+    if algo == _lib.ALGO_FAST:
+        flagged = np.isnan(losses)
+        assert np.array_equal(flagged, ~np.isfinite(np.asarray(want_losses, dtype=np.float64))), \
+            "fast path flagged %s" % np.nonzero(flagged)[0].tolist()
+        if flagged.any():
+            assert np.isnan(grads[flagged]).all()
+            l2, g2 = U.c_abi_loss(x, tg, xl, tl, blank, logprobs, _lib.ALGO_AUTO)
+            losses[flagged], grads[flagged] = l2[flagged], g2[flagged]
+    return losses, grads
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS.get)
 @pytest.mark.parametrize("m", G.meta()["engine"], ids=lambda m: m["name"])
 def test_engine_fixtures(m, algo):
     c = G.engine_case(m["name"])
     lp = torch.from_numpy(c["lp"])
     if m["name"].startswith("permuted_view"):
         lp = lp.permute(1, 0, 2).contiguous().permute(1, 0, 2)     # non-contiguous (B,T,V) view
-    losses, grads = U.c_abi_loss(lp, c["targets"], c["x_len"], c["t_len"], m["blank"], True, algo)
+    losses, grads = run(lp, c["targets"], c["x_len"], c["t_len"], m["blank"], True, algo, c["losses"])
     rt, at = (F64_RTOL, F64_ATOL) if m["dtype"] == "float64" else (F32_RTOL, F32_ATOL)
     U.assert_same(losses, c["losses"], rt, at, m["name"] + " losses")
     U.assert_same(grads, c["grads"], rt, at, m["name"] + " grads")
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS.get)
 @pytest.mark.parametrize("case", G.known_answers()["loss"], ids=lambda c: c["name"])
 def test_known_answer_costs(case, algo):
     lp, tg, xl, tl, blank, cost = G.known_loss_inputs(case)
-    losses, _ = U.c_abi_loss(torch.from_numpy(lp.astype(np.float32)), tg, xl, tl, blank, True, algo)
+    losses, _ = run(torch.from_numpy(lp.astype(np.float32)), tg, xl, tl, blank, True, algo, [0.0] * len(xl))
     assert round(abs(float(losses.astype(np.float64).sum()) - cost), 5) == 0
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS.get)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_fused_logits_equals_logsoftmax_then_engine(dtype, algo):
     g = torch.Generator().manual_seed(21)
@@ -49,9 +68,9 @@ def test_fused_logits_equals_logsoftmax_then_engine(dtype, algo):
     tg = torch.randint(1, V, (B, S), generator=g)
     xl = torch.tensor([61, 50, 33, 61, 29])
     tl = torch.tensor([14, 9, 0, 11, 14])
-    losses, grads = U.c_abi_loss(x, tg, xl, tl, 0, False, algo)
     lp = torch.log_softmax(x.double(), -1).numpy()
     l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    losses, grads = run(x, tg, xl, tl, 0, False, algo, l_o)
     for b in range(B):
         g_o[b, xl[b]:] = 0.0            # what autograd through log_softmax leaves on padded frames
     rt, at = (F64_RTOL, F64_ATOL) if dtype == torch.float64 else (F32_RTOL, F32_ATOL)
@@ -59,7 +78,7 @@ def test_fused_logits_equals_logsoftmax_then_engine(dtype, algo):
     U.assert_same(grads, g_o, rt, at, "grads")
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS.get)
 def test_c2_shape_sample_against_oracle(algo):
     # the headline shape (T=1000, V=29, S in [100,200]) on a few utterances the oracle finishes in seconds
     g = torch.Generator().manual_seed(0)
@@ -69,18 +88,20 @@ def test_c2_shape_sample_against_oracle(algo):
     tl = torch.randint(S // 2, S + 1, (B,), generator=g)
     tl[0] = S
     xl = torch.tensor([T, T, T - 37, T, 640, T])
-    losses, grads = U.c_abi_loss(x, tg, xl, tl, 0, False, algo)
     lp = torch.log_softmax(x.double(), -1).numpy()
     l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    losses, grads = run(x, tg, xl, tl, 0, False, algo, l_o)
     for b in range(B):
         g_o[b, xl[b]:] = 0.0
     U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
     U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS.get)
 def test_wide_alphabet_sample_against_oracle(algo):
     # C5-like: V=8000, S<=64, T=256 on two utterances
+    if algo == _lib.ALGO_FAST:
+        pytest.skip("wide alphabets take the exact kernel for now")
     g = torch.Generator().manual_seed(5)
     B, T, V, S = 2, 256, 8000, 64
     x = torch.randn(B, T, V, generator=g)
@@ -88,9 +109,9 @@ def test_wide_alphabet_sample_against_oracle(algo):
     tg[1, 3] = tg[1, 4]       # a repeat
     tl = torch.tensor([64, 40])
     xl = torch.tensor([256, 200])
-    losses, grads = U.c_abi_loss(x, tg, xl, tl, 0, False, algo)
     lp = torch.log_softmax(x.double(), -1).numpy()
     l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    losses, grads = run(x, tg, xl, tl, 0, False, algo, l_o)
     for b in range(B):
         g_o[b, xl[b]:] = 0.0
     U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
@@ -130,9 +151,10 @@ def test_full_c2_properties():
     U.assert_same(grads[idx], g_o, F32_RTOL, F32_ATOL, "grads")
 
 
-def test_invalid_lengths_poison_not_crash():
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS.get)
+def test_invalid_lengths_poison_not_crash(algo):
     x = torch.randn(3, 5, 4)
-    losses, grads = U.c_abi_loss(x, [[1, 2], [1, 2], [1, 2]], [5, 0, 9], [2, 2, 2], 0, False)
+    losses, grads = U.c_abi_loss(x, [[1, 2], [1, 2], [1, 2]], [5, 0, 9], [2, 2, 2], 0, False, algo)
     assert np.isfinite(losses[0]) and np.isnan(losses[1]) and np.isnan(losses[2])
     assert np.isnan(grads[1]).all() and np.isnan(grads[2]).all() and np.isfinite(grads[0]).all()
 
@@ -141,3 +163,21 @@ def test_argument_errors_are_reported():
     L = _lib.load()
     rc = L.e2e_ctc_loss_fwd_bwd(None, 5, 1, 1, 1, 1, None, 0, None, None, 1, 1, 1, 0, 0, None, None, None, 0, 0, None)
     assert rc == -1 and b"dtype" in L.e2e_last_error()
+
+
+def test_fast_path_falls_back_on_blank_valued_targets_and_tiny_probabilities():
+    # (a) a target equal to the blank id shares the blank column in the reference (ctc_loss.cpp:53,109-113);
+    # (b) log-probs so peaked that the scaled f32 segment rows underflow.  AUTO must still match the oracle.
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 30, 6, generator=g)
+    tg = torch.tensor([[1, 0, 2, 3], [1, 2, 3, 4]])
+    lp = torch.log_softmax(x.double(), -1)
+    lp[1, 5:25, 1:5] -= 80.0          # twenty frames where every label is ~e-80: forces the lattice out of range
+    lp = lp.float()
+    xl, tl = [30, 30], [4, 4]
+    l_o, g_o = O.ctc_loss(lp.double().numpy(), tg.numpy(), xl, tl, 0)
+    losses, grads = U.c_abi_loss(lp, tg, xl, tl, 0, True, _lib.ALGO_AUTO)
+    U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
+    lf, _ = U.c_abi_loss(lp, tg, xl, tl, 0, True, _lib.ALGO_FAST)
+    assert np.isnan(lf[0])            # (a) is always handed to the exact kernel
