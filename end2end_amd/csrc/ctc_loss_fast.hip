@@ -22,6 +22,8 @@
 //     targets that contain the blank id.
 //
 // Reference semantics restated: src/losses/ctc_loss.cpp:33-117 (recurrences, loss, gradient).
+#include <type_traits>
+
 #include "common.h"
 
 // the scaled lattice is not bit-pinned to the reference: let the compiler fuse multiply-adds here
@@ -92,24 +94,60 @@ __device__ __forceinline__ int wave_max(int v) {
   v = max(v, __shfl_xor(v, 32, 64));
   return v;
 }
-// reductions inside aligned groups of G lanes (G = 2..64, power of two)
-template <int G>
-__device__ __forceinline__ float group_max(float v) {
-  for (int o = 1; o < G; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// inclusive prefix sum over the 64 lanes, all DPP
+__device__ __forceinline__ float wave_scan(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));   // row_shr:1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));   // row_shr:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));   // row_shr:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));   // row_shr:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast:15
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));  // row_bcast:31
   return v;
 }
-template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-  for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ int wave_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
   return v;
 }
 
+// all-reduce inside each 16-lane DPP row (pure VALU, no LDS crossbar)
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, __int_as_float(dpp_i<0xB1>(0, __float_as_int(v))));
+  v = fmaxf(v, __int_as_float(dpp_i<0x4E>(0, __float_as_int(v))));
+  v = fmaxf(v, __int_as_float(dpp_i<0x141>(0, __float_as_int(v))));
+  v = fmaxf(v, __int_as_float(dpp_i<0x140>(0, __float_as_int(v))));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(dpp_i<0xB1>(0, __float_as_int(v)));
+  v += __int_as_float(dpp_i<0x4E>(0, __float_as_int(v)));
+  v += __int_as_float(dpp_i<0x141>(0, __float_as_int(v)));
+  v += __int_as_float(dpp_i<0x140>(0, __float_as_int(v)));
+  return v;
+}
+
+// Hand-off words live in LDS and guard LDS data only.  The LDS executes one wave's operations in order, so the
+// producer needs no wait between its data writes and the flag write, and the consumer only has to keep the
+// compiler from hoisting its data reads above the flag read.  (A workgroup-scope release fence would also drain
+// the wave's outstanding GLOBAL stores -- checkpoints, probability rows -- once per 8-step block.)
+#ifdef E2E_FAST_PROFILE
+} __device__ unsigned long long g_prof[256 * 4 * 4]; namespace {   // [wg][wave][total, spin, nspin, -]
+#define PROF_SPIN_BEGIN unsigned long long _t0 = __builtin_amdgcn_s_memtime();
+#define PROF_SPIN_END(acc) acc += __builtin_amdgcn_s_memtime() - _t0;
+#else
+#define PROF_SPIN_BEGIN
+#define PROF_SPIN_END(acc)
+#endif
 __device__ __forceinline__ void spin_until(volatile int* p, int want) {
   while (*p != want) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void publish(volatile int* p, int v) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   *p = v;
 }
 
@@ -151,83 +189,133 @@ struct LaneCells {
 };
 
 // ============================================================================================
-// F1: the two serial chains
+// F1 device code
 // ============================================================================================
-template <int PPL>
-__global__ __launch_bounds__(256) void ctc_fast_chain_kernel(FastParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int NC = 2 * PPL;                     // cells per lane
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int V = p.V, blank = p.blank, ROW = V + 1;   // column V of every row is 0
-  double* ring = reinterpret_cast<double*>(smem);                  // [2][kRingBlks*kBlk][ROW]
-  volatile int* filled = reinterpret_cast<volatile int*>(ring + 2 * kRingBlks * kBlk * ROW);  // [2][kRingBlks]
-  volatile int* freed = filled + 2 * kRingBlks;                    // [2][kRingBlks]
+// Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
+// absolute time (t = 8m .. 8m+7), so that the rescale phase of a step is its position in the block:
+//   alpha: block n covers t = 8n + tt;              beta: block n covers t = 8(M-n) + 7 - tt,  M = (T-1)/8
+// (beta's first block may start with rows t >= T, which are dead).
+__device__ __forceinline__ int block_time(int dir, int n, int tt, int T) {
+  return dir == 0 ? n * kBlk + tt : (((T - 1) >> 3) - n) * kBlk + 7 - tt;
+}
 
-  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
-  const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
-  if (bad) {                       // the exact kernel poisons this utterance
-    if (tid == 0) { p.flags[b] = 1; p.losses[b] = __builtin_nanf(""); }   // reason bit 0: bad lengths
-    return;
-  }
-  const int T = (int)Tq, S = (int)Sq, L = 2 * S + 1;
-  if (tid < 2 * 2 * kRingBlks) const_cast<int*>(filled)[tid] = 0;
-  __syncthreads();
+// exp(x) for x <= ~0 (softmax numerators, log-probabilities): two-constant range reduction + v_exp_f32 + ldexp,
+// ~1 ulp like expf but without its overflow / underflow selects (ldexp saturates to 0 by itself).
+__device__ __forceinline__ float exp_le0(float x) {
+  x = fmaxf(x, -200.f);                                    // -inf (padding, log 0) -> exactly 0 instead of NaN
+  const float t = x * 1.44269504088896340736f;
+  const float n = rintf(t);
+  float f = fmaf(x, 1.44269504088896340736f, -n);          // exact product residual
+  f = fmaf(x, 1.92596299112661746e-8f, f);                 // log2(e) low part
+  return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
 
-  const int dir = wid & 1;                                  // 0 alpha (forward), 1 beta (backward)
+// Probability rows for one chain: each 16-lane DPP row of the wave takes one time step (4 steps per pass), a
+// lane holds the columns v = l16 + 16k, k < NV = ceil(V/16); max / sum by row-wide DPP all-reduce.
+template <int NV>
+__device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int dir, double* ring,
+                                          volatile int* filled, volatile int* freed, int lane) {
+  const int V = p.V, ROW = V + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
   double* myring = ring + (size_t)dir * kRingBlks * kBlk * ROW;
   volatile int* myfilled = filled + dir * kRingBlks;
   volatile int* myfreed = freed + dir * kRingBlks;
   const float* x = p.x + (int64_t)b * p.sB;
-
-  if (wid >= 2) {
-    // ---------------- prep wave: probability rows into the ring ----------------
-    // VP lanes per row (next power of two >= V), RPP rows per pass
-    int VP = 2; while (VP < V) VP <<= 1;
-    const int RPP = 64 / VP, grp = lane / VP, v = lane - grp * VP;
-    float* ytab = p.ytab + (size_t)b * p.T * V;
-    for (int n = 0; n < nblk; n++) {
-      const int slot = n % kRingBlks;
-      if (n >= kRingBlks) spin_until(&myfreed[slot], n - kRingBlks + 1);
-      for (int tt = grp; tt < kBlk; tt += RPP) {
-        const int sidx = n * kBlk + tt;
-        const int t = dir == 0 ? sidx : T - 1 - sidx;
-        const bool live = sidx < T && v < V;
-        const float xv = live ? x[(int64_t)t * p.sT + (int64_t)v * p.sV] : -__builtin_huge_valf();
-        float y;
-        if (p.logprobs) {
-          y = expf(xv);
-        } else {
-          float m = xv, e;
-          switch (VP) {   // group-wide softmax
-            case 2: m = group_max<2>(m); e = expf(xv - m); y = e / group_sum<2>(e); break;
-            case 4: m = group_max<4>(m); e = expf(xv - m); y = e / group_sum<4>(e); break;
-            case 8: m = group_max<8>(m); e = expf(xv - m); y = e / group_sum<8>(e); break;
-            case 16: m = group_max<16>(m); e = expf(xv - m); y = e / group_sum<16>(e); break;
-            case 32: m = group_max<32>(m); e = expf(xv - m); y = e / group_sum<32>(e); break;
-            default: m = group_max<64>(m); e = expf(xv - m); y = e / group_sum<64>(e); break;
-          }
-        }
-        if (live) {
-          myring[(size_t)(slot * kBlk + tt) * ROW + v] = (double)y;
-          if (dir == 0) ytab[(size_t)t * V + v] = y;
-        }
-        if (sidx < T && v == 0) myring[(size_t)(slot * kBlk + tt) * ROW + V] = 0.0;
-      }
-      if (lane == 0) publish(&myfilled[slot], n + 1); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  float* ytab = p.ytab + (size_t)b * p.T * V;
+  const int q = lane >> 4, l16 = lane & 15;
+  const float ninf = -__builtin_huge_valf();
+  constexpr int NP = kBlk / 4;      // passes per block
+  bool col_live[NV];
+  int64_t col_off[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) { col_live[k] = l16 + 16 * k < V; col_off[k] = (int64_t)(l16 + 16 * k) * p.sV; }
+  unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime();
+  (void)prof_spin; (void)prof_t0;
+  // the logits of block n+1 are requested before block n is worked on: an HBM miss (~1 us) would otherwise
+  // sit in front of every pass
+  auto load_block = [&](int n, float (&out)[NP][NV]) {
+#pragma unroll
+    for (int pass = 0; pass < NP; pass++) {
+      const int t = block_time(dir, n, pass * 4 + q, T);
+      const bool row_live = n < nblk && t < T;
+      const float* xr = x + (int64_t)(row_live ? t : 0) * p.sT;
+#pragma unroll
+      for (int k = 0; k < NV; k++) out[pass][k] = (row_live && col_live[k]) ? xr[col_off[k]] : ninf;
     }
-    return;
+  };
+  float xv[NP][NV];
+  load_block(0, xv);
+  for (int n = 0; n < nblk; n++) {
+    float xn[NP][NV];
+    load_block(n + 1, xn);
+    const int slot = n % kRingBlks;
+    if (n >= kRingBlks) { PROF_SPIN_BEGIN spin_until(&myfreed[slot], n - kRingBlks + 1); PROF_SPIN_END(prof_spin) }
+#pragma unroll
+    for (int pass = 0; pass < NP; pass++) {
+      const int tt = pass * 4 + q;
+      const int t = block_time(dir, n, tt, T);
+      const bool row_live = t < T;
+      float y[NV];
+      if (p.logprobs) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) y[k] = exp_le0(xv[pass][k]);
+      } else {
+        float m = xv[pass][0];
+#pragma unroll
+        for (int k = 1; k < NV; k++) m = fmaxf(m, xv[pass][k]);
+        m = row16_max(m);
+        float ssum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; k++) { y[k] = exp_le0(xv[pass][k] - m); ssum += y[k]; }
+        ssum = row16_sum(ssum);
+        float inv = __builtin_amdgcn_rcpf(ssum);
+        inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);        // one Newton step: ~0.5 ulp
+#pragma unroll
+        for (int k = 0; k < NV; k++) y[k] *= inv;
+      }
+      double* dst = myring + (size_t)(slot * kBlk + tt) * ROW;
+      float* yrow = ytab + (size_t)(row_live ? t : 0) * V;
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        if (row_live && col_live[k]) {
+          dst[l16 + 16 * k] = (double)y[k];
+          if (dir == 0) yrow[l16 + 16 * k] = y[k];
+        }
+      }
+      if (row_live && l16 == 0) dst[V] = 0.0;
+    }
+    publish(&myfilled[slot], n + 1);     // every lane stores the same word: no divergence, one LDS write
+#pragma unroll
+    for (int pass = 0; pass < NP; pass++)
+#pragma unroll
+      for (int k = 0; k < NV; k++) xv[pass][k] = xn[pass][k];
   }
+#ifdef E2E_FAST_PROFILE
+  if (lane == 0 && b < 256) { g_prof[(b * 4 + 2 + dir) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + 2 + dir) * 4 + 1] = prof_spin; }
+#endif
+}
 
-  // ---------------- chain wave ----------------
+// One serial chain (DIR 0: alpha forward, DIR 1: beta-with-emission backward).
+template <int PPL, int DIR>
+__device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, int S, double* ring,
+                                           volatile int* filled, volatile int* freed, int lane) {
+  constexpr int NC = 2 * PPL;
+  const int V = p.V, blank = p.blank, ROW = V + 1, L = 2 * S + 1;
+  const int nblk = (T + kBlk - 1) / kBlk;
+  double* myring = ring + (size_t)DIR * kRingBlks * kBlk * ROW;
+  volatile int* myfilled = filled + DIR * kRingBlks;
+  volatile int* myfreed = freed + DIR * kRingBlks;
   __builtin_amdgcn_s_setprio(3);
+  unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime();
+  (void)prof_spin; (void)prof_t0;
   LaneCells<PPL> lc;
   lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, lane);
   const double rr = (double)lc.r;
-  if (dir == 0 && __any(lc.has_blank_label)) { if (lane == 0) atomicOr(&p.flags[b], 2); }
+  if (DIR == 0 && __any(lc.has_blank_label)) { if (lane == 0) atomicOr(&p.flags[b], 2); }
   double sk[PPL];
+  int off[PPL];                                    // element offset of this lane's label columns
 #pragma unroll
-  for (int r = 0; r < PPL; r++) sk[r] = dir == 0 ? (double)lc.skp[r] : (double)lc.skn[r];
+  for (int r = 0; r < PPL; r++) { sk[r] = DIR == 0 ? (double)lc.skp[r] : (double)lc.skn[r]; off[r] = lc.lab[r]; }
   const bool cond = (T > 1 || L == 1);            // ctc_loss.cpp:39,76
 
   double c[NC];                                    // the row: c[2r] blank cell 2i, c[2r+1] label cell 2i+1
@@ -235,64 +323,66 @@ __global__ __launch_bounds__(256) void ctc_fast_chain_kernel(FastParams p) {
   for (int k = 0; k < NC; k++) c[k] = 0.0;
   int e_pending = 0;                               // exponent measured one step earlier
   int e_total = 0;                                 // sum of removed exponents
-  float* ck = (dir == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
-  short* esc = (dir == 0 ? p.escA : p.escB) + (size_t)b * p.NB;
+  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
+  short* esc = (DIR == 0 ? p.escA : p.escB) + (size_t)b * p.NB;
 
-  for (int n = 0; n < nblk; n++) {
+  // One block of 8 steps.  STEADY: all 8 rows are live and none is the chain's first row -- no per-step tests.
+  auto run_block = [&](int n, auto steady_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
     const int slot = n % kRingBlks;
-    spin_until(&myfilled[slot], n + 1);
+    { PROF_SPIN_BEGIN spin_until(&myfilled[slot], n + 1); PROF_SPIN_END(prof_spin) }
     const double* rows = myring + (size_t)slot * kBlk * ROW;
+    // all of the block's probabilities up front: the LDS latency is paid once per 8 steps
+    double yb[kBlk], e[kBlk][PPL];
 #pragma unroll
     for (int tt = 0; tt < kBlk; tt++) {
-      const int sidx = n * kBlk + tt;
-      if (sidx < T) {
-        const int t = dir == 0 ? sidx : T - 1 - sidx;
-        const double* row = rows + tt * ROW;
-        const double yb = row[blank];
-        double e[PPL];
+      yb[tt] = rows[tt * ROW + blank];
 #pragma unroll
-        for (int r = 0; r < PPL; r++) e[r] = row[lc.lab[r]];
-        if (dir == 0) {
-          // alpha_t[j] = (alpha[j] + alpha[j-1] + skip*alpha[j-2]) * y_t[l_j], ctc_loss.cpp:47-60
-          if (sidx == 0) {
+      for (int r = 0; r < PPL; r++) e[tt][r] = rows[tt * ROW + off[r]];
+    }
+    const int tbase = block_time(DIR, n, 0, T);          // t of tt = 0; t = tbase +/- tt
 #pragma unroll
-            for (int k = 0; k < NC; k++) c[k] = 0.0;
-            if (lane == 0) { c[0] = cond ? yb : 0.0; c[1] = rr * e[0]; }   // ctc_loss.cpp:39-42 (e[0]=0 when S=0)
+    for (int tt = 0; tt < kBlk; tt++) {
+      const int t = DIR == 0 ? tbase + tt : tbase - tt;
+      if (STEADY || t < T) {
+        const bool first = !STEADY && (DIR == 0 ? t == 0 : t == T - 1);
+        if (DIR == 0) {
+          // alpha_t[j] = (alpha[j] + r*alpha[j-1] + r^2*skip*alpha[j-2]) * y_t[l_j], ctc_loss.cpp:47-60
+          if (first) {
+            if (lane == 0) { c[0] = cond ? yb[tt] : 0.0; c[1] = rr * e[tt][0]; }   // ctc_loss.cpp:39-42
           } else {
             double pl = from_prev_lane(c[NC - 1]);        // label cell just below this lane's first blank
 #pragma unroll
             for (int r = 0; r < PPL; r++) {
               const double ob = c[2 * r], ol = c[2 * r + 1];
-              c[2 * r] = (ob + rr * pl) * yb;
-              c[2 * r + 1] = (ol + rr * ob + sk[r] * pl) * e[r];
+              c[2 * r] = (ob + rr * pl) * yb[tt];
+              c[2 * r + 1] = (ol + rr * ob + sk[r] * pl) * e[tt][r];
               pl = ol;
             }
           }
         } else {
-          // q_t[j] = (q[j] + q[j+1] + skipn*q[j+2]) * y_t[l_j]; q = beta * emission, ctc_loss.cpp:84-99
-          if (sidx == 0) {
-#pragma unroll
-            for (int k = 0; k < NC; k++) c[k] = 0.0;
+          // q_t[j] = (q[j] + r*q[j+1] + r^2*skipn*q[j+2]) * y_t[l_j]; q = beta * emission, ctc_loss.cpp:84-99
+          if (first) {
 #pragma unroll
             for (int r = 0; r < PPL; r++) {
               const int i = PPL * lane + r;
-              if (2 * i == L - 1 && cond) c[2 * r] = yb;             // ctc_loss.cpp:76
-              if (2 * i + 1 == L - 2) c[2 * r + 1] = rr * e[r];      // ctc_loss.cpp:78
+              if (2 * i == L - 1 && cond) c[2 * r] = yb[tt];             // ctc_loss.cpp:76
+              if (2 * i + 1 == L - 2) c[2 * r + 1] = rr * e[tt][r];      // ctc_loss.cpp:78
             }
           } else {
             double nb = from_next_lane(c[0]), nl = from_next_lane(c[1]);   // next lane's first blank / label
 #pragma unroll
             for (int r = PPL - 1; r >= 0; r--) {
               const double ob = c[2 * r], ol = c[2 * r + 1];
-              c[2 * r + 1] = (ol + rr * nb + sk[r] * nl) * e[r];
-              c[2 * r] = (ob + rr * ol) * yb;
+              c[2 * r + 1] = (ol + rr * nb + sk[r] * nl) * e[tt][r];
+              c[2 * r] = (ob + rr * ol) * yb[tt];
               nb = ob; nl = ol;
             }
           }
         }
-        // power-of-two rescale: measure at phase 6 (alpha: t%8==6, beta: t%8==1), remove at phase 7
-        const int ph = dir == 0 ? (t & 7) : 7 - (t & 7);
-        if (ph == 7) {
+        // power-of-two rescale: measure the row's exponent at position 6 of the block, remove it at position 7
+        // (alpha: t%8 == 6 / 7, beta: t%8 == 1 / 0)
+        if (tt == 7) {
           if (e_pending != 0) {
 #pragma unroll
             for (int k = 0; k < NC; k++) c[k] = ldexp(c[k], -e_pending);
@@ -300,7 +390,7 @@ __global__ __launch_bounds__(256) void ctc_fast_chain_kernel(FastParams p) {
           if (lane == 0) esc[t >> 3] = (short)e_pending;
           e_total += e_pending;
           e_pending = 0;
-          const int kk = dir == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
+          const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
           if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
             // block floating point: each lane stores its cells scaled by its own exponent (f32 keeps every
             // lane's cells however far apart the lanes' magnitudes are)
@@ -311,9 +401,9 @@ __global__ __launch_bounds__(256) void ctc_fast_chain_kernel(FastParams p) {
             float* dst = ck + (size_t)(kk / kSeg) * p.CELLS + lane * NC;
 #pragma unroll
             for (int k = 0; k < NC; k++) dst[k] = m > 0 ? (float)ldexp(c[k], -own) : 0.f;
-            p.ckE[(((size_t)b * p.NS + kk / kSeg) * 2 + dir) * 64 + lane] = (short)own;
+            p.ckE[(((size_t)b * p.NS + kk / kSeg) * 2 + DIR) * 64 + lane] = (short)own;
           }
-        } else if (ph == 6) {
+        } else if (tt == 6) {
           int hi = 0;
 #pragma unroll
           for (int k = 0; k < NC; k++) hi = max(hi, __double2hiint(c[k]));   // positive doubles order like ints
@@ -324,12 +414,18 @@ __global__ __launch_bounds__(256) void ctc_fast_chain_kernel(FastParams p) {
         }
       }
     }
-    if (lane == 0) publish(&myfreed[slot], n + 1);
+    publish(&myfreed[slot], n + 1);
+  };
+  for (int n = 0; n < nblk; n++) {
+    // alpha: block 0 holds the first row, the last block may be short; beta: block 0 holds the first row
+    // (and possibly dead rows), every later block is whole
+    const bool steady = DIR == 0 ? (n > 0 && (n + 1) * kBlk <= T) : (n > 0);
+    if (steady) run_block(n, std::true_type{}); else run_block(n, std::false_type{});
   }
 
   // ---- log Z from this side ----
   double z = 0.0;
-  if (dir == 0) {
+  if (DIR == 0) {
 #pragma unroll
     for (int k = 0; k < NC; k++) {
       const int j = NC * lane + k;
@@ -339,12 +435,14 @@ __global__ __launch_bounds__(256) void ctc_fast_chain_kernel(FastParams p) {
   } else if (lane == 0) {
     z = (cond ? c[0] : 0.0) + rr * c[1];                  // sum_j alpha_0[j]*beta_0[j]
   }
-  // wave sum of a double through two xor-butterflies on the halves is overkill: only <= 2 lanes hold data
+#ifdef E2E_FAST_PROFILE
+  if (lane == 0 && b < 256) { g_prof[(b * 4 + DIR) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + DIR) * 4 + 1] = prof_spin; }
+#endif
   for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
   if (lane == 0) {
     const double lz = log(z) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log(rr);
-    p.logz[2 * b + dir] = lz;
-    if (dir == 0) {
+    p.logz[2 * b + DIR] = lz;
+    if (DIR == 0) {
       p.losses[b] = (float)(-lz);
       if (!(z > 0.0) || !(z < __builtin_huge_val())) atomicOr(&p.flags[b], 4);     // infeasible or out of range
     }
@@ -352,50 +450,58 @@ __global__ __launch_bounds__(256) void ctc_fast_chain_kernel(FastParams p) {
 }
 
 // ============================================================================================
-// F2: one wave per (utterance, segment)
+// F1: the two serial chains
 // ============================================================================================
 template <int PPL>
-__global__ __launch_bounds__(64) void ctc_fast_segment_kernel(FastParams p) {
+__global__ __launch_bounds__(256) void ctc_fast_chain_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int NC = 2 * PPL;
-  constexpr int kSlope = 3 * NC;    // exponent drop allowed per lane (see the alpha load below)
-  const int b = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
-  const int V = p.V, blank = p.blank, ROW = V + 1, Tmax = p.T;
-  float* ys = reinterpret_cast<float*>(smem);          // [kSeg][ROW]  probabilities, column V = 0
-  float* post = ys + kSeg * ROW;                       // [kSeg][ROW]  per-label posteriors
-  float* postb = post + kSeg * ROW;                    // [kSeg][16]   partial sums of the blank cells
-  const int t0 = seg * kSeg;
-  float* grads = p.grads + (size_t)b * Tmax * V;
-  const float* x = p.x + (int64_t)b * p.sB;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int V = p.V, ROW = V + 1;                  // column V of every row is 0
+  double* ring = reinterpret_cast<double*>(smem);                  // [2][kRingBlks*kBlk][ROW]
+  volatile int* filled = reinterpret_cast<volatile int*>(ring + 2 * kRingBlks * kBlk * ROW);  // [2][kRingBlks]
+  volatile int* freed = filled + 2 * kRingBlks;                    // [2][kRingBlks]
 
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
-  if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
-  const int T = (int)Tq, S = (int)Sq, L = 2 * S + 1;
-  const int tend = min(t0 + kSeg, Tmax);
-
-  // frames past the utterance's end: exp(lp) in log-prob mode (quirk Q1), zero for fused logits
-  for (int idx = max(t0, T) * V + lane; idx < tend * V; idx += 64) {
-    const int t = idx / V, v = idx - t * V;
-    grads[idx] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : 0.f;
+  const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
+  if (bad) {                       // the exact kernel poisons this utterance
+    if (tid == 0) { p.flags[b] = 1; p.losses[b] = __builtin_nanf(""); }   // reason bit 0: bad lengths
+    return;
   }
-  if (t0 >= T) return;
-  const int t1 = min(t0 + kSeg, T), n = t1 - t0;
+  const int T = (int)Tq, S = (int)Sq;
+  if (tid < 2 * 2 * kRingBlks) const_cast<int*>(filled)[tid] = 0;
+  __syncthreads();
 
-  // stage the segment's probability rows, clear the accumulators
-  const float* ytab = p.ytab + ((size_t)b * Tmax + t0) * V;
-  for (int idx = lane; idx < n * V; idx += 64) { const int tt = idx / V; ys[tt * ROW + (idx - tt * V)] = ytab[idx]; }
-  for (int tt = lane; tt < kSeg; tt += 64) ys[tt * ROW + V] = 0.f;
-  for (int idx = lane; idx < kSeg * ROW; idx += 64) post[idx] = 0.f;
-  for (int idx = lane; idx < kSeg * 16; idx += 64) postb[idx] = 0.f;
+  const int wave = __builtin_amdgcn_readfirstlane(wid);
+  if (wave == 0) chain_wave<PPL, 0>(p, b, T, S, ring, filled, freed, lane);
+  else if (wave == 1) chain_wave<PPL, 1>(p, b, T, S, ring, filled, freed, lane);
+  else {
+    const int dir = wave & 1;
+    if (V <= 16) prep_wave<1>(p, b, T, dir, ring, filled, freed, lane);
+    else if (V <= 32) prep_wave<2>(p, b, T, dir, ring, filled, freed, lane);
+    else if (V <= 48) prep_wave<3>(p, b, T, dir, ring, filled, freed, lane);
+    else prep_wave<4>(p, b, T, dir, ring, filled, freed, lane);
+  }
+}
 
-  LaneCells<PPL> lc;
-  lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, lane);
+// ============================================================================================
+// F2: one wave per (utterance, segment)
+// ============================================================================================
+// FULL: an interior segment (16 live steps, neither t = 0 nor t = T-1 inside): no guards in the loops.
+template <int PPL, bool FULL>
+__device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg, int T, int S, int n,
+                                             const LaneCells<PPL>& lc, const int (&rank)[PPL],
+                                             const float* ys, float* Ps, int lane) {
+  constexpr int NC = 2 * PPL;
+  constexpr int kSlope = 3 * NC;    // exponent drop allowed per lane (see the alpha load below)
+  constexpr int PROW = 64 * PPL + 64;   // one row of Ps: label cells in label order, then 64 blank partial sums
+  const int V = p.V, blank = p.blank, ROW = V + 1, L = 2 * S + 1, t0 = seg * kSeg;
   const float rr = lc.r;
   const bool cond = (T > 1 || L == 1);
+  // the four rescale exponents that fall inside this segment (alpha at t%8 == 7, beta at t%8 == 0), fetched early
   const short* escA = p.escA + (size_t)b * p.NB;
   const short* escB = p.escB + (size_t)b * p.NB;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0);   // LDS staging visible to this (single) wave
+  const int eA7 = escA[(t0 >> 3)], eA15 = escA[(t0 >> 3) + 1];
+  const int eB0 = escB[(t0 >> 3)], eB8 = escB[(t0 >> 3) + 1];
 
   // ---- alpha rows of the segment, kept in registers ----
   float A[kSeg][NC];
@@ -430,28 +536,30 @@ __global__ __launch_bounds__(64) void ctc_fast_segment_kernel(FastParams p) {
     fA = lane > 0 ? ldexpf(1.f, max(min(ep - eA, 126), -126)) : 0.f;
     fB = lane < 63 ? ldexpf(1.f, max(min(eA - en, 126), -126)) : 0.f;
   }
+  const float* ylab[PPL];           // this lane's label columns in the staged rows
+#pragma unroll
+  for (int r = 0; r < PPL; r++) ylab[r] = ys + lc.lab[r];
+
 #pragma unroll
   for (int tt = 0; tt < kSeg; tt++) {
-    if (tt < n) {
-      const int t = t0 + tt;
-      const float* row = ys + tt * ROW;
-      const float yb = row[blank];
-      if (t == 0) {
+    if (FULL || tt < n) {
+      const float yb = ys[tt * ROW + blank];
+      if (!FULL && t0 + tt == 0) {
 #pragma unroll
         for (int k = 0; k < NC; k++) a[k] = 0.f;
-        if (lane == 0) { a[0] = cond ? yb : 0.f; a[1] = rr * row[lc.lab[0]]; }
+        if (lane == 0) { a[0] = cond ? yb : 0.f; a[1] = rr * ylab[0][tt * ROW]; }
       } else {
         float pl = from_prev_lane(a[NC - 1]) * fA;
 #pragma unroll
         for (int r = 0; r < PPL; r++) {
           const float ob = a[2 * r], ol = a[2 * r + 1];
           a[2 * r] = (ob + rr * pl) * yb;
-          a[2 * r + 1] = (ol + rr * ob + lc.skp[r] * pl) * row[lc.lab[r]];
+          a[2 * r + 1] = (ol + rr * ob + lc.skp[r] * pl) * ylab[r][tt * ROW];
           pl = ol;
         }
       }
-      if ((t & 7) == 7) {
-        const int e = escA[t >> 3];
+      if ((tt & 7) == 7) {             // t0 is a multiple of 16: t & 7 == tt & 7
+        const int e = tt == 7 ? eA7 : eA15;
         if (e != 0) {
 #pragma unroll
           for (int k = 0; k < NC; k++) a[k] = ldexpf(a[k], -e);
@@ -466,14 +574,9 @@ __global__ __launch_bounds__(64) void ctc_fast_segment_kernel(FastParams p) {
   // beta rows live in the reciprocal units of the alpha lanes (lane n: 2^(emax - eA_n)), so that alpha*beta is
   // in one common unit across the wave; the hand-over factor from lane n+1 is then 2^(eA_n - eA_{n+1}) <= 2^kSlope
   float q[NC];
-  const bool last_seg = (t1 == T);
-  const int lane_last = (L - 1) / NC;                 // lane holding cell L-1
-  const int eA_ref = __shfl(eA, lane_last, 64);
-  const float end_unit = ldexpf(1.f, max(min(eA - eA_ref, 126), -126));
-  if (last_seg) {
-#pragma unroll
-    for (int k = 0; k < NC; k++) q[k] = 0.f;
-  } else {
+  const bool last_seg = (t0 + n == T);
+  float end_unit = 1.f;
+  if (FULL || !last_seg) {
     const float* src = p.ckQ + ((size_t)b * p.NS + seg + 1) * p.CELLS + lane * NC;
 #pragma unroll
     for (int k = 0; k < NC; k++) q[k] = src[k];
@@ -483,17 +586,19 @@ __global__ __launch_bounds__(64) void ctc_fast_segment_kernel(FastParams p) {
     const int sh = max(E - emax, -200);
 #pragma unroll
     for (int k = 0; k < NC; k++) q[k] = ldexpf(q[k], sh);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NC; k++) q[k] = 0.f;
+    const int eA_ref = __shfl(eA, (L - 1) / NC, 64);          // lane holding cell L-1
+    end_unit = ldexpf(1.f, max(min(eA - eA_ref, 126), -126));
   }
-  float smin = __builtin_huge_valf();
-  bool finite_ok = true;
 #pragma unroll
   for (int tt = kSeg - 1; tt >= 0; tt--) {
-    if (tt < n) {
+    if (FULL || tt < n) {
       const int t = t0 + tt;
-      const float* row = ys + tt * ROW;
-      const float yb = row[blank];
+      const float yb = ys[tt * ROW + blank];
       float bs[NC];                 // beta_t[j] (no emission at t)
-      if (t == T - 1) {
+      if (!FULL && t == T - 1) {
 #pragma unroll
         for (int r = 0; r < PPL; r++) {
           const int i = PPL * lane + r;
@@ -509,29 +614,22 @@ __global__ __launch_bounds__(64) void ctc_fast_segment_kernel(FastParams p) {
           nb = q[2 * r]; nl = q[2 * r + 1];
         }
       }
-      float pj[NC], part = 0.f, pblank = 0.f;
-#pragma unroll
-      for (int k = 0; k < NC; k++) { pj[k] = A[tt][k] * bs[k]; part += pj[k]; }
-      const float s = wave_sum(part);
-      smin = fminf(smin, s);
-      finite_ok = finite_ok && (s < __builtin_huge_valf());
-      const float inv = 1.0f / s;
+      // alpha*beta of this lane's cells: label cells go to their label-sorted slot, blank cells are pre-summed
+      float pblank = 0.f;
 #pragma unroll
       for (int r = 0; r < PPL; r++) {
-        pblank += pj[2 * r];
-        const float pv = pj[2 * r + 1] * inv;
-        if (pv != 0.f) atomicAdd(&post[tt * ROW + lc.lab[r]], pv);     // ds_add_f32, no return
+        pblank += A[tt][2 * r] * bs[2 * r];
+        Ps[tt * PROW + rank[r]] = A[tt][2 * r + 1] * bs[2 * r + 1];
       }
-      pblank *= inv;
-      if (pblank != 0.f) atomicAdd(&postb[tt * 16 + (lane & 15)], pblank);
+      Ps[tt * PROW + 64 * PPL + lane] = pblank;
       // q_t = beta_t * y_t
 #pragma unroll
       for (int r = 0; r < PPL; r++) {
         q[2 * r] = bs[2 * r] * yb;
-        q[2 * r + 1] = bs[2 * r + 1] * row[lc.lab[r]];
+        q[2 * r + 1] = bs[2 * r + 1] * ylab[r][tt * ROW];
       }
-      if ((t & 7) == 0) {
-        const int e = escB[t >> 3];
+      if ((tt & 7) == 0) {
+        const int e = tt == 0 ? eB0 : eB8;
         if (e != 0) {
 #pragma unroll
           for (int k = 0; k < NC; k++) q[k] = ldexpf(q[k], -e);
@@ -539,33 +637,121 @@ __global__ __launch_bounds__(64) void ctc_fast_segment_kernel(FastParams p) {
       }
     }
   }
-  // range / consistency check: everything that carries posterior mass was representable
+}
+
+template <int PPL>
+__global__ __launch_bounds__(64) void ctc_fast_segment_kernel(FastParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int PROW = 64 * PPL + 64;
+  const int b = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
+  const int V = p.V, blank = p.blank, ROW = V + 1, Tmax = p.T;
+  float* Ps = reinterpret_cast<float*>(smem);          // [kSeg][PROW] alpha*beta, label cells in label order
+  float* ys = Ps + kSeg * PROW;                        // [kSeg][ROW]  probabilities, column V = 0
+  float* invs = ys + kSeg * ROW;                       // [kSeg]       1 / s_t
+  float* btot = invs + kSeg;                           // [kSeg]       blank-cell totals
+  int* starts = reinterpret_cast<int*>(btot + kSeg);   // [66]         first sorted slot of every label
+  const int t0 = seg * kSeg;
+  float* grads = p.grads + (size_t)b * Tmax * V;
+  const float* x = p.x + (int64_t)b * p.sB;
+
+  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
+  if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
+  const int T = (int)Tq, S = (int)Sq;
+  const int tend = min(t0 + kSeg, Tmax);
+
+  // frames past the utterance's end: exp(lp) in log-prob mode (quirk Q1), zero for fused logits
+  for (int t = max(t0, T); t < tend; t++)
+    for (int v = lane; v < V; v += 64)
+      grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : 0.f;
+  if (t0 >= T) return;
+  const int n = min(t0 + kSeg, T) - t0;
+
+  // stage the segment's probability rows
+  const float* ytab = p.ytab + ((size_t)b * Tmax + t0) * V;
+  for (int idx = lane; idx < kSeg * ROW; idx += 64) ys[idx] = 0.f;
+  starts[lane] = 0; if (lane < 2) starts[64 + lane] = 0;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int tt = 0; tt < n; tt++)
+    for (int v = lane; v < V; v += 64) ys[tt * ROW + v] = ytab[tt * V + v];
+
+  // counting sort of the label cells by label: cell i -> slot start[label] + (its order inside the label),
+  // cells past the utterance's S labels keep slot i (they only ever hold zeros)
+  LaneCells<PPL> lc;
+  lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, lane);
+  int rank[PPL];
+#pragma unroll
+  for (int r = 0; r < PPL; r++) {
+    const int i = PPL * lane + r;
+    rank[r] = (i < S && lc.lab[r] < V) ? atomicAdd(&starts[lc.lab[r]], 1) : 0;    // ds_add_rtn_u32
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    const int cnt = starts[lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int incl = wave_scan(cnt);
+    starts[lane] = incl - cnt;
+    if (lane == 63) starts[64] = incl;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < PPL; r++) {
+    const int i = PPL * lane + r;
+    rank[r] = (i < S && lc.lab[r] < V) ? starts[lc.lab[r]] + rank[r] : i;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
+
+  const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
+  if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, ys, Ps, lane);
+  else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, ys, Ps, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // ---- per row: prefix sums over the label-sorted cells, totals, normaliser s_t = sum_j alpha_t[j]*beta_t[j] ----
+  float smin = __builtin_huge_valf(), smax = 0.f;
+#pragma unroll 4
+  for (int tt = 0; tt < kSeg; tt++) {
+    if (tt < n) {
+      float c[PPL];
+#pragma unroll
+      for (int r = 0; r < PPL; r++) c[r] = Ps[tt * PROW + PPL * lane + r];
+      const float bl = Ps[tt * PROW + 64 * PPL + lane];
+#pragma unroll
+      for (int r = 1; r < PPL; r++) c[r] += c[r - 1];
+      const float incl = wave_scan(c[PPL - 1]);
+      const float excl = incl - c[PPL - 1];
+#pragma unroll
+      for (int r = 0; r < PPL; r++) Ps[tt * PROW + PPL * lane + r] = c[r] + excl;
+      const float lab_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+      const float bl_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan(bl)), 63));
+      const float st = lab_total + bl_total;
+      smin = fminf(smin, st); smax = fmaxf(smax, st);
+      if (lane == 0) { invs[tt] = __builtin_amdgcn_rcpf(st); btot[tt] = bl_total; }
+    }
+  }
+  // range check: everything that carries posterior mass was representable (see the header comment)
+  const bool finite_ok = smax < __builtin_huge_valf();
   if (!(smin >= 0x1p-90f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
   if (seg == 0 && lane == 0) {
     const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
     if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // ---- gradient rows: y - posterior (d loss/d logits in fused mode; exp(lp) - posterior otherwise) ----
-  for (int idx = lane; idx < n * V; idx += 64) {
-    const int tt = idx / V, v = idx - tt * V;
-    float pv = post[tt * ROW + v];
-    if (v == blank) {
-      float sb = 0.f;
-#pragma unroll
-      for (int g = 0; g < 16; g++) sb += postb[tt * 16 + g];
-      pv += sb;
+  for (int v = lane; v < V; v += 64) {
+    const int lo = starts[v], hi = starts[v + 1];     // label v owns the sorted slots [lo, hi)
+    for (int tt = 0; tt < n; tt++) {
+      const float* pre = Ps + tt * PROW;
+      float pv = (hi > lo) ? pre[hi - 1] - (lo > 0 ? pre[lo - 1] : 0.f) : 0.f;
+      if (v == blank) pv += btot[tt];
+      grads[(size_t)(t0 + tt) * V + v] = ys[tt * ROW + v] - pv * invs[tt];
     }
-    grads[(size_t)t0 * V + idx] = ys[tt * ROW + v] - pv;
   }
 }
 
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds1 = sizeof(double) * 2 * kRingBlks * kBlk * (p.V + 1) + sizeof(int) * 4 * kRingBlks;
-  const size_t lds2 = sizeof(float) * (2 * kSeg * (p.V + 1) + kSeg * 16);
+  const size_t lds2 = sizeof(float) * (kSeg * (64 * PPL + 64) + kSeg * (p.V + 1) + 2 * kSeg) + sizeof(int) * 66;
   hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(256), lds1, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
   hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);
@@ -652,6 +838,13 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
 }
 
 }  // namespace e2e
+
+#ifdef E2E_FAST_PROFILE
+extern "C" int e2e_debug_fast_profile(unsigned long long* host, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(e2e::g_prof), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : E2E_ERR_HIP;
+}
+#endif
 
 // Diagnostics (not part of include/e2e_ctc.h): copy the fast path's per-utterance flag words and both log Z
 // values out of a workspace that the last e2e_ctc_loss_fwd_bwd(ALGO_FAST/AUTO) call used.  Synchronises.
