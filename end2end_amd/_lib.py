@@ -66,6 +66,8 @@ def load():
         L.e2e_ctc_beam.argtypes = [vp, C.c_int, i64, i64, i64, i64p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_double,
                                    i64p, i64, i64p, vp, C.c_size_t, vp]
+        L.e2e_ctc_beam_status.restype = C.c_int
+        L.e2e_ctc_beam_status.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         if L.e2e_ctc_abi_version() != ABI_VERSION:
             raise ImportError("end2end_amd: %s has ABI %d, expected %d" % (LIB_PATH, L.e2e_ctc_abi_version(), ABI_VERSION))
         _lib = L

@@ -188,6 +188,8 @@ class CTCDecoderEngine:
                                           self.lmwt, self.wip, self.oov_penalty,
                                           out.data_ptr(), max_out, out_len.data_ptr(),
                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
+                # pool exhaustion / truncated output are reported per utterance (synchronises, like .tolist() below)
+                _lib.check(L.e2e_ctc_beam_status(ws.data_ptr(), B, T, V, self.beam_width))
         lens = out_len.tolist()
         width = max(lens) if lens else 0
         ids = out[:, :width].contiguous()    # packed to the longest result (ctc_decoder.cpp:192-200)

@@ -67,3 +67,32 @@ def assert_same(got, want, rtol, atol, what=""):
     assert np.array_equal(got[inf], want[inf]), what
     ok = ~(np.isnan(want) | inf)
     np.testing.assert_allclose(got[ok], want[ok], rtol=rtol, atol=atol, err_msg=what)
+
+
+def c_abi_beam(lp, x_len=None, blank=0, beam_width=100, labels=None, lm=None, lmwt=1.0, wip=0.0, oov_penalty=-1000.0):
+    """Raw C-ABI prefix beam search on log-probs -> (ids [B,maxlen], lengths [B])."""
+    L = _lib.load()
+    d = dev()
+    if not lp.is_cuda:
+        base = lp
+        lp = torch.empty_strided(base.shape, base.stride(), dtype=base.dtype, device=d)
+        lp.copy_(base)
+    B, T, V = lp.shape
+    if x_len is None:
+        x_len = [T] * B
+    xl = torch.as_tensor(np.asarray(x_len)).to(d, torch.long)
+    labels = list(labels or [])
+    space_id = labels.index(" ") if " " in labels else -1
+    max_out = T + 1
+    out = torch.full((B, max_out), -7, dtype=torch.long, device=d)
+    out_len = torch.full((B,), -7, dtype=torch.long, device=d)
+    n = L.e2e_ctc_beam_workspace_bytes(B, T, V, beam_width)
+    ws = torch.empty(n, dtype=torch.uint8, device=d)
+    sB, sT, sV = lp.stride()
+    _lib.check(L.e2e_ctc_beam(lp.data_ptr(), _lib.dtype_code(lp.dtype), sB, sT, sV, xl.data_ptr(), B, T, V, blank,
+                              beam_width, space_id, lm.handle if lm is not None else None, lmwt, wip, oov_penalty,
+                              out.data_ptr(), max_out, out_len.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(d)))
+    _lib.check(L.e2e_ctc_beam_status(ws.data_ptr(), B, T, V, beam_width))
+    lens = out_len.cpu().numpy()
+    width = int(lens.max()) if B else 0
+    return out[:, :width].cpu().numpy(), lens

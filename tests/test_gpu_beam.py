@@ -1,0 +1,99 @@
+"""-m gpu: HIP prefix beam search through the C ABI against the reference tests' known answers and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+import oracle_lib as O
+import gpu_util as U
+from end2end_amd.engines import LanguageModel
+
+pytestmark = pytest.mark.gpu
+ARPA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_3gram.arpa")
+
+
+def rand_lp(seed, B, T, V, sharp=2.0, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    return torch.log_softmax(torch.randn(B, T, V, generator=g, dtype=torch.float64) * sharp, -1).to(dtype)
+
+
+def same_as_oracle(lp, x_len, blank, W, labels, lm=None, olm=None, **kw):
+    gpu_kw = {k: v for k, v in kw.items() if k != "case_sensitive"}     # the LM handle already carries it
+    ids, lens = U.c_abi_beam(lp, x_len, blank, W, labels, lm, **gpu_kw)
+    o_ids, o_lens, _ = O.ctc_beam(lp.double().numpy(), x_len, blank, W, labels, olm, **kw)
+    assert lens.tolist() == o_lens.tolist()
+    assert ids.tolist() == o_ids.tolist()
+    return ids, lens
+
+
+@pytest.mark.parametrize("case", [c for c in G.known_answers()["decode"] if "beam" in c], ids=lambda c: c["name"])
+def test_known_answers(case):
+    lp = torch.log(torch.tensor(case["x"], dtype=torch.float32))
+    ids, lens = U.c_abi_beam(lp, None, case["blank"], case["beam_width"], case["labels"], wip=case["wip"])
+    sent = ["".join(case["labels"][i] for i in ids[b, : lens[b]]) for b in range(len(lens))]
+    assert sent == case["beam"]
+
+
+@pytest.mark.parametrize("W", [2, 3, 10, 20, 100])
+@pytest.mark.parametrize("wip", [0.0, 1.0])
+def test_random_no_lm_matches_oracle(W, wip):
+    labels = ["_", "a", "b", "c", " ", "d", "'"]
+    lp = rand_lp(100 + W, 5, 40, 7)
+    same_as_oracle(lp, [40, 33, 17, 40, 1], 0, W, labels, wip=wip)
+    same_as_oracle(lp, [40, 33, 17, 40, 1], 6, W, labels[::-1], wip=wip)      # blank last, space elsewhere
+    same_as_oracle(lp.float(), None, 0, W, None, wip=wip)                      # f32 input, no labels
+
+
+def test_speech_shape_beam100_matches_oracle():
+    labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
+    lp = rand_lp(7, 3, 120, 29, sharp=3.0)
+    same_as_oracle(lp, [120, 90, 61], 0, 100, labels, wip=1.0)
+
+
+def test_empty_prefix_winner_and_time_major_view():
+    lp = torch.log(torch.tensor([[[0.98, 0.01, 0.01]] * 4], dtype=torch.float64))
+    ids, lens = U.c_abi_beam(lp, None, 0, 10, None)
+    assert ids.tolist() == [[-1]] and lens.tolist() == [1]                    # quirk Q6
+    x = rand_lp(11, 4, 30, 6)
+    tm = x.permute(1, 0, 2).contiguous().permute(1, 0, 2)
+    a = U.c_abi_beam(x, None, 0, 8, None)
+    b = U.c_abi_beam(tm, None, 0, 8, None)
+    assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+
+
+@pytest.mark.parametrize("case_sensitive", [True, False])
+@pytest.mark.parametrize("W,lmwt,wip,oov", [(10, 1.0, 0.0, -10.0), (30, 0.5, 1.0, -3.0), (100, 2.0, 0.0, -1000.0)])
+def test_lm_scored_beam_matches_oracle(W, lmwt, wip, oov, case_sensitive):
+    labels = ["_", "a", "b", " "] if case_sensitive else ["_", "A", "b", " "]
+    lm = LanguageModel(ARPA, labels, case_sensitive)
+    olm = O.OracleLM(ARPA)
+    lp = rand_lp(31 + W, 4, 25, 4, sharp=1.5)
+    same_as_oracle(lp, [25, 25, 18, 9], 0, W, labels, lm, olm, lmwt=lmwt, wip=wip, oov_penalty=oov,
+                   case_sensitive=case_sensitive)
+
+
+def test_lm_changes_the_answer():
+    # acoustically "b a" and "a b" are close; the LM (which has "<s> a b" but no "<s> b") decides
+    labels = ["_", "a", "b", " "]
+    p = np.full((1, 5, 4), 0.02)
+    p[0, 0, [1, 2]] = [0.46, 0.50]
+    p[0, 1, 3] = 0.94
+    p[0, 2, [1, 2]] = [0.50, 0.46]
+    p[0, 3, 0] = 0.94
+    p[0, 4, 0] = 0.94
+    p /= p.sum(-1, keepdims=True)
+    lp = torch.log(torch.tensor(p))
+    no_lm, n0 = U.c_abi_beam(lp, None, 0, 20, labels, wip=0.0)
+    lm = LanguageModel(ARPA, labels, True)
+    with_lm, n1 = U.c_abi_beam(lp, None, 0, 20, labels, lm, lmwt=3.0, wip=0.0, oov_penalty=-10.0)
+    s0 = "".join(labels[i] for i in no_lm[0, : n0[0]])
+    s1 = "".join(labels[i] for i in with_lm[0, : n1[0]])
+    assert s0 == "b a" and s1 == "a b"
+
+
+def test_too_many_candidates_is_reported():
+    from end2end_amd._lib import E2EError
+    with pytest.raises(E2EError, match="candidates"):
+        U.c_abi_beam(rand_lp(1, 1, 4, 100), None, 0, 100, None)
