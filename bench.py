@@ -122,12 +122,93 @@ def cpu_baseline(host_batch, frames):
                       "one thread per utterance as the reference does (%.2f s per pass)" % (n, best)}
 
 
+def synthetic_arpa(path, labels, n_words=10000, seed=0):
+    """A seeded synthetic 3-gram ARPA (the LibriSpeech LM of the reference's tests is not available offline)."""
+    import random
+    rng = random.Random(seed)
+    letters = [c for c in labels if len(c) == 1 and c.isalpha()]
+    words = set()
+    while len(words) < n_words:
+        words.add("".join(rng.choice(letters) for _ in range(rng.randint(1, 7))))
+    words = sorted(words)
+    uni = [(-rng.uniform(2.0, 5.0), w, -rng.uniform(0.1, 0.6)) for w in words]
+    bi = {(rng.choice(words), rng.choice(words)) for _ in range(3 * n_words)}
+    bi |= {("<s>", rng.choice(words)) for _ in range(n_words // 10)}
+    bi = sorted(bi)
+    tri = sorted({(a, b, rng.choice(words)) for a, b in rng.sample(bi, n_words)})
+    with open(path, "w") as f:
+        f.write("\\data\\\nngram 1=%d\nngram 2=%d\nngram 3=%d\n\n\\1-grams:\n" % (len(uni) + 3, len(bi), len(tri)))
+        f.write("-2.0\t<unk>\n-99\t<s>\t-0.3\n-1.5\t</s>\n")
+        for p_, w, b_ in uni:
+            f.write("%.4f\t%s\t%.4f\n" % (p_, w, b_))
+        f.write("\n\\2-grams:\n")
+        for a, b_ in bi:
+            f.write("%.4f\t%s %s\t%.4f\n" % (-rng.uniform(0.5, 3.0), a, b_, -rng.uniform(0.05, 0.4)))
+        f.write("\n\\3-grams:\n")
+        for a, b_, c in tri:
+            f.write("%.4f\t%s %s %s\n" % (-rng.uniform(0.2, 2.0), a, b_, c))
+        f.write("\n\\end\\\n")
+
+
+def decode_numbers(dev):
+    """Secondary metric of BASELINE.json: decode utterances/s.  Greedy at B=1024 T=1500 V=29 (configs[2]); beam=100 at
+    B=64 T=1500 V=29 without and with a 3-gram LM (configs[3], synthetic ARPA).  Inputs resident in HBM."""
+    import tempfile
+    from end2end_amd import CTCDecoder
+    labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(1024, 1500, 29, generator=g) * 3).to(dev)
+    xl = torch.full((1024,), 1500, dtype=torch.long, device=dev)
+    eng = CTCDecoder(beam_width=1, blank_idx=0)._decoder          # no labels: ids only, no per-utterance strings
+    dt = timed(lambda: eng.decode_greedy(x, xl), 10)
+    bytes_alg = 1024 * 1500 * (29 * 4 + 8)
+    out["greedy"] = {"workload": "B=1024 T=1500 V=29", "utterances_per_s": 1024 / dt, "frames_per_s": 1024 * 1500 / dt,
+                     "ms": dt * 1e3, "hbm_frac_algorithmic": bytes_alg / dt / 1e9 / HBM_PEAK_GBS,
+                     "note": "wall time of the Python engine call incl. the device-to-host copy of the result lengths"}
+    xb = torch.log_softmax(x[:64], -1)
+    xlb = xl[:64]
+    eng = CTCDecoder(beam_width=100, blank_idx=0, after_logsoftmax=True, labels=labels, wip=1.0)._decoder
+    dt = timed(lambda: eng.decode(xb, xlb), 2)
+    out["beam100"] = {"workload": "B=64 T=1500 V=29 beam=100, no LM", "utterances_per_s": 64 / dt, "ms": dt * 1e3}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "synthetic_3gram.arpa")
+        synthetic_arpa(path, labels)
+        eng = CTCDecoder(beam_width=100, blank_idx=0, after_logsoftmax=True, labels=labels, lm_path=path, lmwt=1.0,
+                         wip=1.0, oov_penalty=-10.0)._decoder
+        dt = timed(lambda: eng.decode(xb, xlb), 2)
+    out["beam100_lm"] = {"workload": "B=64 T=1500 V=29 beam=100 + synthetic 3-gram ARPA (10k words)",
+                         "utterances_per_s": 64 / dt, "ms": dt * 1e3}
+    return out
+
+
+def recorded_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            rec = json.load(f)
+        return rec["traffic_bytes_per_launch"] if rec.get("workload") == workload else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the secondary decode-throughput numbers")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,12 +287,15 @@ def main():
                        + (" + RCCL all_reduce(scalar)" if distributed else ""),
                        "sharding": "utterances, %d per GPU" % w["B"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": recorded_traffic(w["name"]),
+                         "kernel": "e2e_ctc_loss_fwd_bwd = ctc_fast_chain_kernel + ctc_fast_segment_kernel (both counted)",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
             "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(host_batch, frames)
+        if n_gpus == 1 and not args.no_decode:
+            out["decode"] = decode_numbers(dev)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
