@@ -34,7 +34,7 @@ namespace {
 
 constexpr int kSeg = 16;        // steps per F2 segment == checkpoint spacing
 constexpr int kBlk = 8;         // prep -> chain hand-off block and rescale period
-constexpr int kRingBlks = 8;    // ring depth (blocks)
+constexpr int kRingBlks = 4;    // ring depth (blocks)
 constexpr int kMaxSmallV = 64;  // probability row fits one lane group
 
 struct FastParams {
@@ -142,13 +142,17 @@ __device__ __forceinline__ float row16_sum(float v) {
 #define PROF_SPIN_BEGIN
 #define PROF_SPIN_END(acc)
 #endif
+typedef __attribute__((address_space(3))) int lds_int;
+// (the flags must be addressed as LDS: through a generic pointer the poll becomes a flat load with sc0 sc1 and
+// an s_waitcnt vmcnt(0) that again drains the global stores)
 __device__ __forceinline__ void spin_until(volatile int* p, int want) {
-  while (*p != want) __builtin_amdgcn_s_sleep(1);
+  volatile lds_int* q = (volatile lds_int*)p;
+  while (*q != want) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void publish(volatile int* p, int v) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  *p = v;
+  *(volatile lds_int*)p = v;
 }
 
 // per-lane lattice description shared by F1 and F2: lane holds pairs i = PPL*lane + r
@@ -191,6 +195,28 @@ struct LaneCells {
 // ============================================================================================
 // F1 device code
 // ============================================================================================
+// LDS of F1.  Per direction a ring of kRingBlks blocks; a block holds, for each of its 8 steps, the emission
+// probability of every lattice label cell laid out per lane ([step][lane][PPL] floats: the chain reads its PPL
+// values with ONE wide ds_read) and the blank probability ([step]).  The label gather (PPL narrow LDS reads per
+// lane and step, 12-35 cycles each for a lone wave) is done by the prep waves, which have the slack.
+template <int PPL>
+struct F1Lds {
+  static constexpr int kBlockFloats = kBlk * 64 * PPL;
+  float* ering;      // [2][kRingBlks][kBlk][64][PPL]
+  float* ybr;        // [2][kRingBlks][kBlk]
+  float* ysc;        // [4 prep waves][4 rows][V+1] staging of one pass's probability rows
+  int* flags;        // filled[2][kRingBlks], freed[2][kRingBlks]
+  __device__ F1Lds(unsigned char* smem, int V) {
+    ering = reinterpret_cast<float*>(smem);
+    ybr = ering + 2 * kRingBlks * kBlockFloats;
+    ysc = ybr + 2 * kRingBlks * kBlk;
+    flags = reinterpret_cast<int*>(ysc + 4 * 4 * (V + 1));
+  }
+  static size_t bytes(int V) {
+    return sizeof(float) * (2 * kRingBlks * kBlockFloats + 2 * kRingBlks * kBlk + 4 * 4 * (V + 1)) + sizeof(int) * 4 * kRingBlks;
+  }
+};
+
 // Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
 // absolute time (t = 8m .. 8m+7), so that the rescale phase of a step is its position in the block:
 //   alpha: block n covers t = 8n + tt;              beta: block n covers t = 8(M-n) + 7 - tt,  M = (T-1)/8
@@ -212,14 +238,26 @@ __device__ __forceinline__ float exp_le0(float x) {
 
 // Probability rows for one chain: each 16-lane DPP row of the wave takes one time step (4 steps per pass), a
 // lane holds the columns v = l16 + 16k, k < NV = ceil(V/16); max / sum by row-wide DPP all-reduce.
-template <int NV>
-__device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int dir, double* ring,
-                                          volatile int* filled, volatile int* freed, int lane) {
+template <int PPL, int NV>
+__device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int S, int dir, int first, int stride,
+                                          const F1Lds<PPL>& lds, int prep_id, int lane) {
   const int V = p.V, ROW = V + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
-  double* myring = ring + (size_t)dir * kRingBlks * kBlk * ROW;
-  volatile int* myfilled = filled + dir * kRingBlks;
-  volatile int* myfreed = freed + dir * kRingBlks;
+  float* myring = lds.ering + (size_t)dir * kRingBlks * F1Lds<PPL>::kBlockFloats;
+  float* myyb = lds.ybr + dir * kRingBlks * kBlk;
+  float* mysc = lds.ysc + (size_t)prep_id * 4 * ROW;
+  volatile int* myfilled = lds.flags + dir * kRingBlks;
+  volatile int* myfreed = lds.flags + 2 * kRingBlks + dir * kRingBlks;
+  int lab[PPL];                                   // staging column of this lane's label cells (V = the zero column)
+  {
+    const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
+#pragma unroll
+    for (int r = 0; r < PPL; r++) {
+      const int i = PPL * lane + r;
+      const int li = i < S ? (int)tg[i] : V;
+      lab[r] = (li >= 0 && li < V) ? li : V;
+    }
+  }
   const float* x = p.x + (int64_t)b * p.sB;
   float* ytab = p.ytab + (size_t)b * p.T * V;
   const int q = lane >> 4, l16 = lane & 15;
@@ -244,10 +282,10 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     }
   };
   float xv[NP][NV];
-  load_block(0, xv);
-  for (int n = 0; n < nblk; n++) {
+  load_block(first, xv);
+  for (int n = first; n < nblk; n += stride) {       // this wave fills every `stride`-th block
     float xn[NP][NV];
-    load_block(n + 1, xn);
+    load_block(n + stride, xn);
     const int slot = n % kRingBlks;
     if (n >= kRingBlks) { PROF_SPIN_BEGIN spin_until(&myfreed[slot], n - kRingBlks + 1); PROF_SPIN_END(prof_spin) }
 #pragma unroll
@@ -273,16 +311,30 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 #pragma unroll
         for (int k = 0; k < NV; k++) y[k] *= inv;
       }
-      double* dst = myring + (size_t)(slot * kBlk + tt) * ROW;
+      // stage the pass's four rows, then every lane gathers the probabilities of its own label cells
+      float* srow = mysc + q * ROW;
       float* yrow = ytab + (size_t)(row_live ? t : 0) * V;
 #pragma unroll
       for (int k = 0; k < NV; k++) {
-        if (row_live && col_live[k]) {
-          dst[l16 + 16 * k] = (double)y[k];
-          if (dir == 0) yrow[l16 + 16 * k] = y[k];
+        if (col_live[k]) {
+          srow[l16 + 16 * k] = row_live ? y[k] : 0.f;
+          if (dir == 0 && row_live) yrow[l16 + 16 * k] = y[k];
         }
       }
-      if (row_live && l16 == 0) dst[V] = 0.0;
+      if (l16 == 0) srow[V] = 0.f;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // same wave, LDS in order: rows are readable
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) {
+        const float* row = mysc + qq * ROW;
+        float ev[PPL];
+#pragma unroll
+        for (int r = 0; r < PPL; r++) ev[r] = row[lab[r]];
+        float* dst = myring + ((size_t)(slot * kBlk + pass * 4 + qq) * 64 + lane) * PPL;
+#pragma unroll
+        for (int r = 0; r < PPL; r++) dst[r] = ev[r];
+        if (lane == 0) myyb[slot * kBlk + pass * 4 + qq] = row[p.blank];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // gathers done before the staging rows are reused
     }
     publish(&myfilled[slot], n + 1);     // every lane stores the same word: no divergence, one LDS write
 #pragma unroll
@@ -291,31 +343,30 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
       for (int k = 0; k < NV; k++) xv[pass][k] = xn[pass][k];
   }
 #ifdef E2E_FAST_PROFILE
-  if (lane == 0 && b < 256) { g_prof[(b * 4 + 2 + dir) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + 2 + dir) * 4 + 1] = prof_spin; }
+  if (lane == 0 && b < 256 && first == 0) { g_prof[(b * 4 + 2 + dir) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + 2 + dir) * 4 + 1] = prof_spin; }
 #endif
 }
 
 // One serial chain (DIR 0: alpha forward, DIR 1: beta-with-emission backward).
 template <int PPL, int DIR>
-__device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, int S, double* ring,
-                                           volatile int* filled, volatile int* freed, int lane) {
+__device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, int S, const F1Lds<PPL>& lds, int lane) {
   constexpr int NC = 2 * PPL;
-  const int V = p.V, blank = p.blank, ROW = V + 1, L = 2 * S + 1;
+  const int V = p.V, blank = p.blank, L = 2 * S + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
-  double* myring = ring + (size_t)DIR * kRingBlks * kBlk * ROW;
-  volatile int* myfilled = filled + DIR * kRingBlks;
-  volatile int* myfreed = freed + DIR * kRingBlks;
+  const float* myring = lds.ering + (size_t)DIR * kRingBlks * F1Lds<PPL>::kBlockFloats;
+  const float* myyb = lds.ybr + DIR * kRingBlks * kBlk;
+  volatile int* myfilled = lds.flags + DIR * kRingBlks;
+  volatile int* myfreed = lds.flags + 2 * kRingBlks + DIR * kRingBlks;
   __builtin_amdgcn_s_setprio(3);
-  unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime();
-  (void)prof_spin; (void)prof_t0;
+  unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime(), prof_load = 0, prof_steps = 0;
+  (void)prof_spin; (void)prof_t0; (void)prof_load; (void)prof_steps;
   LaneCells<PPL> lc;
   lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, lane);
   const double rr = (double)lc.r;
   if (DIR == 0 && __any(lc.has_blank_label)) { if (lane == 0) atomicOr(&p.flags[b], 2); }
   double sk[PPL];
-  int off[PPL];                                    // element offset of this lane's label columns
 #pragma unroll
-  for (int r = 0; r < PPL; r++) { sk[r] = DIR == 0 ? (double)lc.skp[r] : (double)lc.skn[r]; off[r] = lc.lab[r]; }
+  for (int r = 0; r < PPL; r++) sk[r] = DIR == 0 ? (double)lc.skp[r] : (double)lc.skn[r];
   const bool cond = (T > 1 || L == 1);            // ctc_loss.cpp:39,76
 
   double c[NC];                                    // the row: c[2r] blank cell 2i, c[2r+1] label cell 2i+1
@@ -331,15 +382,26 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
     constexpr bool STEADY = decltype(steady_tag)::value;
     const int slot = n % kRingBlks;
     { PROF_SPIN_BEGIN spin_until(&myfilled[slot], n + 1); PROF_SPIN_END(prof_spin) }
-    const double* rows = myring + (size_t)slot * kBlk * ROW;
-    // all of the block's probabilities up front: the LDS latency is paid once per 8 steps
+    // all of the block's probabilities up front (one wide read per step + the 8 blank probabilities): the LDS
+    // latency is paid once per 8 steps
+    typedef float fvec __attribute__((ext_vector_type(PPL)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const fvec* rows = reinterpret_cast<const fvec*>(myring + (size_t)slot * F1Lds<PPL>::kBlockFloats) + lane;
+    fvec ef[kBlk];
+#pragma unroll
+    for (int tt = 0; tt < kBlk; tt++) ef[tt] = rows[tt * 64];
+    const f4* ybp = reinterpret_cast<const f4*>(myyb + slot * kBlk);
+    const f4 yb0 = ybp[0], yb1 = ybp[1];
     double yb[kBlk], e[kBlk][PPL];
 #pragma unroll
     for (int tt = 0; tt < kBlk; tt++) {
-      yb[tt] = rows[tt * ROW + blank];
+      yb[tt] = (double)(tt < 4 ? yb0[tt & 3] : yb1[tt & 3]);
 #pragma unroll
-      for (int r = 0; r < PPL; r++) e[tt][r] = rows[tt * ROW + off[r]];
+      for (int r = 0; r < PPL; r++) e[tt][r] = (double)((const float*)&ef[tt])[r];
     }
+#ifdef E2E_FAST_PROFILE
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
     const int tbase = block_time(DIR, n, 0, T);          // t of tt = 0; t = tbase +/- tt
 #pragma unroll
     for (int tt = 0; tt < kBlk; tt++) {
@@ -414,6 +476,10 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
         }
       }
     }
+#ifdef E2E_FAST_PROFILE
+    const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+    prof_steps += ts2 - ts1;
+#endif
     publish(&myfreed[slot], n + 1);
   };
   for (int n = 0; n < nblk; n++) {
@@ -436,7 +502,8 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
     z = (cond ? c[0] : 0.0) + rr * c[1];                  // sum_j alpha_0[j]*beta_0[j]
   }
 #ifdef E2E_FAST_PROFILE
-  if (lane == 0 && b < 256) { g_prof[(b * 4 + DIR) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + DIR) * 4 + 1] = prof_spin; }
+  if (lane == 0 && b < 256) { g_prof[(b * 4 + DIR) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + DIR) * 4 + 1] = prof_spin;
+    g_prof[(b * 4 + DIR) * 4 + 2] = prof_load; g_prof[(b * 4 + DIR) * 4 + 3] = prof_steps; }
 #endif
   for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
   if (lane == 0) {
@@ -452,14 +519,14 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
 // ============================================================================================
 // F1: the two serial chains
 // ============================================================================================
+// Waves of a workgroup land on the SIMDs in the order 0,2,1,3,0,2,1,3: waves 0/1 (the chains) get SIMDs 0 and 2 to
+// themselves, waves 2,6 (alpha rows) share SIMD 1, waves 3,7 (beta rows) share SIMD 3, waves 4/5 retire at once.
 template <int PPL>
-__global__ __launch_bounds__(256) void ctc_fast_chain_kernel(FastParams p) {
+__global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int V = p.V, ROW = V + 1;                  // column V of every row is 0
-  double* ring = reinterpret_cast<double*>(smem);                  // [2][kRingBlks*kBlk][ROW]
-  volatile int* filled = reinterpret_cast<volatile int*>(ring + 2 * kRingBlks * kBlk * ROW);  // [2][kRingBlks]
-  volatile int* freed = filled + 2 * kRingBlks;                    // [2][kRingBlks]
+  const int V = p.V;
+  const F1Lds<PPL> lds(smem, V);
 
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
@@ -468,33 +535,109 @@ __global__ __launch_bounds__(256) void ctc_fast_chain_kernel(FastParams p) {
     return;
   }
   const int T = (int)Tq, S = (int)Sq;
-  if (tid < 2 * 2 * kRingBlks) const_cast<int*>(filled)[tid] = 0;
+  if (tid < 2 * 2 * kRingBlks) lds.flags[tid] = 0;
   __syncthreads();
 
   const int wave = __builtin_amdgcn_readfirstlane(wid);
-  if (wave == 0) chain_wave<PPL, 0>(p, b, T, S, ring, filled, freed, lane);
-  else if (wave == 1) chain_wave<PPL, 1>(p, b, T, S, ring, filled, freed, lane);
+  if (wave == 0) chain_wave<PPL, 0>(p, b, T, S, lds, lane);
+  else if (wave == 1) chain_wave<PPL, 1>(p, b, T, S, lds, lane);
+  else if (wave == 4 || wave == 5) return;
   else {
-    const int dir = wave & 1;
-    if (V <= 16) prep_wave<1>(p, b, T, dir, ring, filled, freed, lane);
-    else if (V <= 32) prep_wave<2>(p, b, T, dir, ring, filled, freed, lane);
-    else if (V <= 48) prep_wave<3>(p, b, T, dir, ring, filled, freed, lane);
-    else prep_wave<4>(p, b, T, dir, ring, filled, freed, lane);
+    const int dir = (wave & 1) ^ 0;              // waves 2,6 -> alpha (dir 0), waves 3,7 -> beta (dir 1)
+    const int d = (wave == 2 || wave == 6) ? 0 : 1;
+    const int first = wave >= 6 ? 1 : 0;
+    (void)dir;
+    const int prep_id = d * 2 + first;
+    if (V <= 16) prep_wave<PPL, 1>(p, b, T, S, d, first, 2, lds, prep_id, lane);
+    else if (V <= 32) prep_wave<PPL, 2>(p, b, T, S, d, first, 2, lds, prep_id, lane);
+    else if (V <= 48) prep_wave<PPL, 3>(p, b, T, S, d, first, 2, lds, prep_id, lane);
+    else prep_wave<PPL, 4>(p, b, T, S, d, first, 2, lds, prep_id, lane);
   }
 }
 
 // ============================================================================================
-// F2: one wave per (utterance, segment)
+// F2: one wave per (utterance, group of kSegPerWave consecutive 16-step segments)
 // ============================================================================================
+constexpr int kSegPerWave = 1;     // segments handled back to back by one wave (labels / label order set up once)
+constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before they are summed and written out
+
+template <int PPL>
+struct F2Lds {
+  static constexpr int PROW = 64 * PPL + 64;   // label cells in label order, then 64 blank partial sums
+  float* Ps;        // [kHalf][PROW]
+  float* ys;        // [kSeg][V+1]  probabilities of the segment, column V = 0
+  float* invs;      // [kHalf]
+  float* btot;      // [kHalf]
+  int* starts;      // [66] first sorted slot of every label
+  __device__ F2Lds(unsigned char* smem, int V) {
+    Ps = reinterpret_cast<float*>(smem);
+    ys = Ps + kHalf * PROW;
+    invs = ys + kSeg * (V + 1);
+    btot = invs + kHalf;
+    starts = reinterpret_cast<int*>(btot + kHalf);
+  }
+  static size_t bytes(int V) { return sizeof(float) * (kHalf * PROW + kSeg * (V + 1) + 2 * kHalf) + sizeof(int) * 66; }
+};
+
+// rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows
+template <int PPL>
+__device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, int n, int h, const F2Lds<PPL>& lds,
+                                            int lane, float& smin, float& smax) {
+  constexpr int PROW = F2Lds<PPL>::PROW;
+  const int V = p.V, blank = p.blank, ROW = V + 1;
+  float* grads = p.grads + (size_t)b * p.T * V;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // prefix sums over the label-sorted cells, totals, s_t = sum_j alpha_t[j]*beta_t[j]
+#pragma unroll 4
+  for (int k = 0; k < kHalf; k++) {
+    const int tt = h * kHalf + k;
+    if (tt < n) {
+      float c[PPL];
+#pragma unroll
+      for (int r = 0; r < PPL; r++) c[r] = lds.Ps[k * PROW + PPL * lane + r];
+      const float bl = lds.Ps[k * PROW + 64 * PPL + lane];
+#pragma unroll
+      for (int r = 1; r < PPL; r++) c[r] += c[r - 1];
+      const float incl = wave_scan(c[PPL - 1]);
+      const float excl = incl - c[PPL - 1];
+#pragma unroll
+      for (int r = 0; r < PPL; r++) lds.Ps[k * PROW + PPL * lane + r] = c[r] + excl;
+      const float lab_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+      const float bl_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan(bl)), 63));
+      const float st = lab_total + bl_total;
+      smin = fminf(smin, st); smax = fmaxf(smax, st);
+      if (lane == 0) { lds.invs[k] = __builtin_amdgcn_rcpf(st); lds.btot[k] = bl_total; }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // gradient rows: y - posterior (d loss/d logits in fused mode; exp(lp) - posterior otherwise)
+  for (int v = lane; v < V; v += 64) {
+    const int lo = lds.starts[v], hi = lds.starts[v + 1];     // label v owns the sorted slots [lo, hi)
+#pragma unroll
+    for (int k = 0; k < kHalf; k++) {
+      const int tt = h * kHalf + k;
+      if (tt < n) {
+        const float* pre = lds.Ps + k * PROW;
+        float pv = (hi > lo) ? pre[hi - 1] - (lo > 0 ? pre[lo - 1] : 0.f) : 0.f;
+        if (v == blank) pv += lds.btot[k];
+        grads[(size_t)(t0 + tt) * V + v] = lds.ys[tt * ROW + v] - pv * lds.invs[k];
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ps / invs are rewritten by the next half
+}
+
 // FULL: an interior segment (16 live steps, neither t = 0 nor t = T-1 inside): no guards in the loops.
 template <int PPL, bool FULL>
 __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg, int T, int S, int n,
                                              const LaneCells<PPL>& lc, const int (&rank)[PPL],
-                                             const float* ys, float* Ps, int lane) {
+                                             const F2Lds<PPL>& lds, int lane, float& smin, float& smax) {
   constexpr int NC = 2 * PPL;
   constexpr int kSlope = 3 * NC;    // exponent drop allowed per lane (see the alpha load below)
-  constexpr int PROW = 64 * PPL + 64;   // one row of Ps: label cells in label order, then 64 blank partial sums
+  constexpr int PROW = F2Lds<PPL>::PROW;
   const int V = p.V, blank = p.blank, ROW = V + 1, L = 2 * S + 1, t0 = seg * kSeg;
+  const float* ys = lds.ys;
+  float* Ps = lds.Ps;
   const float rr = lc.r;
   const bool cond = (T > 1 || L == 1);
   // the four rescale exponents that fall inside this segment (alpha at t%8 == 7, beta at t%8 == 0), fetched early
@@ -593,168 +736,144 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
     end_unit = ldexpf(1.f, max(min(eA - eA_ref, 126), -126));
   }
 #pragma unroll
-  for (int tt = kSeg - 1; tt >= 0; tt--) {
-    if (FULL || tt < n) {
-      const int t = t0 + tt;
-      const float yb = ys[tt * ROW + blank];
-      float bs[NC];                 // beta_t[j] (no emission at t)
-      if (!FULL && t == T - 1) {
+  for (int h = kSeg / kHalf - 1; h >= 0; h--) {
+    if (!FULL && h * kHalf >= n) continue;
+#pragma unroll
+    for (int k = kHalf - 1; k >= 0; k--) {
+      const int tt = h * kHalf + k;
+      if (FULL || tt < n) {
+        const int t = t0 + tt;
+        const float yb = ys[tt * ROW + blank];
+        float bs[NC];                 // beta_t[j] (no emission at t)
+        if (!FULL && t == T - 1) {
+#pragma unroll
+          for (int r = 0; r < PPL; r++) {
+            const int i = PPL * lane + r;
+            bs[2 * r] = (2 * i == L - 1 && cond) ? end_unit : 0.f;
+            bs[2 * r + 1] = (2 * i + 1 == L - 2) ? rr * end_unit : 0.f;
+          }
+        } else {
+          float nb = from_next_lane(q[0]) * fB, nl = from_next_lane(q[1]) * fB;
+#pragma unroll
+          for (int r = PPL - 1; r >= 0; r--) {
+            bs[2 * r + 1] = q[2 * r + 1] + rr * nb + lc.skn[r] * nl;
+            bs[2 * r] = q[2 * r] + rr * q[2 * r + 1];
+            nb = q[2 * r]; nl = q[2 * r + 1];
+          }
+        }
+        // alpha*beta of this lane's cells: label cells go to their label-sorted slot, blank cells are pre-summed
+        float pblank = 0.f;
 #pragma unroll
         for (int r = 0; r < PPL; r++) {
-          const int i = PPL * lane + r;
-          bs[2 * r] = (2 * i == L - 1 && cond) ? end_unit : 0.f;
-          bs[2 * r + 1] = (2 * i + 1 == L - 2) ? rr * end_unit : 0.f;
+          pblank += A[tt][2 * r] * bs[2 * r];
+          Ps[k * PROW + rank[r]] = A[tt][2 * r + 1] * bs[2 * r + 1];
         }
-      } else {
-        float nb = from_next_lane(q[0]) * fB, nl = from_next_lane(q[1]) * fB;
+        Ps[k * PROW + 64 * PPL + lane] = pblank;
+        // q_t = beta_t * y_t
 #pragma unroll
-        for (int r = PPL - 1; r >= 0; r--) {
-          bs[2 * r + 1] = q[2 * r + 1] + rr * nb + lc.skn[r] * nl;
-          bs[2 * r] = q[2 * r] + rr * q[2 * r + 1];
-          nb = q[2 * r]; nl = q[2 * r + 1];
+        for (int r = 0; r < PPL; r++) {
+          q[2 * r] = bs[2 * r] * yb;
+          q[2 * r + 1] = bs[2 * r + 1] * ylab[r][tt * ROW];
         }
-      }
-      // alpha*beta of this lane's cells: label cells go to their label-sorted slot, blank cells are pre-summed
-      float pblank = 0.f;
+        if ((tt & 7) == 0) {
+          const int e = tt == 0 ? eB0 : eB8;
+          if (e != 0) {
 #pragma unroll
-      for (int r = 0; r < PPL; r++) {
-        pblank += A[tt][2 * r] * bs[2 * r];
-        Ps[tt * PROW + rank[r]] = A[tt][2 * r + 1] * bs[2 * r + 1];
-      }
-      Ps[tt * PROW + 64 * PPL + lane] = pblank;
-      // q_t = beta_t * y_t
-#pragma unroll
-      for (int r = 0; r < PPL; r++) {
-        q[2 * r] = bs[2 * r] * yb;
-        q[2 * r + 1] = bs[2 * r + 1] * ylab[r][tt * ROW];
-      }
-      if ((tt & 7) == 0) {
-        const int e = tt == 0 ? eB0 : eB8;
-        if (e != 0) {
-#pragma unroll
-          for (int k = 0; k < NC; k++) q[k] = ldexpf(q[k], -e);
+            for (int kk = 0; kk < NC; kk++) q[kk] = ldexpf(q[kk], -e);
+          }
         }
       }
     }
+    finish_rows<PPL>(p, b, t0, n, h, lds, lane, smin, smax);
   }
 }
 
 template <int PPL>
-__global__ __launch_bounds__(64) void ctc_fast_segment_kernel(FastParams p) {
+__global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int PROW = 64 * PPL + 64;
-  const int b = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.y, lane = threadIdx.x;
   const int V = p.V, blank = p.blank, ROW = V + 1, Tmax = p.T;
-  float* Ps = reinterpret_cast<float*>(smem);          // [kSeg][PROW] alpha*beta, label cells in label order
-  float* ys = Ps + kSeg * PROW;                        // [kSeg][ROW]  probabilities, column V = 0
-  float* invs = ys + kSeg * ROW;                       // [kSeg]       1 / s_t
-  float* btot = invs + kSeg;                           // [kSeg]       blank-cell totals
-  int* starts = reinterpret_cast<int*>(btot + kSeg);   // [66]         first sorted slot of every label
-  const int t0 = seg * kSeg;
+  const F2Lds<PPL> lds(smem, V);
   float* grads = p.grads + (size_t)b * Tmax * V;
   const float* x = p.x + (int64_t)b * p.sB;
 
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
   const int T = (int)Tq, S = (int)Sq;
-  const int tend = min(t0 + kSeg, Tmax);
-
-  // frames past the utterance's end: exp(lp) in log-prob mode (quirk Q1), zero for fused logits
-  for (int t = max(t0, T); t < tend; t++)
-    for (int v = lane; v < V; v += 64)
-      grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : 0.f;
-  if (t0 >= T) return;
-  const int n = min(t0 + kSeg, T) - t0;
-
-  // stage the segment's probability rows
-  const float* ytab = p.ytab + ((size_t)b * Tmax + t0) * V;
-  for (int idx = lane; idx < kSeg * ROW; idx += 64) ys[idx] = 0.f;
-  starts[lane] = 0; if (lane < 2) starts[64 + lane] = 0;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  for (int tt = 0; tt < n; tt++)
-    for (int v = lane; v < V; v += 64) ys[tt * ROW + v] = ytab[tt * V + v];
+  const int seg_first = blockIdx.x * kSegPerWave;
+  if (seg_first * kSeg >= Tmax) return;
 
   // counting sort of the label cells by label: cell i -> slot start[label] + (its order inside the label),
-  // cells past the utterance's S labels keep slot i (they only ever hold zeros)
+  // cells past the utterance's S labels keep slot i (they only ever hold zeros).  Needed only by live segments.
   LaneCells<PPL> lc;
-  lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, lane);
   int rank[PPL];
-#pragma unroll
-  for (int r = 0; r < PPL; r++) {
-    const int i = PPL * lane + r;
-    rank[r] = (i < S && lc.lab[r] < V) ? atomicAdd(&starts[lc.lab[r]], 1) : 0;    // ds_add_rtn_u32
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  {
-    const int cnt = starts[lane];
+  if (seg_first * kSeg < T) {
+    lds.starts[lane] = 0; if (lane < 2) lds.starts[64 + lane] = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int incl = wave_scan(cnt);
-    starts[lane] = incl - cnt;
-    if (lane == 63) starts[64] = incl;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, lane);
 #pragma unroll
-  for (int r = 0; r < PPL; r++) {
-    const int i = PPL * lane + r;
-    rank[r] = (i < S && lc.lab[r] < V) ? starts[lc.lab[r]] + rank[r] : i;
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
-
-  const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
-  if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, ys, Ps, lane);
-  else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, ys, Ps, lane);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-  // ---- per row: prefix sums over the label-sorted cells, totals, normaliser s_t = sum_j alpha_t[j]*beta_t[j] ----
-  float smin = __builtin_huge_valf(), smax = 0.f;
-#pragma unroll 4
-  for (int tt = 0; tt < kSeg; tt++) {
-    if (tt < n) {
-      float c[PPL];
-#pragma unroll
-      for (int r = 0; r < PPL; r++) c[r] = Ps[tt * PROW + PPL * lane + r];
-      const float bl = Ps[tt * PROW + 64 * PPL + lane];
-#pragma unroll
-      for (int r = 1; r < PPL; r++) c[r] += c[r - 1];
-      const float incl = wave_scan(c[PPL - 1]);
-      const float excl = incl - c[PPL - 1];
-#pragma unroll
-      for (int r = 0; r < PPL; r++) Ps[tt * PROW + PPL * lane + r] = c[r] + excl;
-      const float lab_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
-      const float bl_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan(bl)), 63));
-      const float st = lab_total + bl_total;
-      smin = fminf(smin, st); smax = fmaxf(smax, st);
-      if (lane == 0) { invs[tt] = __builtin_amdgcn_rcpf(st); btot[tt] = bl_total; }
+    for (int r = 0; r < PPL; r++) {
+      const int i = PPL * lane + r;
+      rank[r] = (i < S && lc.lab[r] < V) ? atomicAdd(&lds.starts[lc.lab[r]], 1) : 0;    // ds_add_rtn_u32
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const int cnt = lds.starts[lane];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int incl = wave_scan(cnt);
+      lds.starts[lane] = incl - cnt;
+      if (lane == 63) lds.starts[64] = incl;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < PPL; r++) {
+      const int i = PPL * lane + r;
+      rank[r] = (i < S && lc.lab[r] < V) ? lds.starts[lc.lab[r]] + rank[r] : i;
+    }
+    for (int tt = lane; tt < kSeg; tt += 64) lds.ys[tt * ROW + V] = 0.f;
+  }
+
+  float smin = __builtin_huge_valf(), smax = 0.f;
+  for (int g = 0; g < kSegPerWave; g++) {
+    const int seg = seg_first + g, t0 = seg * kSeg;
+    if (t0 >= Tmax) break;
+    const int tend = min(t0 + kSeg, Tmax);
+    // frames past the utterance's end: exp(lp) in log-prob mode (quirk Q1), zero for fused logits
+    for (int t = max(t0, T); t < tend; t++)
+      for (int v = lane; v < V; v += 64)
+        grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : 0.f;
+    if (t0 >= T) continue;
+    const int n = min(t0 + kSeg, T) - t0;
+    // stage the segment's probability rows
+    const float* ytab = p.ytab + ((size_t)b * Tmax + t0) * V;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int tt = 0; tt < n; tt++)
+      for (int v = lane; v < V; v += 64) lds.ys[tt * ROW + v] = ytab[tt * V + v];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
+    const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
+    if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, lds, lane, smin, smax);
+    else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, lds, lane, smin, smax);
   }
   // range check: everything that carries posterior mass was representable (see the header comment)
-  const bool finite_ok = smax < __builtin_huge_valf();
-  if (!(smin >= 0x1p-90f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
-  if (seg == 0 && lane == 0) {
-    const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
-    if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-  // ---- gradient rows: y - posterior (d loss/d logits in fused mode; exp(lp) - posterior otherwise) ----
-  for (int v = lane; v < V; v += 64) {
-    const int lo = starts[v], hi = starts[v + 1];     // label v owns the sorted slots [lo, hi)
-    for (int tt = 0; tt < n; tt++) {
-      const float* pre = Ps + tt * PROW;
-      float pv = (hi > lo) ? pre[hi - 1] - (lo > 0 ? pre[lo - 1] : 0.f) : 0.f;
-      if (v == blank) pv += btot[tt];
-      grads[(size_t)(t0 + tt) * V + v] = ys[tt * ROW + v] - pv * invs[tt];
+  if (seg_first * kSeg < T) {
+    const bool finite_ok = smax < __builtin_huge_valf();
+    if (!(smin >= 0x1p-90f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
+    if (seg_first == 0 && lane == 0) {
+      const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
+      if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
     }
   }
 }
 
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
-  const size_t lds1 = sizeof(double) * 2 * kRingBlks * kBlk * (p.V + 1) + sizeof(int) * 4 * kRingBlks;
-  const size_t lds2 = sizeof(float) * (kSeg * (64 * PPL + 64) + kSeg * (p.V + 1) + 2 * kSeg) + sizeof(int) * 66;
-  hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(256), lds1, stream, p);
+  const size_t lds1 = F1Lds<PPL>::bytes(p.V);
+  E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute");
+  const size_t lds2 = F2Lds<PPL>::bytes(p.V);
+  hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
-  hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);
+  hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3((p.NS + kSegPerWave - 1) / kSegPerWave, p.B), dim3(64), lds2, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
   return E2E_OK;
 }

@@ -1,12 +1,12 @@
 import sys, ctypes as C, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import end2end_amd._lib as _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_prof_lib.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out_prof_lib.so")
 L = _lib.load()
 d = torch.device("cuda", 0)
 gen = torch.Generator().manual_seed(0)
-B,T,V,S = 256,1000,29,200
+B,T,V,S = 256,1000,29,int(sys.argv[1]) if len(sys.argv) > 1 else 200
 x = torch.randn(B,T,V,generator=gen).to(d); tg = torch.randint(1,V,(B,S),generator=gen).to(d); tl = torch.randint(S//2,S+1,(B,),generator=gen).to(d); xl=torch.full((B,),T).to(d)
 losses = torch.empty(B, device=d); grads = torch.empty(B,T,V, device=d)
 n = L.e2e_ctc_loss_workspace_bytes(B,T,V,S,0,2); ws = torch.zeros(n, dtype=torch.uint8, device=d)
@@ -22,3 +22,5 @@ names = ["alpha chain","beta chain","alpha prep","beta prep"]
 for w in range(4):
     print("%-12s total cycles: mean %.0f max %.0f | spin cycles: mean %.0f (%.0f%%)" % (names[w], a[:,w,0].mean(), a[:,w,0].max(), a[:,w,1].mean(), 100*a[:,w,1].mean()/a[:,w,0].mean()))
 print("per step (T=1000): alpha %.0f beta %.0f cycles" % (a[:,0,0].mean()/1000, a[:,1,0].mean()/1000))
+for w in range(2):
+    print("%-12s per step: spin %.0f | ring loads %.0f | 8-step compute %.0f | rest %.0f" % (names[w], a[:,w,1].mean()/1000, a[:,w,2].mean()/1000, a[:,w,3].mean()/1000, (a[:,w,0]-a[:,w,1]-a[:,w,2]-a[:,w,3]).mean()/1000))
