@@ -34,7 +34,7 @@ namespace {
 
 constexpr int kSeg = 16;        // steps per F2 segment == checkpoint spacing
 constexpr int kBlk = 8;         // prep -> chain hand-off block and rescale period
-constexpr int kRingBlks = 4;    // ring depth (blocks)
+constexpr int kRingBlks = 8;    // ring depth (blocks)
 constexpr int kMaxSmallV = 64;  // probability row fits one lane group
 
 struct FastParams {
@@ -195,26 +195,21 @@ struct LaneCells {
 // ============================================================================================
 // F1 device code
 // ============================================================================================
-// LDS of F1.  Per direction a ring of kRingBlks blocks; a block holds, for each of its 8 steps, the emission
-// probability of every lattice label cell laid out per lane ([step][lane][PPL] floats: the chain reads its PPL
-// values with ONE wide ds_read) and the blank probability ([step]).  The label gather (PPL narrow LDS reads per
-// lane and step, 12-35 cycles each for a lone wave) is done by the prep waves, which have the slack.
-template <int PPL>
+// LDS of F1.  Per direction a ring of kRingBlks blocks; a block holds the probabilities of its 8 steps TRANSPOSED:
+// [label v][step] floats (32 B per label), plus an all-zero row V for lattice cells past the utterance's labels.
+// What costs on this machine is the number of LDS instructions (a wave pays >= 12 cycles for each, whatever its
+// width), so the per-lane gather is arranged to pull 4 consecutive time steps of the lane's label per instruction:
+// 2 reads per label cell and block instead of 8, and the producers need no gather at all.
 struct F1Lds {
-  static constexpr int kBlockFloats = kBlk * 64 * PPL;
-  float* ering;      // [2][kRingBlks][kBlk][64][PPL]
-  float* ybr;        // [2][kRingBlks][kBlk]
-  float* ysc;        // [4 prep waves][4 rows][V+1] staging of one pass's probability rows
+  float* ring;       // [2][kRingBlks][V+1][kBlk]
   int* flags;        // filled[2][kRingBlks], freed[2][kRingBlks]
+  int blk_floats;
   __device__ F1Lds(unsigned char* smem, int V) {
-    ering = reinterpret_cast<float*>(smem);
-    ybr = ering + 2 * kRingBlks * kBlockFloats;
-    ysc = ybr + 2 * kRingBlks * kBlk;
-    flags = reinterpret_cast<int*>(ysc + 4 * 4 * (V + 1));
+    blk_floats = (V + 1) * kBlk;
+    ring = reinterpret_cast<float*>(smem);
+    flags = reinterpret_cast<int*>(ring + 2 * kRingBlks * blk_floats);
   }
-  static size_t bytes(int V) {
-    return sizeof(float) * (2 * kRingBlks * kBlockFloats + 2 * kRingBlks * kBlk + 4 * 4 * (V + 1)) + sizeof(int) * 4 * kRingBlks;
-  }
+  static size_t bytes(int V) { return sizeof(float) * 2 * kRingBlks * (V + 1) * kBlk + sizeof(int) * 4 * kRingBlks; }
 };
 
 // Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
@@ -238,26 +233,14 @@ __device__ __forceinline__ float exp_le0(float x) {
 
 // Probability rows for one chain: each 16-lane DPP row of the wave takes one time step (4 steps per pass), a
 // lane holds the columns v = l16 + 16k, k < NV = ceil(V/16); max / sum by row-wide DPP all-reduce.
-template <int PPL, int NV>
-__device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int S, int dir, int first, int stride,
-                                          const F1Lds<PPL>& lds, int prep_id, int lane) {
-  const int V = p.V, ROW = V + 1;
+template <int NV>
+__device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int dir, int first, int stride,
+                                          const F1Lds& lds, int lane) {
+  const int V = p.V;
   const int nblk = (T + kBlk - 1) / kBlk;
-  float* myring = lds.ering + (size_t)dir * kRingBlks * F1Lds<PPL>::kBlockFloats;
-  float* myyb = lds.ybr + dir * kRingBlks * kBlk;
-  float* mysc = lds.ysc + (size_t)prep_id * 4 * ROW;
+  float* myring = lds.ring + (size_t)dir * kRingBlks * lds.blk_floats;
   volatile int* myfilled = lds.flags + dir * kRingBlks;
   volatile int* myfreed = lds.flags + 2 * kRingBlks + dir * kRingBlks;
-  int lab[PPL];                                   // staging column of this lane's label cells (V = the zero column)
-  {
-    const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
-#pragma unroll
-    for (int r = 0; r < PPL; r++) {
-      const int i = PPL * lane + r;
-      const int li = i < S ? (int)tg[i] : V;
-      lab[r] = (li >= 0 && li < V) ? li : V;
-    }
-  }
   const float* x = p.x + (int64_t)b * p.sB;
   float* ytab = p.ytab + (size_t)b * p.T * V;
   const int q = lane >> 4, l16 = lane & 15;
@@ -269,7 +252,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
   for (int k = 0; k < NV; k++) { col_live[k] = l16 + 16 * k < V; col_off[k] = (int64_t)(l16 + 16 * k) * p.sV; }
   unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime();
   (void)prof_spin; (void)prof_t0;
-  // the logits of block n+1 are requested before block n is worked on: an HBM miss (~1 us) would otherwise
+  // the logits of block n+stride are requested before block n is worked on: an HBM miss (~1 us) would otherwise
   // sit in front of every pass
   auto load_block = [&](int n, float (&out)[NP][NV]) {
 #pragma unroll
@@ -288,6 +271,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     load_block(n + stride, xn);
     const int slot = n % kRingBlks;
     if (n >= kRingBlks) { PROF_SPIN_BEGIN spin_until(&myfreed[slot], n - kRingBlks + 1); PROF_SPIN_END(prof_spin) }
+    float* blk = myring + (size_t)slot * lds.blk_floats;
 #pragma unroll
     for (int pass = 0; pass < NP; pass++) {
       const int tt = pass * 4 + q;
@@ -311,30 +295,14 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 #pragma unroll
         for (int k = 0; k < NV; k++) y[k] *= inv;
       }
-      // stage the pass's four rows, then every lane gathers the probabilities of its own label cells
-      float* srow = mysc + q * ROW;
       float* yrow = ytab + (size_t)(row_live ? t : 0) * V;
 #pragma unroll
       for (int k = 0; k < NV; k++) {
         if (col_live[k]) {
-          srow[l16 + 16 * k] = row_live ? y[k] : 0.f;
+          blk[(l16 + 16 * k) * kBlk + tt] = row_live ? y[k] : 0.f;        // transposed: [label][step]
           if (dir == 0 && row_live) yrow[l16 + 16 * k] = y[k];
         }
       }
-      if (l16 == 0) srow[V] = 0.f;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // same wave, LDS in order: rows are readable
-#pragma unroll
-      for (int qq = 0; qq < 4; qq++) {
-        const float* row = mysc + qq * ROW;
-        float ev[PPL];
-#pragma unroll
-        for (int r = 0; r < PPL; r++) ev[r] = row[lab[r]];
-        float* dst = myring + ((size_t)(slot * kBlk + pass * 4 + qq) * 64 + lane) * PPL;
-#pragma unroll
-        for (int r = 0; r < PPL; r++) dst[r] = ev[r];
-        if (lane == 0) myyb[slot * kBlk + pass * 4 + qq] = row[p.blank];
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // gathers done before the staging rows are reused
     }
     publish(&myfilled[slot], n + 1);     // every lane stores the same word: no divergence, one LDS write
 #pragma unroll
@@ -349,12 +317,11 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 
 // One serial chain (DIR 0: alpha forward, DIR 1: beta-with-emission backward).
 template <int PPL, int DIR>
-__device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, int S, const F1Lds<PPL>& lds, int lane) {
+__device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, int S, const F1Lds& lds, int lane) {
   constexpr int NC = 2 * PPL;
   const int V = p.V, blank = p.blank, L = 2 * S + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
-  const float* myring = lds.ering + (size_t)DIR * kRingBlks * F1Lds<PPL>::kBlockFloats;
-  const float* myyb = lds.ybr + DIR * kRingBlks * kBlk;
+  const float* myring = lds.ring + (size_t)DIR * kRingBlks * lds.blk_floats;
   volatile int* myfilled = lds.flags + DIR * kRingBlks;
   volatile int* myfreed = lds.flags + 2 * kRingBlks + DIR * kRingBlks;
   __builtin_amdgcn_s_setprio(3);
@@ -382,22 +349,25 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
     constexpr bool STEADY = decltype(steady_tag)::value;
     const int slot = n % kRingBlks;
     { PROF_SPIN_BEGIN spin_until(&myfilled[slot], n + 1); PROF_SPIN_END(prof_spin) }
-    // all of the block's probabilities up front (one wide read per step + the 8 blank probabilities): the LDS
-    // latency is paid once per 8 steps
-    typedef float fvec __attribute__((ext_vector_type(PPL)));
+    // all of the block's probabilities up front: per label cell (and for the blank) two wide reads fetch the 8 steps
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const fvec* rows = reinterpret_cast<const fvec*>(myring + (size_t)slot * F1Lds<PPL>::kBlockFloats) + lane;
-    fvec ef[kBlk];
+    const float* blk = myring + (size_t)slot * lds.blk_floats;
+    f4 eraw[PPL][2], braw[2];
 #pragma unroll
-    for (int tt = 0; tt < kBlk; tt++) ef[tt] = rows[tt * 64];
-    const f4* ybp = reinterpret_cast<const f4*>(myyb + slot * kBlk);
-    const f4 yb0 = ybp[0], yb1 = ybp[1];
+    for (int r = 0; r < PPL; r++) {
+      const f4* src = reinterpret_cast<const f4*>(blk + lc.lab[r] * kBlk);
+      eraw[r][0] = src[0]; eraw[r][1] = src[1];
+    }
+    {
+      const f4* src = reinterpret_cast<const f4*>(blk + blank * kBlk);
+      braw[0] = src[0]; braw[1] = src[1];
+    }
     double yb[kBlk], e[kBlk][PPL];
 #pragma unroll
     for (int tt = 0; tt < kBlk; tt++) {
-      yb[tt] = (double)(tt < 4 ? yb0[tt & 3] : yb1[tt & 3]);
+      yb[tt] = (double)braw[tt >> 2][tt & 3];
 #pragma unroll
-      for (int r = 0; r < PPL; r++) e[tt][r] = (double)((const float*)&ef[tt])[r];
+      for (int r = 0; r < PPL; r++) e[tt][r] = (double)eraw[r][tt >> 2][tt & 3];
     }
 #ifdef E2E_FAST_PROFILE
     const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
@@ -526,7 +496,7 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V;
-  const F1Lds<PPL> lds(smem, V);
+  const F1Lds lds(smem, V);
 
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
@@ -536,6 +506,8 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   }
   const int T = (int)Tq, S = (int)Sq;
   if (tid < 2 * 2 * kRingBlks) lds.flags[tid] = 0;
+  for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
+    lds.ring[(size_t)(i / kBlk) * lds.blk_floats + V * kBlk + (i % kBlk)] = 0.f;
   __syncthreads();
 
   const int wave = __builtin_amdgcn_readfirstlane(wid);
@@ -547,11 +519,10 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
     const int d = (wave == 2 || wave == 6) ? 0 : 1;
     const int first = wave >= 6 ? 1 : 0;
     (void)dir;
-    const int prep_id = d * 2 + first;
-    if (V <= 16) prep_wave<PPL, 1>(p, b, T, S, d, first, 2, lds, prep_id, lane);
-    else if (V <= 32) prep_wave<PPL, 2>(p, b, T, S, d, first, 2, lds, prep_id, lane);
-    else if (V <= 48) prep_wave<PPL, 3>(p, b, T, S, d, first, 2, lds, prep_id, lane);
-    else prep_wave<PPL, 4>(p, b, T, S, d, first, 2, lds, prep_id, lane);
+    if (V <= 16) prep_wave<1>(p, b, T, d, first, 2, lds, lane);
+    else if (V <= 32) prep_wave<2>(p, b, T, d, first, 2, lds, lane);
+    else if (V <= 48) prep_wave<3>(p, b, T, d, first, 2, lds, lane);
+    else prep_wave<4>(p, b, T, d, first, 2, lds, lane);
   }
 }
 
@@ -560,23 +531,25 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
 // ============================================================================================
 constexpr int kSegPerWave = 1;     // segments handled back to back by one wave (labels / label order set up once)
 constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before they are summed and written out
+constexpr int kYs = kSeg + 4;      // row stride (floats) of the transposed probability tile: 80 B spreads the
+                                   // 16-byte gathers of different labels over the LDS bank row
 
 template <int PPL>
 struct F2Lds {
   static constexpr int PROW = 64 * PPL + 64;   // label cells in label order, then 64 blank partial sums
   float* Ps;        // [kHalf][PROW]
-  float* ys;        // [kSeg][V+1]  probabilities of the segment, column V = 0
+  float* ys;        // [V+1][kYs]   probabilities of the segment, TRANSPOSED (label-major, 16 steps + pad), row V = 0
   float* invs;      // [kHalf]
   float* btot;      // [kHalf]
   int* starts;      // [66] first sorted slot of every label
   __device__ F2Lds(unsigned char* smem, int V) {
     Ps = reinterpret_cast<float*>(smem);
     ys = Ps + kHalf * PROW;
-    invs = ys + kSeg * (V + 1);
+    invs = ys + kYs * (V + 1);
     btot = invs + kHalf;
     starts = reinterpret_cast<int*>(btot + kHalf);
   }
-  static size_t bytes(int V) { return sizeof(float) * (kHalf * PROW + kSeg * (V + 1) + 2 * kHalf) + sizeof(int) * 66; }
+  static size_t bytes(int V) { return sizeof(float) * (kHalf * PROW + kYs * (V + 1) + 2 * kHalf) + sizeof(int) * 66; }
 };
 
 // rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows
@@ -584,7 +557,7 @@ template <int PPL>
 __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, int n, int h, const F2Lds<PPL>& lds,
                                             int lane, float& smin, float& smax) {
   constexpr int PROW = F2Lds<PPL>::PROW;
-  const int V = p.V, blank = p.blank, ROW = V + 1;
+  const int V = p.V, blank = p.blank;
   float* grads = p.grads + (size_t)b * p.T * V;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // prefix sums over the label-sorted cells, totals, s_t = sum_j alpha_t[j]*beta_t[j]
@@ -620,7 +593,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
         const float* pre = lds.Ps + k * PROW;
         float pv = (hi > lo) ? pre[hi - 1] - (lo > 0 ? pre[lo - 1] : 0.f) : 0.f;
         if (v == blank) pv += lds.btot[k];
-        grads[(size_t)(t0 + tt) * V + v] = lds.ys[tt * ROW + v] - pv * lds.invs[k];
+        grads[(size_t)(t0 + tt) * V + v] = lds.ys[v * kYs + tt] - pv * lds.invs[k];
       }
     }
   }
@@ -635,7 +608,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
   constexpr int NC = 2 * PPL;
   constexpr int kSlope = 3 * NC;    // exponent drop allowed per lane (see the alpha load below)
   constexpr int PROW = F2Lds<PPL>::PROW;
-  const int V = p.V, blank = p.blank, ROW = V + 1, L = 2 * S + 1, t0 = seg * kSeg;
+  const int V = p.V, blank = p.blank, L = 2 * S + 1, t0 = seg * kSeg;
   const float* ys = lds.ys;
   float* Ps = lds.Ps;
   const float rr = lc.r;
@@ -679,25 +652,34 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
     fA = lane > 0 ? ldexpf(1.f, max(min(ep - eA, 126), -126)) : 0.f;
     fB = lane < 63 ? ldexpf(1.f, max(min(eA - en, 126), -126)) : 0.f;
   }
-  const float* ylab[PPL];           // this lane's label columns in the staged rows
+  // this lane's label rows (and the blank row) in the transposed tile: one 16-byte read fetches 4 time steps
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4* ylab[PPL];
 #pragma unroll
-  for (int r = 0; r < PPL; r++) ylab[r] = ys + lc.lab[r];
+  for (int r = 0; r < PPL; r++) ylab[r] = reinterpret_cast<const f4*>(ys + lc.lab[r] * kYs);
+  const f4* yblank = reinterpret_cast<const f4*>(ys + blank * kYs);
+  f4 e4[PPL], b4;
 
 #pragma unroll
   for (int tt = 0; tt < kSeg; tt++) {
+    if ((tt & 3) == 0) {
+      b4 = yblank[tt >> 2];
+#pragma unroll
+      for (int r = 0; r < PPL; r++) e4[r] = ylab[r][tt >> 2];
+    }
     if (FULL || tt < n) {
-      const float yb = ys[tt * ROW + blank];
+      const float yb = b4[tt & 3];
       if (!FULL && t0 + tt == 0) {
 #pragma unroll
         for (int k = 0; k < NC; k++) a[k] = 0.f;
-        if (lane == 0) { a[0] = cond ? yb : 0.f; a[1] = rr * ylab[0][tt * ROW]; }
+        if (lane == 0) { a[0] = cond ? yb : 0.f; a[1] = rr * e4[0][tt & 3]; }
       } else {
         float pl = from_prev_lane(a[NC - 1]) * fA;
 #pragma unroll
         for (int r = 0; r < PPL; r++) {
           const float ob = a[2 * r], ol = a[2 * r + 1];
           a[2 * r] = (ob + rr * pl) * yb;
-          a[2 * r + 1] = (ol + rr * ob + lc.skp[r] * pl) * ylab[r][tt * ROW];
+          a[2 * r + 1] = (ol + rr * ob + lc.skp[r] * pl) * e4[r][tt & 3];
           pl = ol;
         }
       }
@@ -741,9 +723,14 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
 #pragma unroll
     for (int k = kHalf - 1; k >= 0; k--) {
       const int tt = h * kHalf + k;
+      if ((tt & 3) == 3) {
+        b4 = yblank[tt >> 2];
+#pragma unroll
+        for (int r = 0; r < PPL; r++) e4[r] = ylab[r][tt >> 2];
+      }
       if (FULL || tt < n) {
         const int t = t0 + tt;
-        const float yb = ys[tt * ROW + blank];
+        const float yb = b4[tt & 3];
         float bs[NC];                 // beta_t[j] (no emission at t)
         if (!FULL && t == T - 1) {
 #pragma unroll
@@ -773,7 +760,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
 #pragma unroll
         for (int r = 0; r < PPL; r++) {
           q[2 * r] = bs[2 * r] * yb;
-          q[2 * r + 1] = bs[2 * r + 1] * ylab[r][tt * ROW];
+          q[2 * r + 1] = bs[2 * r + 1] * e4[r][tt & 3];
         }
         if ((tt & 7) == 0) {
           const int e = tt == 0 ? eB0 : eB8;
@@ -792,7 +779,7 @@ template <int PPL>
 __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.y, lane = threadIdx.x;
-  const int V = p.V, blank = p.blank, ROW = V + 1, Tmax = p.T;
+  const int V = p.V, blank = p.blank, Tmax = p.T;
   const F2Lds<PPL> lds(smem, V);
   float* grads = p.grads + (size_t)b * Tmax * V;
   const float* x = p.x + (int64_t)b * p.sB;
@@ -830,7 +817,7 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
       const int i = PPL * lane + r;
       rank[r] = (i < S && lc.lab[r] < V) ? lds.starts[lc.lab[r]] + rank[r] : i;
     }
-    for (int tt = lane; tt < kSeg; tt += 64) lds.ys[tt * ROW + V] = 0.f;
+    for (int i = lane; i < kYs * (V + 1); i += 64) lds.ys[i] = 0.f;      // incl. the zero row V and dead steps
   }
 
   float smin = __builtin_huge_valf(), smax = 0.f;
@@ -847,8 +834,8 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
     // stage the segment's probability rows
     const float* ytab = p.ytab + ((size_t)b * Tmax + t0) * V;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int tt = 0; tt < n; tt++)
-      for (int v = lane; v < V; v += 64) lds.ys[tt * ROW + v] = ytab[tt * V + v];
+    for (int tt = 0; tt < kSeg; tt++)
+      for (int v = lane; v < V; v += 64) lds.ys[v * kYs + tt] = tt < n ? ytab[tt * V + v] : 0.f;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
     const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
     if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, lds, lane, smin, smax);
@@ -867,7 +854,7 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
 
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
-  const size_t lds1 = F1Lds<PPL>::bytes(p.V);
+  const size_t lds1 = F1Lds::bytes(p.V);
   E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute");
   const size_t lds2 = F2Lds<PPL>::bytes(p.V);
