@@ -192,6 +192,44 @@ def decode_numbers(dev):
     return out
 
 
+def wide_alphabet_numbers(dev):
+    """One GPU's share of BASELINE configs[4] (B=4096 over 8 GPUs -> 512 per GPU, T=256, V=8000, S<=64): the shape on
+    which the path is genuinely HBM-bound.  Same C-ABI call as the headline, inputs resident in HBM."""
+    from end2end_amd import _lib
+    L = _lib.load()
+    B, T, V, S = 512, 256, 8000, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, V, generator=g).to(dev)
+    tg = torch.randint(1, V, (B, S), generator=g).to(dev)
+    tl = torch.randint(S // 2, S + 1, (B,), generator=g).to(dev)
+    xl = torch.full((B,), T, dtype=torch.long, device=dev)
+    losses = torch.empty(B, device=dev)
+    grads = torch.empty((B, T, V), device=dev)
+    ws = torch.empty(L.e2e_ctc_loss_workspace_bytes(B, T, V, S, _lib.F32, _lib.ALGO_AUTO), dtype=torch.uint8, device=dev)
+
+    def call():
+        _lib.check(L.e2e_ctc_loss_fwd_bwd(x.data_ptr(), _lib.F32, 0, *x.stride(), tg.data_ptr(), tg.stride(0), xl.data_ptr(),
+                                          tl.data_ptr(), B, T, V, S, 0, losses.data_ptr(), grads.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), _lib.ALGO_AUTO, _lib.stream_ptr(dev)))
+    for _ in range(2):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    algo = 2.0 * V * 4 * B * T
+    return {"workload": "B=512 T=256 V=8000 S<=64 f32 (one GPU's share of configs[4])", "ms": ms,
+            "frames_per_s": B * T / (ms * 1e-3), "algorithmic_bytes": algo,
+            "roofline": {"bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "note": "logits are read twice (row log-sum-exp, dense gradient) and the gradient written once: 3/2 of the "
+                    "algorithmic bytes, so 2/3 of the roofline is the ceiling of this structure"}
+
+
 def recorded_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
     try:
@@ -296,6 +334,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host_batch, frames)
         if n_gpus == 1 and not args.no_decode:
             out["decode"] = decode_numbers(dev)
+            out["wide_alphabet"] = wide_alphabet_numbers(dev)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -56,16 +56,21 @@ extern "C" {
 int e2e_ctc_abi_version(void) { return E2E_CTC_ABI_VERSION; }
 const char* e2e_last_error(void) { return g_err; }
 
+static bool use_wide(int dtype, int T, int V, int Smax) {
+  return !fast_supported(T, V, Smax, dtype) && wide_supported(T, V, Smax, dtype);
+}
+
 static int resolve_algo(int algo, int dtype, int T, int V, int Smax) {
   if (algo == E2E_ALGO_EXACT) return E2E_ALGO_EXACT;
   if (algo == E2E_ALGO_FAST) return E2E_ALGO_FAST;
-  return (dtype == E2E_F32 && fast_supported(T, V, Smax, dtype)) ? E2E_ALGO_AUTO : E2E_ALGO_EXACT;
+  return (dtype == E2E_F32 && (fast_supported(T, V, Smax, dtype) || wide_supported(T, V, Smax, dtype))) ? E2E_ALGO_AUTO : E2E_ALGO_EXACT;
 }
 
 size_t e2e_ctc_loss_workspace_bytes(int B, int T, int V, int Smax, int dtype, int algo) {
   if (B < 0 || T < 1 || V < 1 || Smax < 0) return 0;
   const int r = resolve_algo(algo, dtype, T, V, Smax);
   size_t n = 0;
+  if (r != E2E_ALGO_EXACT && use_wide(dtype, T, V, Smax)) return wide_workspace_bytes(B, T, V, Smax, r == E2E_ALGO_AUTO) + 256;
   if (r == E2E_ALGO_EXACT || r == E2E_ALGO_AUTO) n += exact_workspace_bytes(B, T, V, Smax);   // (fallback region)
   if (r == E2E_ALGO_FAST || r == E2E_ALGO_AUTO) n += fast_workspace_bytes(B, T, V, Smax);
   return n + 256;
@@ -94,6 +99,7 @@ int e2e_ctc_loss_fwd_bwd(const void* x, int dtype, int input_is_logprobs,
              B, T, V, Smax, blank, losses, grads, workspace, workspace_bytes, (hipStream_t)stream};
   const int r = resolve_algo(algo, dtype, T, V, Smax);
   if (r == E2E_ALGO_EXACT) return launch_exact(a);
+  if (use_wide(dtype, T, V, Smax)) return launch_wide(a, r == E2E_ALGO_AUTO);
   if (r == E2E_ALGO_FAST) {
     if (!fast_supported(T, V, Smax, dtype)) { set_error("fast CTC path does not support this shape/dtype"); return E2E_ERR_UNSUPPORTED; }
     return launch_fast(a, false);

@@ -34,6 +34,10 @@ int launch_exact(const LossArgs& a);
 size_t fast_workspace_bytes(int B, int T, int V, int Smax);
 int launch_fast(const LossArgs& a, bool fallback_to_exact);
 bool fast_supported(int T, int V, int Smax, int dtype);
+// wide alphabets: per-utterance compaction around the fast path (ctc_loss_wide.hip)
+bool wide_supported(int T, int V, int Smax, int dtype);
+size_t wide_workspace_bytes(int B, int T, int V, int Smax, bool with_exact);
+int launch_wide(const LossArgs& a, bool fallback_to_exact);
 
 }  // namespace e2e
 

@@ -35,7 +35,7 @@ namespace {
 constexpr int kSeg = 16;        // steps per F2 segment == checkpoint spacing
 constexpr int kBlk = 8;         // prep -> chain hand-off block and rescale period
 constexpr int kRingBlks = 8;    // ring depth (blocks)
-constexpr int kMaxSmallV = 64;  // probability row fits one lane group
+constexpr int kMaxSmallV = 96;  // alphabet columns the lattice kernels take (prep: <= 6 columns per lane)
 
 struct FastParams {
   const float* x; int64_t sB, sT, sV; int logprobs;
@@ -522,7 +522,8 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
     if (V <= 16) prep_wave<1>(p, b, T, d, first, 2, lds, lane);
     else if (V <= 32) prep_wave<2>(p, b, T, d, first, 2, lds, lane);
     else if (V <= 48) prep_wave<3>(p, b, T, d, first, 2, lds, lane);
-    else prep_wave<4>(p, b, T, d, first, 2, lds, lane);
+    else if (V <= 64) prep_wave<4>(p, b, T, d, first, 2, lds, lane);
+    else prep_wave<6>(p, b, T, d, first, 2, lds, lane);
   }
 }
 
@@ -541,7 +542,7 @@ struct F2Lds {
   float* ys;        // [V+1][kYs]   probabilities of the segment, TRANSPOSED (label-major, 16 steps + pad), row V = 0
   float* invs;      // [kHalf]
   float* btot;      // [kHalf]
-  int* starts;      // [66] first sorted slot of every label
+  int* starts;      // [130] first sorted slot of every label (V+1 entries used)
   __device__ F2Lds(unsigned char* smem, int V) {
     Ps = reinterpret_cast<float*>(smem);
     ys = Ps + kHalf * PROW;
@@ -549,7 +550,7 @@ struct F2Lds {
     btot = invs + kHalf;
     starts = reinterpret_cast<int*>(btot + kHalf);
   }
-  static size_t bytes(int V) { return sizeof(float) * (kHalf * PROW + kYs * (V + 1) + 2 * kHalf) + sizeof(int) * 66; }
+  static size_t bytes(int V) { return sizeof(float) * (kHalf * PROW + kYs * (V + 1) + 2 * kHalf) + sizeof(int) * 130; }
 };
 
 // rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   LaneCells<PPL> lc;
   int rank[PPL];
   if (seg_first * kSeg < T) {
-    lds.starts[lane] = 0; if (lane < 2) lds.starts[64 + lane] = 0;
+    lds.starts[lane] = 0; lds.starts[64 + lane] = 0; if (lane < 2) lds.starts[128 + lane] = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, lane);
 #pragma unroll
@@ -805,11 +806,15 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
-      const int cnt = lds.starts[lane];
+      // exclusive prefix over the label counts, two chunks of 64 labels
+      const int c0 = lds.starts[lane], c1 = lds.starts[64 + lane];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int incl = wave_scan(cnt);
-      lds.starts[lane] = incl - cnt;
-      if (lane == 63) lds.starts[64] = incl;
+      const int i0 = wave_scan(c0);
+      const int t0s = __builtin_amdgcn_readlane(i0, 63);
+      const int i1 = wave_scan(c1) + t0s;
+      lds.starts[lane] = i0 - c0;
+      lds.starts[64 + lane] = i1 - c1;
+      if (lane == 63) lds.starts[128] = i1;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll

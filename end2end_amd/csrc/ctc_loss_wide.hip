@@ -1,0 +1,329 @@
+// Wide alphabets (V > 64, e.g. the V=8000 word-piece / OCR shape): the lattice only ever touches the utterance's
+// own labels, so the alphabet is COMPACTED per utterance to its distinct labels + the blank (<= Smax+1 columns) and
+// the small-alphabet lattice kernels (ctc_loss_fast.hip, with the exact kernel as their fallback) run unchanged on
+// the compact log-probabilities.  Around them two streaming kernels carry all of the HBM traffic:
+//   wide_rows_kernel   one wave per frame: online max / sum-exp over the V logits (read once, 16 B per lane), writes
+//                      the row's log-sum-exp and the <= Smax+1 compact log-probs
+//   wide_emit_kernel   one wave per frame: grad[v] = exp(x[v] - lse) for all v (logits read a second time, gradient
+//                      written once), then the <= Smax+1 label columns are overwritten with (prob - posterior) from the
+//                      compact gradient
+// Bytes: 3*V*4 per frame against the algorithmic 2*V*4 (the logits cannot stay on chip between the two passes:
+// 4.2 GB per GPU at B=512, T=256, V=8000), i.e. at best 2/3 of the HBM roofline.
+// Reference semantics: src/losses/ctc_loss.cpp:102-117 (gradient over the full (T,V) slab, quirks Q1/Q2).
+#include "common.h"
+
+#pragma clang fp contract(fast)
+
+namespace e2e {
+namespace {
+
+constexpr int kWaves = 4;      // frames per workgroup
+
+struct WideParams {
+  const float* x; int64_t sB, sT, sV; int logprobs;
+  const int64_t* targets; int64_t tgt_stride; const int64_t* x_len; const int64_t* t_len;
+  int B, T, V, Smax, VC, blank;
+  float* grads; float* losses;
+  int64_t* targets_c;   // [B][Smax]  compact id of target i
+  int* clabel;          // [B][VC]    original label of compact column k (-1: unused); column VC-1 is the blank
+  float* lse;           // [B][T]
+  float* shift;         // [B][T]     max of the frame's compact log-probs (<= 0), removed from the compact row
+  float* xc;            // [B][T][VC] compact log-probs minus the frame's shift
+  const float* gc;      // [B][T][VC] compact gradient from the lattice kernels
+};
+
+__device__ __forceinline__ float exp_acc(float x) {        // ~1 ulp, x <= ~88
+  x = fmaxf(x, -200.f);
+  const float t = x * 1.44269504088896340736f;
+  const float n = rintf(t);
+  float f = fmaf(x, 1.44269504088896340736f, -n);
+  f = fmaf(x, 1.92596299112661746e-8f, f);
+  return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+__device__ __forceinline__ float wave_max_f(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
+__device__ __forceinline__ float wave_sum_f(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+
+// One workgroup per utterance: distinct labels in order of first appearance -> compact ids.
+__global__ __launch_bounds__(256) void wide_compact_kernel(WideParams p) {
+  extern __shared__ int sh[];
+  int* lab = sh;                    // [Smax]
+  int* rep = sh + p.Smax;           // [Smax] index of the first occurrence of target i's label
+  int* cid = sh + 2 * p.Smax;       // [Smax] compact id (valid at representatives)
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t Sq = p.t_len[b];
+  const int S = Sq < 0 ? 0 : (Sq > p.Smax ? p.Smax : (int)Sq);
+  const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
+  for (int i = tid; i < S; i += 256) lab[i] = (int)tg[i];
+  for (int k = tid; k < p.VC; k += 256) p.clabel[(size_t)b * p.VC + k] = (k == p.VC - 1) ? p.blank : -1;
+  __syncthreads();
+  for (int i = tid; i < S; i += 256) {
+    const int li = lab[i];
+    int r = i;
+    for (int k = 0; k < i; k++) if (lab[k] == li) { r = k; break; }
+    rep[i] = r;
+  }
+  __syncthreads();
+  for (int i = tid; i < S; i += 256) {
+    int c = 0;
+    if (rep[i] == i) for (int k = 0; k < i; k++) c += rep[k] == k ? 1 : 0;
+    cid[i] = c;
+  }
+  __syncthreads();
+  for (int i = tid; i < p.Smax; i += 256) {
+    int64_t out = p.VC - 1;                       // beyond the utterance's targets: never read by the lattice
+    if (i < S) {
+      const int li = lab[i];
+      const int c = cid[rep[i]];
+      // a target equal to the blank id, or outside the alphabet, keeps the reference's semantics by mapping to the
+      // compact blank column: the lattice kernels then hand the utterance to the exact path (ctc_loss.cpp:53,109-113)
+      out = (li == p.blank || li < 0 || li >= p.V) ? p.VC - 1 : c;
+      if (rep[i] == i && out != p.VC - 1) p.clabel[(size_t)b * p.VC + c] = li;
+    }
+    p.targets_c[(size_t)b * p.Smax + i] = out;
+  }
+}
+
+// log-sum-exp of every live frame + its compact log-probs.  One wave per frame.
+template <bool VEC4>
+__global__ __launch_bounds__(64 * kWaves) void wide_rows_kernel(WideParams p) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * kWaves + w;
+  if (row >= (int64_t)p.B * p.T) return;
+  const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+  const int64_t Tq = p.x_len[b];
+  if (t >= Tq) return;
+  const float* xr = p.x + (int64_t)b * p.sB + (int64_t)t * p.sT;
+  float lse = 0.f;
+  if (!p.logprobs) {
+    float m = -__builtin_huge_valf(), s = 0.f;
+    if (VEC4) {
+      const float4* x4 = reinterpret_cast<const float4*>(xr);
+      const int n4 = p.V >> 2;
+      int i = lane;
+      for (; i + 192 < n4; i += 256) {              // 4 independent 16-byte loads in flight, one rescale test per 16 values
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = x4[i + 64 * u];
+        float cm = v[0].x;
+#pragma unroll
+        for (int u = 0; u < 4; u++) cm = fmaxf(cm, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+        if (cm > m) { s *= exp_acc(m - cm); m = cm; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) s += exp_acc(v[u].x - m) + exp_acc(v[u].y - m) + exp_acc(v[u].z - m) + exp_acc(v[u].w - m);
+      }
+      for (; i < n4; i += 64) {
+        const float4 v = x4[i];
+        const float cm = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+        if (cm > m) { s *= exp_acc(m - cm); m = cm; }
+        s += exp_acc(v.x - m) + exp_acc(v.y - m) + exp_acc(v.z - m) + exp_acc(v.w - m);
+      }
+      for (int i = (n4 << 2) + lane; i < p.V; i += 64) {
+        const float v = xr[i];
+        if (v > m) { s *= exp_acc(m - v); m = v; }
+        s += exp_acc(v - m);
+      }
+    } else {
+      for (int i = lane; i < p.V; i += 64) {
+        const float v = xr[(int64_t)i * p.sV];
+        if (v > m) { s *= exp_acc(m - v); m = v; }
+        s += exp_acc(v - m);
+      }
+    }
+    const float M = wave_max_f(m);
+    s = wave_sum_f(m > -__builtin_huge_valf() ? s * exp_acc(m - M) : 0.f);
+    lse = M + logf(s);
+    if (lane == 0) p.lse[row] = lse;
+  }
+  // Compact row, shifted so that its largest entry is 0.  A common per-frame factor cancels in the posteriors; it
+  // keeps the lattice rows from decaying by ~V per step (2^-13 at V=8000), which the f32 segment kernel could not
+  // bridge between two rescales.  The loss is corrected by sum_t shift_t afterwards (wide_loss_fix_kernel).
+  float* xc = p.xc + (size_t)row * p.VC;
+  const int* cl = p.clabel + (size_t)b * p.VC;
+  float cm = -__builtin_huge_valf();
+  for (int k = lane; k < p.VC; k += 64) {
+    const int l = cl[k];
+    const float v = l >= 0 ? xr[(int64_t)l * p.sV] - lse : -__builtin_huge_valf();
+    xc[k] = v;
+    cm = fmaxf(cm, v);
+  }
+  cm = wave_max_f(cm);
+  if (!(cm > -__builtin_huge_valf())) cm = 0.f;                  // every compact entry is log 0: nothing to shift
+  for (int k = lane; k < p.VC; k += 64) xc[k] -= cm;             // same lanes, same addresses as above
+  if (lane == 0) p.shift[row] = cm;
+}
+
+// loss_true = loss_shifted - sum_{t < T} shift_t   (log Z gains the sum of the removed per-frame factors)
+__global__ __launch_bounds__(64) void wide_loss_fix_kernel(WideParams p) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int64_t Tq = p.x_len[b];
+  if (Tq < 1 || Tq > p.T) return;
+  double s = 0.0;
+  for (int t = lane; t < (int)Tq; t += 64) s += (double)p.shift[(size_t)b * p.T + t];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) p.losses[b] = (float)((double)p.losses[b] - s);
+}
+
+// dense gradient rows.  One wave per frame.
+template <bool VEC4>
+__global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * kWaves + w;
+  if (row >= (int64_t)p.B * p.T) return;
+  const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
+  const float* xr = p.x + (int64_t)b * p.sB + (int64_t)t * p.sT;
+  float* gr = p.grads + (size_t)row * p.V;
+  const bool bad_len = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
+  const float loss = p.losses[b];
+  const bool poison = bad_len || !(loss < __builtin_huge_valf());      // invalid lengths / infeasible (Q2) / NaN
+  const bool live = !poison && t < Tq;
+  const bool zero = !poison && !live && !p.logprobs;                   // padded frame, fused logits: 0 (else exp(lp), Q1)
+  const float lse = (live && !p.logprobs) ? p.lse[row] : 0.f;
+  const float qnan = __builtin_nanf("");
+  // label columns (prob - posterior, with posterior = exp(xc) - gc in the shifted compact space): fetched and computed
+  // up front, written after the dense row
+  constexpr int kMaxFix = 2;            // VC <= 128 columns
+  float fix[kMaxFix]; int fixcol[kMaxFix];
+#pragma unroll
+  for (int u = 0; u < kMaxFix; u++) { fix[u] = 0.f; fixcol[u] = -1; }
+  if (live) {
+    const float* gc = p.gc + (size_t)row * p.VC;
+    const int* cl = p.clabel + (size_t)b * p.VC;
+    const float sh = p.shift[row];
+#pragma unroll
+    for (int u = 0; u < kMaxFix; u++) {
+      const int k = lane + 64 * u;
+      if (k < p.VC) {
+        const int l = cl[k];
+        if (l >= 0) {
+          const float xl = xr[(int64_t)l * p.sV] - lse;
+          fix[u] = exp_acc(xl) - (exp_acc(xl - sh) - gc[k]);
+          fixcol[u] = l;
+        }
+      }
+    }
+  }
+  if (VEC4) {
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    const vf4* x4 = reinterpret_cast<const vf4*>(xr);
+    vf4* g4 = reinterpret_cast<vf4*>(gr);
+    const int n4 = p.V >> 2;
+    if (poison || zero) {
+      const float f = poison ? qnan : 0.f;
+      const vf4 o = {f, f, f, f};
+      for (int i = lane; i < n4; i += 64) __builtin_nontemporal_store(o, &g4[i]);
+    } else {
+      // 8 independent 16-byte loads in flight per lane, then their exps and (streaming) stores
+      int i = lane;
+      for (; i + 448 < n4; i += 512) {
+        vf4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(&x4[i + 64 * u]);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const vf4 o = {exp_acc(v[u].x - lse), exp_acc(v[u].y - lse), exp_acc(v[u].z - lse), exp_acc(v[u].w - lse)};
+          __builtin_nontemporal_store(o, &g4[i + 64 * u]);
+        }
+      }
+      for (; i + 64 < n4; i += 128) {
+        vf4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) v[u] = __builtin_nontemporal_load(&x4[i + 64 * u]);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const vf4 o = {exp_acc(v[u].x - lse), exp_acc(v[u].y - lse), exp_acc(v[u].z - lse), exp_acc(v[u].w - lse)};
+          __builtin_nontemporal_store(o, &g4[i + 64 * u]);
+        }
+      }
+      for (; i < n4; i += 64) {
+        const vf4 v = x4[i];
+        const vf4 o = {exp_acc(v.x - lse), exp_acc(v.y - lse), exp_acc(v.z - lse), exp_acc(v.w - lse)};
+        g4[i] = o;
+      }
+    }
+    for (int i = (n4 << 2) + lane; i < p.V; i += 64) gr[i] = poison ? qnan : (zero ? 0.f : exp_acc(xr[i] - lse));
+  } else {
+    for (int i = lane; i < p.V; i += 64) gr[i] = poison ? qnan : (zero ? 0.f : exp_acc(xr[(int64_t)i * p.sV] - lse));
+  }
+  if (live) {
+    // the dense row above and these columns are written by different lanes of this wave: order them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+    for (int u = 0; u < kMaxFix; u++) if (fixcol[u] >= 0) gr[fixcol[u]] = fix[u];
+  }
+}
+
+struct WideLayout { size_t targets_c, clabel, lse, shift, xc, gc, inner, total; int VC; };
+
+WideLayout wide_layout(int B, int T, int V, int Smax, bool with_exact) {
+  (void)V;
+  WideLayout l;
+  l.VC = Smax + 1;
+  size_t o = 0;
+  l.targets_c = o; o += align_up((size_t)B * (Smax > 0 ? Smax : 1) * sizeof(int64_t), 256);
+  l.clabel = o; o += align_up((size_t)B * l.VC * sizeof(int), 256);
+  l.lse = o; o += align_up((size_t)B * T * sizeof(float), 256);
+  l.shift = o; o += align_up((size_t)B * T * sizeof(float), 256);
+  l.xc = o; o += align_up((size_t)B * T * l.VC * sizeof(float), 256);
+  l.gc = o; o += align_up((size_t)B * T * l.VC * sizeof(float), 256);
+  l.inner = o;
+  o += fast_workspace_bytes(B, T, l.VC, Smax);
+  if (with_exact) o += exact_workspace_bytes(B, T, l.VC, Smax);
+  l.total = o;
+  return l;
+}
+
+}  // namespace
+
+bool wide_supported(int T, int V, int Smax, int dtype) {
+  return dtype == E2E_F32 && V > 1 && Smax >= 0 && fast_supported(T, Smax + 1, Smax, dtype);
+}
+
+size_t wide_workspace_bytes(int B, int T, int V, int Smax, bool with_exact) {
+  return wide_layout(B, T, V, Smax, with_exact).total;
+}
+
+int launch_wide(const LossArgs& a, bool fallback_to_exact) {
+  const WideLayout l = wide_layout(a.B, a.T, a.V, a.Smax, fallback_to_exact);
+  if (!a.ws || a.ws_bytes < l.total) { set_error("workspace too small: %zu < %zu", a.ws_bytes, l.total); return E2E_ERR_WORKSPACE; }
+  if (a.B == 0) return E2E_OK;
+  char* ws = reinterpret_cast<char*>(a.ws);
+  WideParams p;
+  p.x = reinterpret_cast<const float*>(a.x); p.sB = a.sB; p.sT = a.sT; p.sV = a.sV; p.logprobs = a.logprobs;
+  p.targets = a.targets; p.tgt_stride = a.tgt_stride; p.x_len = a.x_len; p.t_len = a.t_len;
+  p.B = a.B; p.T = a.T; p.V = a.V; p.Smax = a.Smax; p.VC = l.VC; p.blank = a.blank;
+  p.grads = reinterpret_cast<float*>(a.grads); p.losses = reinterpret_cast<float*>(a.losses);
+  p.targets_c = reinterpret_cast<int64_t*>(ws + l.targets_c); p.clabel = reinterpret_cast<int*>(ws + l.clabel);
+  p.lse = reinterpret_cast<float*>(ws + l.lse); p.shift = reinterpret_cast<float*>(ws + l.shift);
+  p.xc = reinterpret_cast<float*>(ws + l.xc);
+  p.gc = reinterpret_cast<const float*>(ws + l.gc);
+  const bool vec4 = a.sV == 1 && (a.sT % 4 == 0) && (a.sB % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0) &&
+                    (a.V % 4 == 0) && (reinterpret_cast<uintptr_t>(a.grads) % 16 == 0);
+  const int64_t rows = (int64_t)a.B * a.T;
+  const dim3 grid_rows((unsigned)((rows + kWaves - 1) / kWaves));
+  hipLaunchKernelGGL(wide_compact_kernel, dim3(a.B), dim3(256), sizeof(int) * 3 * (a.Smax > 0 ? a.Smax : 1), a.stream, p);
+  E2E_HIP_CHECK(hipGetLastError(), "wide_compact_kernel launch");
+  if (vec4) hipLaunchKernelGGL(wide_rows_kernel<true>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
+  else hipLaunchKernelGGL(wide_rows_kernel<false>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
+  E2E_HIP_CHECK(hipGetLastError(), "wide_rows_kernel launch");
+  // the lattice on the compact alphabet: log-probabilities in, (prob - posterior) out
+  LossArgs c = a;
+  c.x = p.xc; c.dtype = E2E_F32; c.logprobs = 1;
+  c.sB = (int64_t)a.T * l.VC; c.sT = l.VC; c.sV = 1;
+  c.targets = p.targets_c; c.tgt_stride = a.Smax > 0 ? a.Smax : 1;
+  c.V = l.VC; c.blank = l.VC - 1;
+  c.grads = ws + l.gc;
+  c.ws = ws + l.inner; c.ws_bytes = a.ws_bytes - l.inner;
+  const int rc = launch_fast(c, fallback_to_exact);
+  if (rc != E2E_OK) return rc;
+  hipLaunchKernelGGL(wide_loss_fix_kernel, dim3(a.B), dim3(64), 0, a.stream, p);
+  E2E_HIP_CHECK(hipGetLastError(), "wide_loss_fix_kernel launch");
+  if (vec4) hipLaunchKernelGGL(wide_emit_kernel<true>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
+  else hipLaunchKernelGGL(wide_emit_kernel<false>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
+  E2E_HIP_CHECK(hipGetLastError(), "wide_emit_kernel launch");
+  return E2E_OK;
+}
+
+}  // namespace e2e

@@ -99,9 +99,7 @@ def test_c2_shape_sample_against_oracle(algo):
 
 @pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS.get)
 def test_wide_alphabet_sample_against_oracle(algo):
-    # C5-like: V=8000, S<=64, T=256 on two utterances
-    if algo == _lib.ALGO_FAST:
-        pytest.skip("wide alphabets take the exact kernel for now")
+    # C5-like: V=8000, S<=64, T=256 on two utterances (per-utterance alphabet compaction around the lattice kernels)
     g = torch.Generator().manual_seed(5)
     B, T, V, S = 2, 256, 8000, 64
     x = torch.randn(B, T, V, generator=g)
@@ -115,7 +113,7 @@ def test_wide_alphabet_sample_against_oracle(algo):
     for b in range(B):
         g_o[b, xl[b]:] = 0.0
     U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
-    U.assert_same(grads, g_o, F32_RTOL, 1e-7, "grads")
+    U.assert_same(grads, g_o, F32_RTOL, 5e-7, "grads")
 
 
 def test_full_c2_properties():
@@ -181,3 +179,54 @@ def test_fast_path_falls_back_on_blank_valued_targets_and_tiny_probabilities():
     U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
     lf, _ = U.c_abi_loss(lp, tg, xl, tl, 0, True, _lib.ALGO_FAST)
     assert np.isnan(lf[0])            # (a) is always handed to the exact kernel
+
+
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS.get)
+@pytest.mark.parametrize("logprobs", [False, True])
+def test_wide_alphabet_edge_cases(algo, logprobs):
+    # V=203 (not a multiple of 4: scalar row loops), ragged lengths, repeats, an empty target, an infeasible utterance,
+    # blank in the middle of the alphabet, time-major strides
+    g = torch.Generator().manual_seed(77)
+    B, T, V, S = 5, 40, 203, 12
+    x = torch.randn(T, B, V, generator=g).permute(1, 0, 2)          # (B,T,V) view of a time-major tensor
+    if logprobs:
+        x = torch.log_softmax(x, -1)
+    tg = torch.randint(0, V - 1, (B, S), generator=g)
+    tg[tg == 100] = 101                                              # blank id 100 must not appear
+    tg[1, 3] = tg[1, 4] = tg[1, 5]                                   # repeats
+    xl = torch.tensor([40, 31, 40, 9, 22])
+    tl = torch.tensor([12, 7, 0, 12, 5])                             # utterance 3: T=9 < S=12 -> infeasible
+    lp = (x if logprobs else torch.log_softmax(x.double(), -1)).double().numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 100)
+    if not logprobs:
+        for b in range(B):
+            if np.isfinite(l_o[b]):
+                g_o[b, xl[b]:] = 0.0
+    losses, grads = run(x, tg, xl, tl, 100, logprobs, algo, l_o)
+    U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads, g_o, F32_RTOL, 1e-6, "grads")
+
+
+def test_full_c5_shape_properties():
+    # one GPU's share of BASELINE configs[4]: B=512, T=256, V=8000, S<=64 (4.2 GB of logits)
+    g = torch.Generator().manual_seed(5)
+    B, T, V, S = 512, 256, 8000, 64
+    x = torch.randn(B, T, V, generator=g, dtype=torch.float32)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tl = torch.randint(S // 2, S + 1, (B,), generator=g)
+    xl = torch.randint(200, T + 1, (B,), generator=g)
+    d = U.dev()
+    xd = x.to(d)
+    losses, grads = U.c_abi_loss(xd, tg, xl, tl, 0, False)
+    assert np.isfinite(losses).all() and (losses > 0).all()
+    idx = [0, 255, 511]
+    sub = grads[idx].astype(np.float64)
+    assert np.abs(sub.sum(-1)).max() < 2e-4                      # rows of softmax - posterior sum to zero
+    for k, b in enumerate(idx):
+        assert not sub[k, xl[b]:].any()
+    lp = torch.log_softmax(x[idx].double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg[idx].numpy(), xl[idx].numpy(), tl[idx].numpy(), 0)
+    for k, b in enumerate(idx):
+        g_o[k, xl[b]:] = 0.0
+    U.assert_same(losses[idx], l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads[idx], g_o, F32_RTOL, 5e-7, "grads")

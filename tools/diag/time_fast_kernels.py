@@ -26,3 +26,5 @@ def run(B, T, V, S, reps=20):
     print("B=%d T=%d V=%d S<=%d: %.1f us per call, %d flagged" % (B, T, V, S, ms * 1e3, nan))
 for shape in [(256, 1000, 29, 200), (256, 1000, 29, 127), (256, 1000, 29, 63), (256, 500, 29, 100), (512, 1000, 29, 200), (1024, 1000, 29, 200), (256, 1000, 64, 200)]:
     run(*shape)
+print("wide alphabet (C5 per-GPU share):")
+run(512, 256, 8000, 64, reps=5)
