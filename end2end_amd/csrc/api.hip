@@ -71,7 +71,8 @@ size_t e2e_ctc_loss_workspace_bytes(int B, int T, int V, int Smax, int dtype, in
   const int r = resolve_algo(algo, dtype, T, V, Smax);
   size_t n = 0;
   if (r != E2E_ALGO_EXACT && use_wide(dtype, T, V, Smax)) return wide_workspace_bytes(B, T, V, Smax, r == E2E_ALGO_AUTO) + 256;
-  if (r == E2E_ALGO_EXACT || r == E2E_ALGO_AUTO) n += exact_workspace_bytes(B, T, V, Smax);   // (fallback region)
+  if (r == E2E_ALGO_EXACT) n += exact_workspace_bytes(B, T, V, Smax);
+  if (r == E2E_ALGO_AUTO) n += exact_fallback_workspace_bytes(B, T, V, Smax);
   if (r == E2E_ALGO_FAST || r == E2E_ALGO_AUTO) n += fast_workspace_bytes(B, T, V, Smax);
   return n + 256;
 }

@@ -29,7 +29,8 @@ struct LossArgs {
   hipStream_t stream;
 };
 
-size_t exact_workspace_bytes(int B, int T, int V, int Smax);
+size_t exact_workspace_bytes(int B, int T, int V, int Smax);            // every utterance (algo EXACT)
+size_t exact_fallback_workspace_bytes(int B, int T, int V, int Smax);   // flagged-utterance fallback of the fast path
 int launch_exact(const LossArgs& a);
 size_t fast_workspace_bytes(int B, int T, int V, int Smax);
 int launch_fast(const LossArgs& a, bool fallback_to_exact);

@@ -49,10 +49,10 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// One utterance b, with the alpha slab `slot` of the workspace.
 template <typename IO>
-__global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int b = blockIdx.x, tid = threadIdx.x;
+__device__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, int slot) {
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int V = p.V, Tmax = p.T, Lmax = p.Lmax, Smax = p.Smax, blank = p.blank;
 
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   const IO* x = reinterpret_cast<const IO*>(p.x) + (int64_t)b * p.sB;
   IO* grads = reinterpret_cast<IO*>(p.grads) + (size_t)b * (size_t)Tmax * (size_t)V;
   IO* losses = reinterpret_cast<IO*>(p.losses);
-  double* wa = p.ws_alpha + (size_t)b * (size_t)Tmax * (size_t)Lmax;
-  double* wl = p.ws_lse + (size_t)b * (size_t)Tmax;
+  double* wa = p.ws_alpha + (size_t)slot * (size_t)Tmax * (size_t)Lmax;
+  double* wl = p.ws_lse + (size_t)slot * (size_t)Tmax;
 
   if (p.mode != 0 && p.flags[b] == 0) return;
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
@@ -230,6 +230,17 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   }
 }
 
+// Workgroups stride over the batch (gridDim.x slabs of workspace).  In flagged mode the grid is small: only the
+// utterances the fast path handed over are computed, one after the other per workgroup.
+template <typename IO>
+__global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    ctc_exact_one<IO>(p, smem, b, blockIdx.x);
+    __syncthreads();                       // LDS is reused by the next utterance
+  }
+}
+
 size_t exact_lds_bytes(int V, int Smax) {
   const size_t Lmax = 2 * (size_t)Smax + 1, S1 = Smax > 0 ? Smax : 1;
   return sizeof(double) * (2 * Lmax + S1 + (size_t)V + 16) + sizeof(int) * (Lmax + 2 * S1);
@@ -237,10 +248,21 @@ size_t exact_lds_bytes(int V, int Smax) {
 
 }  // namespace
 
+constexpr int kFallbackSlabs = 32;     // workgroups (= alpha slabs) of the flagged-utterance fallback launch
+
+static size_t exact_bytes_for(int slabs, int T, int Smax) {
+  const size_t Lmax = 2 * (size_t)Smax + 1;
+  return align_up((size_t)slabs * T * Lmax * sizeof(double), 256) + align_up((size_t)slabs * T * sizeof(double), 256);
+}
+
 size_t exact_workspace_bytes(int B, int T, int V, int Smax) {
   (void)V;
-  const size_t Lmax = 2 * (size_t)Smax + 1;
-  return align_up((size_t)B * T * Lmax * sizeof(double), 256) + align_up((size_t)B * T * sizeof(double), 256);
+  return exact_bytes_for(B, T, Smax);
+}
+
+size_t exact_fallback_workspace_bytes(int B, int T, int V, int Smax) {
+  (void)V;
+  return exact_bytes_for(B < kFallbackSlabs ? B : kFallbackSlabs, T, Smax);
 }
 
 int launch_exact_flagged(const LossArgs& a, const int* flags, int mode);
@@ -253,7 +275,8 @@ int launch_exact_flagged(const LossArgs& a, const int* flags, int mode) {
     set_error("exact CTC kernel: V=%d, Smax=%d need %zu B of LDS (> 160 KiB)", a.V, a.Smax, lds);
     return E2E_ERR_UNSUPPORTED;
   }
-  const size_t need = mode == 2 ? 0 : exact_workspace_bytes(a.B, a.T, a.V, a.Smax);
+  const int slabs = mode == 0 ? a.B : (a.B < kFallbackSlabs ? a.B : kFallbackSlabs);
+  const size_t need = mode == 2 ? 0 : exact_bytes_for(slabs, a.T, a.Smax);
   if (mode != 2 && (a.ws_bytes < need || !a.ws)) {
     set_error("workspace too small: %zu < %zu", a.ws_bytes, need);
     return E2E_ERR_WORKSPACE;
@@ -265,16 +288,17 @@ int launch_exact_flagged(const LossArgs& a, const int* flags, int mode) {
   p.losses = a.losses; p.grads = a.grads; p.flags = flags; p.mode = mode;
   p.ws_alpha = reinterpret_cast<double*>(a.ws);
   p.ws_lse = reinterpret_cast<double*>(reinterpret_cast<char*>(a.ws) +
-                                       align_up((size_t)a.B * a.T * p.Lmax * sizeof(double), 256));
+                                       align_up((size_t)slabs * a.T * p.Lmax * sizeof(double), 256));
+  const int grid = mode == 2 ? a.B : slabs;
   if (a.B == 0) return E2E_OK;
   if (a.dtype == E2E_F32) {
     E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_exact_kernel<float>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_exact_kernel<float>, dim3(a.B), dim3(kThreads), lds, a.stream, p);
+    hipLaunchKernelGGL(ctc_exact_kernel<float>, dim3(grid), dim3(kThreads), lds, a.stream, p);
   } else {
     E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_exact_kernel<double>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_exact_kernel<double>, dim3(a.B), dim3(kThreads), lds, a.stream, p);
+    hipLaunchKernelGGL(ctc_exact_kernel<double>, dim3(grid), dim3(kThreads), lds, a.stream, p);
   }
   E2E_HIP_CHECK(hipGetLastError(), "ctc_exact_kernel launch");
   return E2E_OK;

@@ -918,7 +918,7 @@ int launch_exact_flagged(const LossArgs& a, const int* flags, int mode);
 int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   const FastLayout l = fast_layout(a.B, a.T, a.V, a.Smax);
   size_t need = l.total;
-  if (fallback_to_exact) need += exact_workspace_bytes(a.B, a.T, a.V, a.Smax);
+  if (fallback_to_exact) need += exact_fallback_workspace_bytes(a.B, a.T, a.V, a.Smax);
   if (!a.ws || a.ws_bytes < need) { set_error("workspace too small: %zu < %zu", a.ws_bytes, need); return E2E_ERR_WORKSPACE; }
   if (a.B == 0) return E2E_OK;
   char* ws = reinterpret_cast<char*>(a.ws);

@@ -270,7 +270,7 @@ WideLayout wide_layout(int B, int T, int V, int Smax, bool with_exact) {
   l.gc = o; o += align_up((size_t)B * T * l.VC * sizeof(float), 256);
   l.inner = o;
   o += fast_workspace_bytes(B, T, l.VC, Smax);
-  if (with_exact) o += exact_workspace_bytes(B, T, l.VC, Smax);
+  if (with_exact) o += exact_fallback_workspace_bytes(B, T, l.VC, Smax);
   l.total = o;
   return l;
 }
