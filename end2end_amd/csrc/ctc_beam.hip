@@ -277,7 +277,7 @@ extern "C" double e2e_lm_score(const e2e_lm* lm, const uint32_t* ctx, int ctx_le
 namespace e2e {
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;
 constexpr int kMaxCand = 8192;     // W*V + W must fit the LDS sort
 
 struct BeamNode {
