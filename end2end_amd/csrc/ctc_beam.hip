@@ -9,9 +9,13 @@
 //   * the weak `next_data` map of a prefix is a V-entry child table that exists only while the prefix is in the
 //     beam (only beam members are ever asked for a child); a dying child clears its entry -- so a pruned child that
 //     is kept alive by a descendant is still found, receives probability, and is NOT re-added (quirk Q7).
-// All scores are IEEE doubles with the reference's two-argument log-sum-exp.  Top-W selection is a full bitonic
-// sort in LDS on (score descending, position ascending): the reference's nth_element leaves ties unspecified
-// (quirk Q9); the oracle uses the same total order.
+// All scores are IEEE doubles with the reference's two-argument log-sum-exp.  The beam (probabilities, LM state, child
+// tables) lives in LDS; prefixes are created LAZILY: a step scores all W*V would-be prefixes, selects the W survivors
+// (8-pass radix select on an order-preserving 64-bit key, ties by position, then a one-wavefront bitonic sort of the
+// survivors into (score descending, position ascending) order -- the reference's nth_element leaves ties unspecified,
+// quirk Q9; the oracle uses the same total order) and only then allocates nodes for the new ones.  Upstream a new prefix
+// that does not survive its first pruning is destroyed at once, so this is equivalent and saves ~W*V allocations,
+// LM-state writes and frees per step.
 //
 // The language model stands where KenLM stands upstream (src/decoders/ctc_decoder.cpp:60-71,77-88,264-308):
 // host-side ARPA reader (plain or gzip), device-resident open-addressing tables, standard back-off scoring.
@@ -278,16 +282,24 @@ namespace e2e {
 namespace {
 
 constexpr int kThreads = 1024;
-constexpr int kMaxCand = 8192;     // W*V + W must fit the LDS sort
+constexpr int kMaxCand = 8192;     // W*V + W candidates per step (LDS key array)
+constexpr int kLdsBudget = 158 * 1024;
 
-struct BeamNode {
-  double pb, pnb, ppb, ppnb;               // cur / prev log-probs ending in blank / non-blank
+// LM-related state of a prefix (Prefix::lm_*, num_*, last_word, ctc_decoder.h:79-86)
+struct LmFields {
   double lm_score, lm_before;
-  int parent, last_char, refs, tab;
   int num_words, num_oov, num_oov_before, word_len;
   unsigned long long word_hash;            // hash of the spelled last word (get_idx(vector<int>), :84-88)
   unsigned int st[kCtx], stb[kCtx];        // LM context after / before the last word, most recent first
   int st_n, stb_n;
+};
+
+// tree node in HBM: structure + LM state.  The four log-probabilities of a prefix matter only while it is in the beam
+// and live in LDS (a pruned-but-alive prefix still "receives" probability upstream, but nothing ever reads it: quirk Q7
+// reduces to "its (parent, char) slot stays occupied").
+struct BeamNode {
+  int parent, last_char, refs, slot, tab, pad;
+  LmFields lm;
 };
 
 struct BeamParams {
@@ -295,9 +307,8 @@ struct BeamParams {
   int B, T, V, blank, W, space_id;
   int has_lm; LmView lm; double lmwt, wip, oov;
   int64_t* out; int64_t max_out; int64_t* out_len;
-  // per-utterance workspace
-  BeamNode* nodes; int* free_nodes; int* ctab; int* free_tabs; int* cand; int* cand2; int* status;
-  int NCAP, TCAP, CMAX, NP2;
+  BeamNode* nodes; int* free_nodes; int* status;      // per-utterance workspace
+  int NCAP, TCAP, CMAX, WP2;
 };
 
 __device__ __forceinline__ double ninf() { return -__builtin_huge_val(); }
@@ -310,244 +321,339 @@ __device__ __forceinline__ double lse2(double a, double b) {
   return b + log(1.0 + exp(a - b));
 }
 
-// (score desc, position asc): does a come before b?
-__device__ __forceinline__ bool before(double sa, int ia, double sb, int ib) {
-  return sa > sb || (sa == sb && ia < ib);
+// order-preserving map double -> uint64 (larger double <=> larger key)
+__device__ __forceinline__ unsigned long long okey(double d) {
+  unsigned long long u = (unsigned long long)__double_as_longlong(d);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
 }
 
-__device__ void bitonic_sort(double* key, int* idx, int n2, int tid) {
-  for (int k = 2; k <= n2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int e = tid; e < n2; e += kThreads) {
-        const int partner = e ^ j;
-        if (partner > e) {
-          const bool up = (e & k) == 0;           // this run ends up "before-ordered"
-          const double ka = key[e], kb = key[partner];
-          const int ia = idx[e], ib = idx[partner];
-          const bool a_first = before(ka, ia, kb, ib);
-          if (up ? !a_first : a_first) { key[e] = kb; key[partner] = ka; idx[e] = ib; idx[partner] = ia; }
-        }
-      }
-      __syncthreads();
+// the LM part of get_next_prefix (:258-308) for the child (parent pr, char c)
+__device__ __forceinline__ void child_lm(const BeamParams& p, const LmFields& pr, int parent_last, int c, LmFields& nn) {
+  const bool new_word = c != p.space_id && (pr.num_words == 0 || parent_last == p.space_id);     // :258-259
+  nn.num_words = pr.num_words + (new_word ? 1 : 0);
+  nn.lm_score = 0.0; nn.lm_before = 0.0; nn.num_oov = 0; nn.num_oov_before = 0;
+  nn.word_len = 0; nn.word_hash = kFnvInit; nn.st_n = 0; nn.stb_n = 0;
+  if (!p.has_lm) return;
+  const double kLogE10 = 2.302585092994045684;
+  if (c != p.space_id) {
+    unsigned long long h = new_word ? kFnvInit : pr.word_hash;
+    for (int bi = p.lm.label_off[c]; bi < p.lm.label_off[c + 1]; bi++) {
+      unsigned char ch = p.lm.label_bytes[bi];
+      if (p.lm.fold_case && ch >= 'A' && ch <= 'Z') ch += 32;
+      h = fnv_step(h, ch);
     }
+    nn.word_hash = h; nn.word_len = (new_word ? 0 : pr.word_len) + 1;
+    const uint32_t wi = lm_word_lookup(p.lm, h);
+    if (new_word) {                                                       // :265-281
+      for (int s = 0; s < pr.st_n; s++) nn.stb[s] = pr.st[s];
+      nn.stb_n = pr.st_n; nn.lm_before = pr.lm_score; nn.num_oov_before = pr.num_oov;
+    } else {                                                              // :282-297
+      for (int s = 0; s < pr.stb_n; s++) nn.stb[s] = pr.stb[s];
+      nn.stb_n = pr.stb_n; nn.lm_before = pr.lm_before; nn.num_oov_before = pr.num_oov_before;
+    }
+    int on = 0;
+    const float sc = lm_base_score(p.lm, nn.stb, nn.stb_n, wi, nn.st, &on);
+    nn.st_n = on;
+    nn.lm_score = nn.lm_before + (double)sc / kLogE10;                     // quirk Q8: divides by ln 10
+    nn.num_oov = nn.num_oov_before + (wi == 0 ? 1 : 0);
+  } else {                                                                // :299-307 copy
+    nn.word_hash = pr.word_hash; nn.word_len = pr.word_len;
+    nn.lm_score = pr.lm_score; nn.lm_before = pr.lm_before;
+    nn.num_oov = pr.num_oov; nn.num_oov_before = pr.num_oov_before;
+    for (int s = 0; s < pr.st_n; s++) nn.st[s] = pr.st[s];
+    for (int s = 0; s < pr.stb_n; s++) nn.stb[s] = pr.stb[s];
+    nn.st_n = pr.st_n; nn.stb_n = pr.stb_n;
   }
 }
+
+// get_prev_full_prob_with_lmwt, :314-318, from the already "next_step"-ed probabilities
+__device__ __forceinline__ double beam_score(const BeamParams& p, double ppnb, double ppb, const LmFields& lm) {
+  return lse2(ppnb, ppb) + lm.lm_score * p.lmwt - lm.num_words * p.wip + lm.num_oov * p.oov;
+}
+
+// members of the beam, structure of arrays in LDS (two copies: the beam is rebuilt into the other one every step)
+struct Members {
+  double* ppb; double* ppnb;   // prev_prob_blank / prev_prob_not_blank
+  double* npb; double* npnb;   // this step's prob_blank / prob_not_blank (become prev at next_step)
+  double* inc;                 // contribution to prob_not_blank arriving from the parent (if it is in the beam)
+  int* node; int* last; int* tab; int* kept;
+  LmFields* lm;
+  __device__ unsigned char* carve(unsigned char* q, int W) {
+    ppb = (double*)q; q += sizeof(double) * W; ppnb = (double*)q; q += sizeof(double) * W;
+    npb = (double*)q; q += sizeof(double) * W; npnb = (double*)q; q += sizeof(double) * W;
+    inc = (double*)q; q += sizeof(double) * W;
+    lm = (LmFields*)q; q += sizeof(LmFields) * W;
+    node = (int*)q; q += sizeof(int) * W; last = (int*)q; q += sizeof(int) * W;
+    tab = (int*)q; q += sizeof(int) * W; kept = (int*)q; q += sizeof(int) * W;
+    return q;
+  }
+  static size_t bytes(int W) { return (size_t)W * (5 * sizeof(double) + sizeof(LmFields) + 4 * sizeof(int)); }
+};
+
+struct BeamLds {
+  static size_t bytes(int W, int V, int CMAX, int TCAP, int WP2) {
+    return sizeof(double) * ((size_t)CMAX + V + WP2) + sizeof(int) * ((size_t)CMAX + WP2 + (size_t)TCAP * V + TCAP + 256 + 64) +
+           2 * Members::bytes(W) + 64;
+  }
+};
 
 template <typename IO>
 __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  double* skey = reinterpret_cast<double*>(smem);          // [NP2]
-  double* srow = skey + p.NP2;                             // [V]
-  int* sidx = reinterpret_cast<int*>(srow + p.V);          // [NP2]
-  __shared__ int s_free_nodes, s_free_tabs, s_new, s_err;
-  __shared__ int s_part[kThreads];
-
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int V = p.V, W = p.W, blank = p.blank, space = p.space_id;
+  const int V = p.V, W = p.W, blank = p.blank;
+  // ---- LDS carve-up ----
+  unsigned char* q8 = smem;
+  double* key = (double*)q8; q8 += sizeof(double) * p.CMAX;          // score of candidate d (dense: old members, then new)
+  double* srow = (double*)q8; q8 += sizeof(double) * V;
+  double* skey = (double*)q8; q8 += sizeof(double) * p.WP2;          // the selected W, for the final ordering
+  Members M[2];
+  q8 = M[0].carve(q8, W); q8 = M[1].carve(q8, W);
+  int* newq = (int*)q8; q8 += sizeof(int) * p.CMAX;                  // pair index q = c*n + i of new candidate j
+  int* sidx = (int*)q8; q8 += sizeof(int) * p.WP2;
+  int* ctab = (int*)q8; q8 += sizeof(int) * (size_t)p.TCAP * V;      // child tables of the beam members (weak next_data)
+  int* free_tabs = (int*)q8; q8 += sizeof(int) * p.TCAP;
+  int* hist = (int*)q8; q8 += sizeof(int) * 256;
+  int* s_part = (int*)q8; q8 += sizeof(int) * 64;
+  __shared__ int s_free_nodes, s_free_tabs, s_err, s_digit, s_krem;
+  __shared__ unsigned long long s_prefix;
+
   BeamNode* nodes = p.nodes + (size_t)b * p.NCAP;
   int* free_nodes = p.free_nodes + (size_t)b * p.NCAP;
-  int* ctab = p.ctab + (size_t)b * p.TCAP * V;
-  int* free_tabs = p.free_tabs + (size_t)b * p.TCAP;
-  int* cand = p.cand + (size_t)b * p.CMAX;
-  int* cand2 = p.cand2 + (size_t)b * p.CMAX;
   const IO* lp = reinterpret_cast<const IO*>(p.lp) + (int64_t)b * p.sB;
   int64_t Tq = p.x_len[b];
   const int T = Tq < 0 ? 0 : (Tq > p.T ? p.T : (int)Tq);
-  const double kLogE10 = log(10.0);
 
   // ---- pools, root prefix (get_initial_prefix, :222-230) ----
   for (int i = tid; i < p.NCAP; i += kThreads) free_nodes[i] = p.NCAP - 1 - i;     // pop order 0,1,2,...
   for (int i = tid; i < p.TCAP; i += kThreads) free_tabs[i] = p.TCAP - 1 - i;
-  if (tid == 0) { s_free_nodes = p.NCAP - 1; s_free_tabs = p.TCAP - 1; s_err = 0; }   // node 0 / table 0 = root's
-  for (int c = tid; c < V; c += kThreads) ctab[c] = -1;
+  for (int c = tid; c < V; c += kThreads) ctab[c] = -1;                              // table 0 = the root's
   if (tid == 0) {
+    s_free_nodes = p.NCAP - 1; s_free_tabs = p.TCAP - 1; s_err = 0;                 // node 0 / table 0 are taken
     BeamNode& r = nodes[0];
-    r.pb = ninf(); r.pnb = ninf(); r.ppb = 0.0; r.ppnb = ninf();
-    r.lm_score = 0.0; r.lm_before = 0.0;
-    r.parent = -1; r.last_char = -1; r.refs = 1; r.tab = 0;
-    r.num_words = 0; r.num_oov = 0; r.num_oov_before = 0; r.word_len = 0; r.word_hash = kFnvInit;
-    r.st_n = 0; r.stb_n = 0;
-    if (p.has_lm) { r.st[0] = p.lm.bos; r.st_n = 1; r.stb[0] = p.lm.bos; r.stb_n = 1; }
-    cand[0] = 0;
+    r.parent = -1; r.last_char = -1; r.refs = 1; r.slot = 0; r.tab = 0;
+    LmFields l;
+    l.lm_score = 0.0; l.lm_before = 0.0; l.num_words = 0; l.num_oov = 0; l.num_oov_before = 0; l.word_len = 0;
+    l.word_hash = kFnvInit; l.st_n = 0; l.stb_n = 0;
+    if (p.has_lm) { l.st[0] = p.lm.bos; l.st_n = 1; l.stb[0] = p.lm.bos; l.stb_n = 1; }
+    r.lm = l;
+    M[0].ppb[0] = 0.0; M[0].ppnb[0] = ninf(); M[0].node[0] = 0; M[0].last[0] = -1; M[0].tab[0] = 0; M[0].lm[0] = l;
   }
   __syncthreads();
-  int n = 1;
+  int n = 1, cur = 0;
 
   for (int t = 0; t < T; t++) {
+    Members& A = M[cur];
+    Members& Bm = M[cur ^ 1];
     for (int c = tid; c < V; c += kThreads) srow[c] = (double)lp[(int64_t)t * p.sT + (int64_t)c * p.sV];
-    if (tid == 0) s_new = 0;
+    for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; }
     __syncthreads();
     // pairs in the reference's order: character outer, prefix inner (:370-395): q = c*n + i
     const int npairs = n * V;
     const int chunk = (npairs + kThreads - 1) / kThreads;
     const int q0 = min(tid * chunk, npairs), q1 = min(q0 + chunk, npairs);
-    // pass 1: which pairs create a prefix?  (weak child lookup, :250-252)
+    // pass 1: which pairs would create a prefix?  (weak child lookup, :250-252)
     int my_new = 0;
     for (int q = q0; q < q1; q++) {
       const int c = q / n, i = q - c * n;
-      if (c == blank) continue;
-      const BeamNode& pr = nodes[cand[i]];
-      if (ctab[pr.tab * V + c] < 0) my_new++;
+      if (c != blank && ctab[A.tab[i] * V + c] < 0) my_new++;
     }
-    // exclusive scan of my_new over the threads (pairs are chunked in order, so this is the reference's order)
     int incl = my_new;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
     if (lane == 63) s_part[wid] = incl;
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wid; w++) base += s_part[w];
-    int total_new = 0;
-    for (int w = 0; w < kThreads / 64; w++) total_new += s_part[w];
-    int pos = n + base + incl - my_new;
-    __syncthreads();
-    // pass 2: blank and child updates; creation
+    int base = 0, total_new = 0;
+    for (int w = 0; w < kThreads / 64; w++) { if (w < wid) base += s_part[w]; total_new += s_part[w]; }
+    int pos = base + incl - my_new;
+    // pass 2: blank shares, child shares, scores of the would-be prefixes
     for (int q = q0; q < q1; q++) {
       const int c = q / n, i = q - c * n;
-      const int pi = cand[i];
-      BeamNode& pr = nodes[pi];
-      const double cur = srow[c];
-      if (c == blank) {                                                          // :374-376
-        pr.pb = lse2(pr.pb, cur + lse2(pr.ppnb, pr.ppb));
-        continue;
+      const double curp = srow[c];
+      const double full = lse2(A.ppnb[i], A.ppb[i]);
+      if (c == blank) { A.npb[i] = curp + full; continue; }                    // :374-376 (prob_blank was -inf)
+      const double val = curp + (c == A.last[i] ? A.ppb[i] : full);            // :383-385 / :389-391
+      const int k = ctab[A.tab[i] * V + c];
+      if (k >= 0) {
+        const int j = nodes[k].slot;
+        if (j >= 0) A.inc[j] = val;            // the child is a beam member: its share from this parent
+        // else: alive but pruned (Q7) -- the probability is lost and the slot stays taken
+      } else {
+        LmFields nl;
+        child_lm(p, A.lm[i], A.last[i], c, nl);
+        newq[pos] = q;
+        key[n + pos] = beam_score(p, val, ninf(), nl);                        // after next_step: prev_pnb = val, prev_pb = -inf
+        pos++;
       }
-      int k = ctab[pr.tab * V + c];
-      if (k < 0) {                                                               // make_shared<Prefix>, :254-310
-        const int fi = atomicSub(&s_free_nodes, 1) - 1;
-        if (fi < 0) { s_err = 1; continue; }
-        k = free_nodes[fi];
-        BeamNode& nn = nodes[k];
-        nn.pb = ninf(); nn.pnb = ninf(); nn.ppb = ninf(); nn.ppnb = ninf();
-        nn.last_char = c; nn.parent = pi; nn.refs = 1; nn.tab = -1;
-        const bool new_word = c != space && (pr.num_words == 0 || pr.last_char == space);     // :258-259
-        nn.num_words = pr.num_words + (new_word ? 1 : 0);
-        nn.lm_score = 0.0; nn.lm_before = 0.0; nn.num_oov = 0; nn.num_oov_before = 0;
-        nn.word_len = 0; nn.word_hash = kFnvInit; nn.st_n = 0; nn.stb_n = 0;
-        if (p.has_lm) {
-          if (c != space) {
-            uint64_t h = new_word ? kFnvInit : pr.word_hash;
-            for (int bi = p.lm.label_off[c]; bi < p.lm.label_off[c + 1]; bi++) {
-              unsigned char ch = p.lm.label_bytes[bi];
-              if (p.lm.fold_case && ch >= 'A' && ch <= 'Z') ch += 32;
-              h = fnv_step(h, ch);
-            }
-            nn.word_hash = h; nn.word_len = (new_word ? 0 : pr.word_len) + 1;
-            const uint32_t wi = lm_word_lookup(p.lm, h);
-            if (new_word) {                                                       // :265-281
-              for (int s = 0; s < pr.st_n; s++) nn.stb[s] = pr.st[s];
-              nn.stb_n = pr.st_n; nn.lm_before = pr.lm_score; nn.num_oov_before = pr.num_oov;
-            } else {                                                              // :282-297
-              for (int s = 0; s < pr.stb_n; s++) nn.stb[s] = pr.stb[s];
-              nn.stb_n = pr.stb_n; nn.lm_before = pr.lm_before; nn.num_oov_before = pr.num_oov_before;
-            }
-            int on = 0;
-            const float sc = lm_base_score(p.lm, nn.stb, nn.stb_n, wi, nn.st, &on);
-            nn.st_n = on;
-            nn.lm_score = nn.lm_before + (double)sc / kLogE10;                     // quirk Q8: divides by ln 10
-            nn.num_oov = nn.num_oov_before + (wi == 0 ? 1 : 0);
-          } else {                                                                // :299-307 copy
-            nn.word_hash = pr.word_hash; nn.word_len = pr.word_len;
-            nn.lm_score = pr.lm_score; nn.lm_before = pr.lm_before;
-            nn.num_oov = pr.num_oov; nn.num_oov_before = pr.num_oov_before;
-            for (int s = 0; s < pr.st_n; s++) nn.st[s] = pr.st[s];
-            for (int s = 0; s < pr.stb_n; s++) nn.stb[s] = pr.stb[s];
-            nn.st_n = pr.st_n; nn.stb_n = pr.stb_n;
-          }
-        }
-        atomicAdd(&pr.refs, 1);
-        ctab[pr.tab * V + c] = k;
-        cand[pos++] = k;
-      }
-      BeamNode& ch = nodes[k];
-      if (c == pr.last_char) ch.pnb = lse2(ch.pnb, cur + pr.ppb);                  // :383-385 (child part)
-      else ch.pnb = lse2(ch.pnb, cur + lse2(pr.ppnb, pr.ppb));                    // :389-391
     }
-    __threadfence_block();
     __syncthreads();
-    // repeated character, the prefix's own share (:386-387); after the child updates because a prefix can be the
-    // child of another beam member -- log_sum_exp is symmetric, so the order of the two updates does not matter
+    // members: repeated-character share (:386-387), next_step (:337-342), score
     for (int i = tid; i < n; i += kThreads) {
-      BeamNode& pr = nodes[cand[i]];
-      if (pr.last_char >= 0 && pr.last_char != blank) pr.pnb = lse2(pr.pnb, srow[pr.last_char] + pr.ppnb);
+      const int lc = A.last[i];
+      double pnb = A.inc[i];
+      if (lc >= 0 && lc != blank) pnb = lse2(pnb, srow[lc] + A.ppnb[i]);
+      A.npnb[i] = pnb;
+      key[i] = beam_score(p, pnb, A.npb[i], A.lm[i]);
     }
-    __threadfence_block();
     __syncthreads();
     const int ntot = n + total_new;
-    // next_step (:337-342) on every member, old and new
-    for (int i = tid; i < ntot; i += kThreads) {
-      BeamNode& nd = nodes[cand[i]];
-      nd.ppb = nd.pb; nd.ppnb = nd.pnb; nd.pb = ninf(); nd.pnb = ninf();
-    }
-    __threadfence_block();
-    __syncthreads();
+    const int nsel = ntot > W ? W : ntot;
     if (ntot > W) {                                                              // :405-415
-      int n2 = 1; while (n2 < ntot) n2 <<= 1;
-      for (int i = tid; i < n2; i += kThreads) {
-        if (i < ntot) {
-          const BeamNode& nd = nodes[cand[i]];
-          skey[i] = lse2(nd.ppnb, nd.ppb) + nd.lm_score * p.lmwt - nd.num_words * p.wip + nd.num_oov * p.oov;   // :314-318
-        } else {
-          skey[i] = ninf();
+      // ---- radix select of the W-th largest score (8 bits per pass), ties broken by position ----
+      if (tid == 0) { s_prefix = 0ULL; s_krem = W; }
+      __syncthreads();
+      unsigned long long mask = 0ULL;
+      for (int pass = 7; pass >= 0; pass--) {
+        const int shift = pass * 8;
+        for (int h = tid; h < 256; h += kThreads) hist[h] = 0;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        for (int d = tid; d < ntot; d += kThreads) {
+          const unsigned long long u = okey(key[d]);
+          if ((u & mask) == prefix) atomicAdd(&hist[(int)((u >> shift) & 255ULL)], 1);
         }
-        sidx[i] = i;
+        __syncthreads();
+        if (wid == 0) {
+          // lane l owns digits 255-4l .. 252-4l (descending); find the digit where the running count reaches k
+          int c4[4], s4 = 0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) { c4[j] = hist[255 - 4 * lane - j]; s4 += c4[j]; }
+          int inc4 = s4;
+          for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc4, o, 64); if (lane >= o) inc4 += v; }
+          int above = inc4 - s4;                      // elements with a larger digit than this lane's first
+          const int k = s_krem;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (above < k && above + c4[j] >= k) { s_digit = 255 - 4 * lane - j; s_krem = k - above; }
+            above += c4[j];
+          }
+        }
+        __syncthreads();
+        if (tid == 0) s_prefix = prefix | ((unsigned long long)s_digit << shift);
+        mask |= 255ULL << shift;
+        __syncthreads();
+      }
+      const unsigned long long Tk = s_prefix;          // key of the W-th largest; s_krem of the equal ones are taken
+      // ---- compaction: larger keys first, then the first s_krem equal ones (by position) ----
+      const int per = (ntot + kThreads - 1) / kThreads;
+      const int d0 = min(tid * per, ntot), d1 = min(d0 + per, ntot);
+      int ngt = 0, neq = 0;
+      for (int d = d0; d < d1; d++) { const unsigned long long u = okey(key[d]); ngt += u > Tk; neq += u == Tk; }
+      int ig = ngt, ie = neq;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int vg = __shfl_up(ig, o, 64), ve = __shfl_up(ie, o, 64);
+        if (lane >= o) { ig += vg; ie += ve; }
+      }
+      if (lane == 63) { s_part[wid] = ig; s_part[16 + wid] = ie; }
+      __syncthreads();
+      int bg = 0, be = 0, tg = 0;
+      for (int w = 0; w < kThreads / 64; w++) { if (w < wid) { bg += s_part[w]; be += s_part[16 + w]; } tg += s_part[w]; }
+      int og = bg + ig - ngt, oe = be + ie - neq;
+      const int krem = s_krem;
+      for (int d = d0; d < d1; d++) {
+        const unsigned long long u = okey(key[d]);
+        if (u > Tk) { skey[og] = key[d]; sidx[og] = d; og++; }
+        else if (u == Tk) { if (oe < krem) { skey[tg + oe] = key[d]; sidx[tg + oe] = d; } oe++; }
+      }
+      for (int j = W + tid; j < p.WP2; j += kThreads) { skey[j] = ninf(); sidx[j] = 0x7fffffff; }
+      __syncthreads();
+      // ---- order the survivors: (score desc, position asc), one wavefront, no workgroup barriers ----
+      if (wid == 0) {
+        for (int k = 2; k <= p.WP2; k <<= 1) {
+          for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int e = lane; e < p.WP2; e += 64) {
+              const int partner = e ^ j;
+              if (partner > e) {
+                const bool up = (e & k) == 0;
+                const double ka = skey[e], kb = skey[partner];
+                const int ia = sidx[e], ib = sidx[partner];
+                const bool a_first = ka > kb || (ka == kb && ia < ib);
+                if (up ? !a_first : a_first) { skey[e] = kb; skey[partner] = ka; sidx[e] = ib; sidx[partner] = ia; }
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
       }
       __syncthreads();
-      bitonic_sort(skey, sidx, n2, tid);
-      for (int i = tid; i < ntot; i += kThreads) cand2[i] = cand[sidx[i]];
-      __threadfence_block();
-      __syncthreads();
-      // leaving the beam: give the child table back, drop the beam's reference, cascade (shared_ptr release)
-      for (int i = W + tid; i < ntot; i += kThreads) {
-        int k = cand2[i];
-        if (nodes[k].tab >= 0) { free_tabs[atomicAdd(&s_free_tabs, 1)] = nodes[k].tab; nodes[k].tab = -1; }
-        while (k >= 0) {
-          if (atomicSub(&nodes[k].refs, 1) != 1) break;
-          const int par = nodes[k].parent;
-          if (par >= 0) { const int pt = nodes[par].tab; if (pt >= 0) ctab[pt * V + nodes[k].last_char] = -1; }   // weak_ptr expires
-          free_nodes[atomicAdd(&s_free_nodes, 1)] = k;
-          k = par;
-        }
-      }
-      __threadfence_block();
-      __syncthreads();
-      for (int i = tid; i < W; i += kThreads) cand[i] = cand2[i];
-      n = W;
     } else {
-      n = ntot;
+      for (int j = tid; j < ntot; j += kThreads) sidx[j] = j;                     // unchanged order: old members, then new
+      __syncthreads();
     }
-    __syncthreads();
-    // members without a child table (the new ones) get one
-    for (int i = tid; i < n; i += kThreads) {
-      BeamNode& nd = nodes[cand[i]];
-      if (nd.tab < 0) {
-        const int ti = atomicSub(&s_free_tabs, 1) - 1;
-        if (ti < 0) { s_err = 2; continue; }
-        nd.tab = free_tabs[ti];
-        for (int c = 0; c < V; c++) ctab[nd.tab * V + c] = -1;
+    // ---- rebuild the beam in the other member set ----
+    for (int j = tid; j < nsel; j += kThreads) {
+      const int d = sidx[j];
+      if (d < n) {
+        const int i = d;
+        A.kept[i] = 1;
+        Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i];
+        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; Bm.tab[j] = A.tab[i]; Bm.lm[j] = A.lm[i];
+        nodes[A.node[i]].slot = j;
+      } else {
+        const int q = newq[d - n];
+        const int c = q / n, i = q - c * n;
+        const double full = lse2(A.ppnb[i], A.ppb[i]);
+        const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : full);
+        LmFields nl;
+        child_lm(p, A.lm[i], A.last[i], c, nl);
+        const int fi = atomicSub(&s_free_nodes, 1) - 1;                           // make_shared<Prefix>, :254
+        int k = 0;
+        if (fi < 0) s_err = 1; else k = free_nodes[fi];
+        BeamNode& nn = nodes[k];
+        nn.parent = A.node[i]; nn.last_char = c; nn.refs = 1; nn.slot = j; nn.tab = -1; nn.lm = nl;
+        atomicAdd(&nodes[A.node[i]].refs, 1);
+        ctab[A.tab[i] * V + c] = k;
+        Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.node[j] = k; Bm.last[j] = c; Bm.tab[j] = -1; Bm.lm[j] = nl;
       }
     }
     __threadfence_block();
     __syncthreads();
+    // ---- members that left the beam: give the table back, drop the beam's reference, cascade (shared_ptr release) ----
+    for (int i = tid; i < n; i += kThreads) {
+      if (A.kept[i]) continue;
+      int k = A.node[i];
+      free_tabs[atomicAdd(&s_free_tabs, 1)] = A.tab[i];
+      nodes[k].tab = -1; nodes[k].slot = -1;
+      while (k >= 0) {
+        if (atomicSub(&nodes[k].refs, 1) != 1) break;
+        const int par = nodes[k].parent;
+        if (par >= 0) { const int pt = nodes[par].tab; if (pt >= 0) ctab[pt * V + nodes[k].last_char] = -1; }   // weak_ptr expires
+        free_nodes[atomicAdd(&s_free_nodes, 1)] = k;
+        k = par;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- new members get a child table ----
+    for (int j = tid; j < nsel; j += kThreads) {
+      if (Bm.tab[j] < 0) {
+        const int ti = atomicSub(&s_free_tabs, 1) - 1;
+        int tb = 0;
+        if (ti < 0) s_err = 2; else tb = free_tabs[ti];
+        Bm.tab[j] = tb; nodes[Bm.node[j]].tab = tb;
+        for (int c = 0; c < V; c++) ctab[tb * V + c] = -1;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    n = nsel; cur ^= 1;
     if (s_err) break;
   }
 
-  // ---- final sort (:418-424), best prefix, its sentence (:232-245) ----
+  // ---- final sort (:418-424) reduces to the best prefix; its sentence (:232-245) ----
   {
-    int n2 = 1; while (n2 < n) n2 <<= 1;
-    for (int i = tid; i < n2; i += kThreads) {
-      if (i < n) {
-        const BeamNode& nd = nodes[cand[i]];
-        skey[i] = lse2(nd.ppnb, nd.ppb) + nd.lm_score * p.lmwt - nd.num_words * p.wip + nd.num_oov * p.oov;
-      } else skey[i] = ninf();
-      sidx[i] = i;
-    }
+    Members& A = M[cur];
+    for (int i = tid; i < n; i += kThreads) key[i] = beam_score(p, A.ppnb[i], A.ppb[i], A.lm[i]);
     __syncthreads();
-    bitonic_sort(skey, sidx, n2, tid);
   }
   int64_t* out = p.out + (int64_t)b * p.max_out;
   for (int64_t i = tid; i < p.max_out; i += kThreads) out[i] = 0;
+  __threadfence_block();
   __syncthreads();
   if (tid == 0) {
-    const int best = cand[sidx[0]];
+    int bi = 0;
+    for (int i = 1; i < n; i++) if (key[i] > key[bi]) bi = i;            // first maximum = (score desc, position asc)
+    const int best = M[cur].node[bi];
     int64_t m = 0;
     for (int k = best; k >= 0; k = nodes[k].parent) if (k == best || nodes[k].parent >= 0) m++;
     int64_t at = m;
@@ -560,22 +666,19 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   }
 }
 
-struct BeamLayout { size_t nodes, free_nodes, ctab, free_tabs, cand, cand2, status, total; int NCAP, TCAP, CMAX, NP2; };
+struct BeamLayout { size_t nodes, free_nodes, status, total, lds; int NCAP, TCAP, CMAX, WP2; };
 
 BeamLayout beam_layout(int B, int T, int V, int W) {
   BeamLayout l;
   l.CMAX = W * V + W + 8;
-  // live nodes: the beam, its ancestors (at most one root path of length <= T per member) and one step's candidates
-  l.NCAP = W * V + W * (T + 2) + 8;
+  // live nodes: the beam and its ancestors (at most one root path of length <= T per member); at most W are created per step
+  l.NCAP = W * (T + 3) + 8;
   l.TCAP = 2 * W + 8;
-  l.NP2 = 1; while (l.NP2 < l.CMAX) l.NP2 <<= 1;
+  l.WP2 = 64; while (l.WP2 < W) l.WP2 <<= 1;
+  l.lds = BeamLds::bytes(W, V, l.CMAX, l.TCAP, l.WP2);
   size_t o = 0;
   l.nodes = o; o += align_up((size_t)B * l.NCAP * sizeof(BeamNode), 256);
   l.free_nodes = o; o += align_up((size_t)B * l.NCAP * sizeof(int), 256);
-  l.ctab = o; o += align_up((size_t)B * l.TCAP * V * sizeof(int), 256);
-  l.free_tabs = o; o += align_up((size_t)B * l.TCAP * sizeof(int), 256);
-  l.cand = o; o += align_up((size_t)B * l.CMAX * sizeof(int), 256);
-  l.cand2 = o; o += align_up((size_t)B * l.CMAX * sizeof(int), 256);
   l.status = o; o += align_up((size_t)B * sizeof(int), 256);
   l.total = o;
   return l;
@@ -601,8 +704,9 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   if (B > 0 && (!lp || !x_len || !out || !out_len)) { set_error("null pointer argument"); return E2E_ERR_ARG; }
   if (lm && !lm->d_ng) { set_error("the language model has no device tables (it was loaded without a GPU)"); return E2E_ERR_HIP; }
   const BeamLayout l = beam_layout(B, T, V, beam_width);
-  if (l.CMAX > kMaxCand) {
-    set_error("beam_width*alphabet = %d candidates per step exceed the %d the LDS sort holds", l.CMAX, kMaxCand);
+  if (l.CMAX > kMaxCand || l.lds > (size_t)kLdsBudget) {
+    set_error("beam_width*alphabet = %d candidates per step (%zu B of LDS) exceed what one workgroup holds (%d, %d B)",
+              l.CMAX, l.lds, kMaxCand, kLdsBudget);
     return E2E_ERR_UNSUPPORTED;
   }
   uintptr_t base = reinterpret_cast<uintptr_t>(workspace);
@@ -619,20 +723,17 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   p.wip = wip; p.oov = oov_penalty;
   p.out = out; p.max_out = max_out; p.out_len = out_len;
   p.nodes = reinterpret_cast<BeamNode*>(ws + l.nodes); p.free_nodes = reinterpret_cast<int*>(ws + l.free_nodes);
-  p.ctab = reinterpret_cast<int*>(ws + l.ctab); p.free_tabs = reinterpret_cast<int*>(ws + l.free_tabs);
-  p.cand = reinterpret_cast<int*>(ws + l.cand); p.cand2 = reinterpret_cast<int*>(ws + l.cand2);
   p.status = reinterpret_cast<int*>(ws + l.status);
-  p.NCAP = l.NCAP; p.TCAP = l.TCAP; p.CMAX = l.CMAX; p.NP2 = l.NP2;
-  const size_t lds = sizeof(double) * ((size_t)l.NP2 + V) + sizeof(int) * (size_t)l.NP2;
+  p.NCAP = l.NCAP; p.TCAP = l.TCAP; p.CMAX = l.CMAX; p.WP2 = l.WP2;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == E2E_F32) {
     E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_beam_kernel<float>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_beam_kernel<float>, dim3(B), dim3(kThreads), lds, s, p);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds), "hipFuncSetAttribute");
+    hipLaunchKernelGGL(ctc_beam_kernel<float>, dim3(B), dim3(kThreads), l.lds, s, p);
   } else {
     E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_beam_kernel<double>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_beam_kernel<double>, dim3(B), dim3(kThreads), lds, s, p);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds), "hipFuncSetAttribute");
+    hipLaunchKernelGGL(ctc_beam_kernel<double>, dim3(B), dim3(kThreads), l.lds, s, p);
   }
   E2E_HIP_CHECK(hipGetLastError(), "ctc_beam_kernel launch");
   return E2E_OK;
