@@ -376,26 +376,36 @@ struct Members {
   double* ppb; double* ppnb;   // prev_prob_blank / prev_prob_not_blank
   double* npb; double* npnb;   // this step's prob_blank / prob_not_blank (become prev at next_step)
   double* inc;                 // contribution to prob_not_blank arriving from the parent (if it is in the beam)
+  double* full;                // log_sum_exp(prev_pnb, prev_pb), once per member and step
   int* node; int* last; int* tab; int* kept;
   LmFields* lm;
   __device__ unsigned char* carve(unsigned char* q, int W) {
     ppb = (double*)q; q += sizeof(double) * W; ppnb = (double*)q; q += sizeof(double) * W;
     npb = (double*)q; q += sizeof(double) * W; npnb = (double*)q; q += sizeof(double) * W;
-    inc = (double*)q; q += sizeof(double) * W;
+    inc = (double*)q; q += sizeof(double) * W; full = (double*)q; q += sizeof(double) * W;
     lm = (LmFields*)q; q += sizeof(LmFields) * W;
     node = (int*)q; q += sizeof(int) * W; last = (int*)q; q += sizeof(int) * W;
     tab = (int*)q; q += sizeof(int) * W; kept = (int*)q; q += sizeof(int) * W;
     return q;
   }
-  static size_t bytes(int W) { return (size_t)W * (5 * sizeof(double) + sizeof(LmFields) + 4 * sizeof(int)); }
+  static size_t bytes(int W) { return (size_t)W * (6 * sizeof(double) + sizeof(LmFields) + 4 * sizeof(int)); }
 };
 
 struct BeamLds {
   static size_t bytes(int W, int V, int CMAX, int TCAP, int WP2) {
-    return sizeof(double) * ((size_t)CMAX + V + WP2) + sizeof(int) * ((size_t)CMAX + WP2 + (size_t)TCAP * V + TCAP + 256 + 64) +
+    return sizeof(double) * ((size_t)CMAX + V + WP2) + sizeof(int) * ((size_t)CMAX + WP2 + (size_t)TCAP * V + TCAP + 512 + 64) +
            2 * Members::bytes(W) + 64;
   }
 };
+
+#ifdef E2E_BEAM_PROFILE
+} }  // leave the namespaces for the device symbol
+__device__ unsigned long long g_beam_prof[16];
+namespace e2e { namespace {
+#define BPROF(slot) do { if (b == 0 && tid == 0) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); g_beam_prof[slot] += _n - _tprev; _tprev = _n; } } while (0)
+#else
+#define BPROF(slot) do {} while (0)
+#endif
 
 template <typename IO>
 __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
@@ -413,10 +423,11 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   int* sidx = (int*)q8; q8 += sizeof(int) * p.WP2;
   int* ctab = (int*)q8; q8 += sizeof(int) * (size_t)p.TCAP * V;      // child tables of the beam members (weak next_data)
   int* free_tabs = (int*)q8; q8 += sizeof(int) * p.TCAP;
-  int* hist = (int*)q8; q8 += sizeof(int) * 256;
+  int* hist = (int*)q8; q8 += sizeof(int) * 512;
   int* s_part = (int*)q8; q8 += sizeof(int) * 64;
-  __shared__ int s_free_nodes, s_free_tabs, s_err, s_digit, s_krem;
+  __shared__ int s_free_nodes, s_free_tabs, s_err, s_krem, s_done;
   __shared__ unsigned long long s_prefix;
+  __shared__ unsigned long long s_kmin[kThreads / 64], s_kmax[kThreads / 64];
 
   BeamNode* nodes = p.nodes + (size_t)b * p.NCAP;
   int* free_nodes = p.free_nodes + (size_t)b * p.NCAP;
@@ -441,12 +452,16 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   }
   __syncthreads();
   int n = 1, cur = 0;
+#ifdef E2E_BEAM_PROFILE
+  unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+  if (b == 0 && tid == 0) for (int i = 0; i < 16; i++) g_beam_prof[i] = 0;
+#endif
 
   for (int t = 0; t < T; t++) {
     Members& A = M[cur];
     Members& Bm = M[cur ^ 1];
     for (int c = tid; c < V; c += kThreads) srow[c] = (double)lp[(int64_t)t * p.sT + (int64_t)c * p.sV];
-    for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; }
+    for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; A.full[i] = lse2(A.ppnb[i], A.ppb[i]); }
     __syncthreads();
     // pairs in the reference's order: character outer, prefix inner (:370-395): q = c*n + i
     const int npairs = n * V;
@@ -462,6 +477,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
     if (lane == 63) s_part[wid] = incl;
     __syncthreads();
+    BPROF(0);
     int base = 0, total_new = 0;
     for (int w = 0; w < kThreads / 64; w++) { if (w < wid) base += s_part[w]; total_new += s_part[w]; }
     int pos = base + incl - my_new;
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     for (int q = q0; q < q1; q++) {
       const int c = q / n, i = q - c * n;
       const double curp = srow[c];
-      const double full = lse2(A.ppnb[i], A.ppb[i]);
+      const double full = A.full[i];
       if (c == blank) { A.npb[i] = curp + full; continue; }                    // :374-376 (prob_blank was -inf)
       const double val = curp + (c == A.last[i] ? A.ppb[i] : full);            // :383-385 / :389-391
       const int k = ctab[A.tab[i] * V + c];
@@ -486,6 +502,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       }
     }
     __syncthreads();
+    BPROF(1);
     // members: repeated-character share (:386-387), next_step (:337-342), score
     for (int i = tid; i < n; i += kThreads) {
       const int lc = A.last[i];
@@ -495,49 +512,78 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       key[i] = beam_score(p, pnb, A.npb[i], A.lm[i]);
     }
     __syncthreads();
+    BPROF(2);
     const int ntot = n + total_new;
     const int nsel = ntot > W ? W : ntot;
     if (ntot > W) {                                                              // :405-415
       // ---- radix select of the W-th largest score (8 bits per pass), ties broken by position ----
-      if (tid == 0) { s_prefix = 0ULL; s_krem = W; }
+      // Two histograms alternate (the idle one is cleared while the other is scanned), wave 0 scans the bins and
+      // publishes the digit / prefix itself: two barriers per pass.  As soon as the bin of the chosen digit is taken
+      // whole (count == remaining k) the threshold is known to the bits decided so far and the passes stop.
+      // The scores of a step lie in a narrow range: their keys share the leading bits, and histogramming those would
+      // send every LDS atomic to one bin.  So the passes start at the highest bit in which the keys differ.
+      unsigned long long kmin = ~0ULL, kmax = 0ULL;
+      for (int d = tid; d < ntot; d += kThreads) { const unsigned long long u = okey(key[d]); kmin = u < kmin ? u : kmin; kmax = u > kmax ? u : kmax; }
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = __shfl_xor(kmin, o, 64), c2 = __shfl_xor(kmax, o, 64);
+        kmin = a < kmin ? a : kmin; kmax = c2 > kmax ? c2 : kmax;
+      }
+      if (lane == 0) { s_kmin[wid] = kmin; s_kmax[wid] = kmax; }
+      for (int h = tid; h < 512; h += kThreads) hist[h] = 0;
       __syncthreads();
-      unsigned long long mask = 0ULL;
-      for (int pass = 7; pass >= 0; pass--) {
-        const int shift = pass * 8;
-        for (int h = tid; h < 256; h += kThreads) hist[h] = 0;
-        __syncthreads();
+      kmin = s_kmin[0]; kmax = s_kmax[0];
+      for (int w = 1; w < kThreads / 64; w++) { kmin = s_kmin[w] < kmin ? s_kmin[w] : kmin; kmax = s_kmax[w] > kmax ? s_kmax[w] : kmax; }
+      const unsigned long long diff = kmin ^ kmax;
+      const int hb = diff ? 63 - __clzll((long long)diff) : 0;          // highest differing bit
+      unsigned long long mask = hb >= 63 ? 0ULL : ~((2ULL << hb) - 1ULL);  // bits above hb: common to all keys
+      if (tid == 0) { s_prefix = kmax & mask; s_krem = W; s_done = 0; }
+      __syncthreads();
+      int shift = hb - 7 > 0 ? hb - 7 : 0;
+      for (int pass = 0;; pass++) {
+        int* hcur = hist + (pass & 1) * 256;
+        int* hnext = hist + ((pass & 1) ^ 1) * 256;
         const unsigned long long prefix = s_prefix;
         for (int d = tid; d < ntot; d += kThreads) {
           const unsigned long long u = okey(key[d]);
-          if ((u & mask) == prefix) atomicAdd(&hist[(int)((u >> shift) & 255ULL)], 1);
+          if ((u & mask) == prefix) atomicAdd(&hcur[(int)((u >> shift) & 255ULL)], 1);
         }
         __syncthreads();
+        const unsigned long long digit_mask = 255ULL << shift;
         if (wid == 0) {
           // lane l owns digits 255-4l .. 252-4l (descending); find the digit where the running count reaches k
           int c4[4], s4 = 0;
 #pragma unroll
-          for (int j = 0; j < 4; j++) { c4[j] = hist[255 - 4 * lane - j]; s4 += c4[j]; }
+          for (int j = 0; j < 4; j++) { c4[j] = hcur[255 - 4 * lane - j]; s4 += c4[j]; }
           int inc4 = s4;
           for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc4, o, 64); if (lane >= o) inc4 += v; }
           int above = inc4 - s4;                      // elements with a larger digit than this lane's first
           const int k = s_krem;
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            if (above < k && above + c4[j] >= k) { s_digit = 255 - 4 * lane - j; s_krem = k - above; }
+            if (above < k && above + c4[j] >= k) {
+              s_krem = k - above;
+              s_prefix = (prefix & ~digit_mask) | ((unsigned long long)(255 - 4 * lane - j) << shift);
+              if (c4[j] == k - above) s_done = 1;     // the whole bin survives: no finer threshold needed
+            }
             above += c4[j];
           }
+        } else if (wid == 1) {
+          for (int h = lane; h < 256; h += 64) hnext[h] = 0;
         }
+        mask |= digit_mask;
         __syncthreads();
-        if (tid == 0) s_prefix = prefix | ((unsigned long long)s_digit << shift);
-        mask |= 255ULL << shift;
-        __syncthreads();
+        if (s_done || shift == 0) break;
+        shift = shift - 8 > 0 ? shift - 8 : 0;
       }
-      const unsigned long long Tk = s_prefix;          // key of the W-th largest; s_krem of the equal ones are taken
+      // survivors: keys whose decided bits are above the threshold prefix, plus s_krem keys equal to it (all of them
+      // when the passes stopped early)
+      const unsigned long long Tk = s_prefix;
+#define OKEY_CMP(u) ((u) & mask)
       // ---- compaction: larger keys first, then the first s_krem equal ones (by position) ----
       const int per = (ntot + kThreads - 1) / kThreads;
       const int d0 = min(tid * per, ntot), d1 = min(d0 + per, ntot);
       int ngt = 0, neq = 0;
-      for (int d = d0; d < d1; d++) { const unsigned long long u = okey(key[d]); ngt += u > Tk; neq += u == Tk; }
+      for (int d = d0; d < d1; d++) { const unsigned long long u = OKEY_CMP(okey(key[d])); ngt += u > Tk; neq += u == Tk; }
       int ig = ngt, ie = neq;
       for (int o = 1; o < 64; o <<= 1) {
         const int vg = __shfl_up(ig, o, 64), ve = __shfl_up(ie, o, 64);
@@ -550,10 +596,11 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       int og = bg + ig - ngt, oe = be + ie - neq;
       const int krem = s_krem;
       for (int d = d0; d < d1; d++) {
-        const unsigned long long u = okey(key[d]);
+        const unsigned long long u = OKEY_CMP(okey(key[d]));
         if (u > Tk) { skey[og] = key[d]; sidx[og] = d; og++; }
         else if (u == Tk) { if (oe < krem) { skey[tg + oe] = key[d]; sidx[tg + oe] = d; } oe++; }
       }
+#undef OKEY_CMP
       for (int j = W + tid; j < p.WP2; j += kThreads) { skey[j] = ninf(); sidx[j] = 0x7fffffff; }
       __syncthreads();
       // ---- order the survivors: (score desc, position asc), one wavefront, no workgroup barriers ----
@@ -580,6 +627,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       for (int j = tid; j < ntot; j += kThreads) sidx[j] = j;                     // unchanged order: old members, then new
       __syncthreads();
     }
+    BPROF(3);
     // ---- rebuild the beam in the other member set ----
     for (int j = tid; j < nsel; j += kThreads) {
       const int d = sidx[j];
@@ -592,8 +640,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       } else {
         const int q = newq[d - n];
         const int c = q / n, i = q - c * n;
-        const double full = lse2(A.ppnb[i], A.ppb[i]);
-        const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : full);
+        const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : A.full[i]);
         LmFields nl;
         child_lm(p, A.lm[i], A.last[i], c, nl);
         const int fi = atomicSub(&s_free_nodes, 1) - 1;                           // make_shared<Prefix>, :254
@@ -608,6 +655,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     }
     __threadfence_block();
     __syncthreads();
+    BPROF(4);
     // ---- members that left the beam: give the table back, drop the beam's reference, cascade (shared_ptr release) ----
     for (int i = tid; i < n; i += kThreads) {
       if (A.kept[i]) continue;
@@ -624,6 +672,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     }
     __threadfence_block();
     __syncthreads();
+    BPROF(5);
     // ---- new members get a child table ----
     for (int j = tid; j < nsel; j += kThreads) {
       if (Bm.tab[j] < 0) {
@@ -636,6 +685,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     }
     __threadfence_block();
     __syncthreads();
+    BPROF(6);
     n = nsel; cur ^= 1;
     if (s_err) break;
   }
@@ -750,3 +800,10 @@ extern "C" int e2e_ctc_beam_status(const void* workspace, int B, int T, int V, i
   for (int v : st) if (v) { set_error("beam search: utterance status %d (1 node pool, 2 table pool, 3 output truncated)", v); return E2E_ERR_UNSUPPORTED; }
   return E2E_OK;
 }
+
+#ifdef E2E_BEAM_PROFILE
+extern "C" int e2e_debug_beam_profile(unsigned long long* host) {
+  if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_beam_prof), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : E2E_ERR_HIP;
+}
+#endif
