@@ -97,3 +97,25 @@ def test_too_many_candidates_is_reported():
     from end2end_amd._lib import E2EError
     with pytest.raises(E2EError, match="candidates"):
         U.c_abi_beam(rand_lp(1, 1, 4, 100), None, 0, 100, None)
+
+
+def test_full_c4_shape_properties():
+    # BASELINE configs[3] without the LM fixture: B=64, T=1500, V=29, beam 100 -- the oracle needs minutes here, so
+    # size-independent properties: the beam result is at least as probable as the greedy one, contains no blanks or
+    # immediate artefacts, and is reproducible
+    labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
+    g = torch.Generator().manual_seed(2)
+    lp = torch.log_softmax(torch.randn(64, 1500, 29, generator=g) * 3, -1)
+    xl = torch.randint(750, 1501, (64,), generator=g)
+    ids, lens = U.c_abi_beam(lp, xl, 0, 100, labels, wip=0.0)
+    ids2, lens2 = U.c_abi_beam(lp, xl, 0, 100, labels, wip=0.0)
+    assert np.array_equal(ids, ids2) and np.array_equal(lens, lens2)
+    gi, gl = U.c_abi_greedy(lp, xl, 0)
+    for b in (0, 31, 63):
+        n = int(xl[b])
+        seq = ids[b, : lens[b]]
+        assert (seq != 0).all() and lens[b] <= n
+        nll_beam, _ = O.ctc_loss(lp[b:b + 1, :n].double().numpy(), seq[None, :], [n], [len(seq)], 0)
+        gseq = gi[b, : gl[b]]
+        nll_greedy, _ = O.ctc_loss(lp[b:b + 1, :n].double().numpy(), gseq[None, :], [n], [len(gseq)], 0)
+        assert nll_beam[0] <= nll_greedy[0] + 1e-6

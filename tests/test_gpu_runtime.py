@@ -1,0 +1,105 @@
+"""-m gpu: runtime contract of the C ABI (asynchronous on the caller's stream, no allocation / sync inside -> graph
+capturable) and an end-to-end training loop through the drop-in modules."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import gpu_util as U
+from end2end_amd import CTCDecoder, CTCLoss, _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(seed, B=6, T=90, V=12, S=14):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl = torch.randint(T // 2 + S, T + 1, (B,), generator=g)
+    tl = torch.randint(S // 2, S + 1, (B,), generator=g)
+    return x, tg, xl, tl
+
+
+def _raw_call(L, x, tg, xl, tl, losses, grads, ws, stream):
+    _lib.check(L.e2e_ctc_loss_fwd_bwd(x.data_ptr(), _lib.F32, 0, *x.stride(), tg.data_ptr(), tg.stride(0), xl.data_ptr(),
+                                      tl.data_ptr(), x.shape[0], x.shape[1], x.shape[2], tg.shape[1], 0,
+                                      losses.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(), _lib.ALGO_AUTO,
+                                      stream))
+
+
+def test_loss_call_is_graph_capturable_and_replays_on_new_data():
+    import ctypes as C
+    L = _lib.load()
+    d = U.dev()
+    x, tg, xl, tl = (t.to(d) for t in _batch(1))
+    B, T, V = x.shape
+    losses = torch.zeros(B, device=d)
+    grads = torch.zeros(B, T, V, device=d)
+    ws = torch.empty(L.e2e_ctc_loss_workspace_bytes(B, T, V, tg.shape[1], _lib.F32, _lib.ALGO_AUTO), dtype=torch.uint8, device=d)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        _raw_call(L, x, tg, xl, tl, losses, grads, ws, C.c_void_p(s.cuda_stream))      # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _raw_call(L, x, tg, xl, tl, losses, grads, ws, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    x2, _, _, _ = _batch(2)
+    x.copy_(x2.to(d))                    # new logits in the captured buffers
+    losses.zero_(); grads.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    lp = torch.log_softmax(x2.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.cpu().numpy(), xl.cpu().numpy(), tl.cpu().numpy(), 0)
+    for b in range(B):
+        g_o[b, int(xl[b]):] = 0.0
+    U.assert_same(losses.cpu().numpy(), l_o, 1e-4, 2e-6, "losses after replay")
+    U.assert_same(grads.cpu().numpy(), g_o, 1e-4, 2e-6, "grads after replay")
+
+
+def test_modules_follow_the_current_stream():
+    d = U.dev()
+    x, tg, xl, tl = _batch(3)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        xd = x.to(d, non_blocking=True).requires_grad_()
+        loss = CTCLoss(reduce=True, size_average=False)(xd, tg.to(d), xl.to(d), tl.to(d))
+        loss.backward()
+        dec = CTCDecoder(beam_width=8, blank_idx=0).decode(xd.detach(), xl.to(d))
+    side.synchronize()
+    lp = torch.log_softmax(x.double(), -1).numpy()
+    l_o, _ = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    assert abs(loss.item() - l_o.sum()) < 1e-4 * l_o.sum()
+    o_ids, o_len, _ = O.ctc_beam(lp, xl.numpy(), 0, 8, None, wip=1.0)
+    assert dec.decoded_targets_lengths.tolist() == o_len.tolist() and dec.decoded_targets.tolist() == o_ids.tolist()
+
+
+def test_tiny_model_trains_with_the_drop_in_loss_and_decodes_its_targets():
+    # a linear "acoustic model" overfits 8 utterances; greedy and beam decoding then return the transcripts
+    torch.manual_seed(0)
+    d = U.dev()
+    B, T, F, V, S = 8, 40, 16, 9, 6
+    feats = torch.randn(B, T, F, device=d)
+    targets = torch.randint(1, V, (B, S), device=d)
+    xl = torch.full((B,), T, dtype=torch.long, device=d)
+    tl = torch.full((B,), S, dtype=torch.long, device=d)
+    model = torch.nn.Sequential(torch.nn.Linear(F, 64), torch.nn.Tanh(), torch.nn.Linear(64, V)).to(d)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-2)
+    ctc = CTCLoss(reduce=True, size_average=True)
+    first = last = None
+    for it in range(300):
+        opt.zero_grad()
+        loss = ctc(model(feats), targets, xl, tl)
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+        last = loss.item()
+    assert np.isfinite(last) and last < 0.05 * first
+    logits = model(feats).detach()
+    labels = ["_"] + [chr(97 + i) for i in range(V - 1)]
+    want = ["".join(labels[k] for k in row) for row in targets.tolist()]
+    # collapse repeats in the references the way CTC does (a repeated label needs a blank; the model learned that)
+    greedy = CTCDecoder(beam_width=1, blank_idx=0, labels=labels).decode(logits, xl)
+    beam = CTCDecoder(beam_width=16, blank_idx=0, labels=labels, wip=0.0).decode(logits, xl)
+    assert greedy.decoded_sentences == want and beam.decoded_sentences == want

@@ -1,0 +1,36 @@
+"""A/B two builds of libe2e_ctc.so in ONE process on the headline shape (interleaved rounds, median)."""
+import ctypes as C, os, sys, statistics
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root)
+import torch
+from end2end_amd import _lib
+def bind(path):
+    L = C.CDLL(path)
+    L.e2e_ctc_loss_workspace_bytes.restype = C.c_size_t; L.e2e_ctc_loss_workspace_bytes.argtypes = [C.c_int] * 6
+    L.e2e_ctc_loss_fwd_bwd.restype = C.c_int
+    L.e2e_ctc_loss_fwd_bwd.argtypes = _lib.load().e2e_ctc_loss_fwd_bwd.argtypes
+    return L
+libs = {os.path.basename(p): bind(os.path.join(root, p)) for p in sys.argv[1:]}
+d = torch.device("cuda", 0)
+B, T, V, S = 256, 1000, 29, 200
+gen = torch.Generator().manual_seed(0)
+x = torch.randn(B, T, V, generator=gen).to(d); tg = torch.randint(1, V, (B, S), generator=gen).to(d)
+tl = torch.randint(S // 2, S + 1, (B,), generator=gen).to(d); xl = torch.full((B,), T).to(d)
+losses = torch.empty(B, device=d); grads = torch.empty(B, T, V, device=d)
+n = max(L.e2e_ctc_loss_workspace_bytes(B, T, V, S, 0, 2) for L in libs.values()); ws = torch.zeros(n, dtype=torch.uint8, device=d)
+def call(L):
+    rc = L.e2e_ctc_loss_fwd_bwd(x.data_ptr(), 0, 0, *x.stride(), tg.data_ptr(), tg.stride(0), xl.data_ptr(), tl.data_ptr(),
+                                B, T, V, S, 0, losses.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(), 2, None)
+    assert rc == 0
+res = {k: [] for k in libs}
+for rnd in range(12):
+    for k, L in libs.items():
+        for _ in range(3): call(L)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): call(L)
+        e1.record(); torch.cuda.synchronize()
+        res[k].append(e0.elapsed_time(e1) / 20 * 1e3)
+for k, v in res.items():
+    print("%-28s median %.1f us  min %.1f us" % (k, statistics.median(v), min(v)))
