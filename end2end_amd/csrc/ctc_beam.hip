@@ -321,6 +321,17 @@ __device__ __forceinline__ double lse2(double a, double b) {
   return b + log(1.0 + exp(a - b));
 }
 
+// inclusive prefix sum over the 64 lanes, all DPP (row_shr 1/2/4/8 with zero fill, row_bcast 15/31)
+__device__ __forceinline__ int wave_scan_i(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
 // order-preserving map double -> uint64 (larger double <=> larger key)
 __device__ __forceinline__ unsigned long long okey(double d) {
   unsigned long long u = (unsigned long long)__double_as_longlong(d);
@@ -427,7 +438,6 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   int* s_part = (int*)q8; q8 += sizeof(int) * 64;
   __shared__ int s_free_nodes, s_free_tabs, s_err, s_krem, s_done;
   __shared__ unsigned long long s_prefix;
-  __shared__ unsigned long long s_kmin[kThreads / 64], s_kmax[kThreads / 64];
 
   BeamNode* nodes = p.nodes + (size_t)b * p.NCAP;
   int* free_nodes = p.free_nodes + (size_t)b * p.NCAP;
@@ -473,8 +483,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       const int c = q / n, i = q - c * n;
       if (c != blank && ctab[A.tab[i] * V + c] < 0) my_new++;
     }
-    int incl = my_new;
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const int incl = wave_scan_i(my_new);
     if (lane == 63) s_part[wid] = incl;
     __syncthreads();
     BPROF(0);
@@ -520,24 +529,11 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       // Two histograms alternate (the idle one is cleared while the other is scanned), wave 0 scans the bins and
       // publishes the digit / prefix itself: two barriers per pass.  As soon as the bin of the chosen digit is taken
       // whole (count == remaining k) the threshold is known to the bits decided so far and the passes stop.
-      // The scores of a step lie in a narrow range: their keys share the leading bits, and histogramming those would
-      // send every LDS atomic to one bin.  So the passes start at the highest bit in which the keys differ.
-      unsigned long long kmin = ~0ULL, kmax = 0ULL;
-      for (int d = tid; d < ntot; d += kThreads) { const unsigned long long u = okey(key[d]); kmin = u < kmin ? u : kmin; kmax = u > kmax ? u : kmax; }
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long a = __shfl_xor(kmin, o, 64), c2 = __shfl_xor(kmax, o, 64);
-        kmin = a < kmin ? a : kmin; kmax = c2 > kmax ? c2 : kmax;
-      }
-      if (lane == 0) { s_kmin[wid] = kmin; s_kmax[wid] = kmax; }
       for (int h = tid; h < 512; h += kThreads) hist[h] = 0;
+      if (tid == 0) { s_prefix = 0ULL; s_krem = W; s_done = 0; }
+      unsigned long long mask = 0ULL;
       __syncthreads();
-      kmin = s_kmin[0]; kmax = s_kmax[0];
-      for (int w = 1; w < kThreads / 64; w++) { kmin = s_kmin[w] < kmin ? s_kmin[w] : kmin; kmax = s_kmax[w] > kmax ? s_kmax[w] : kmax; }
-      const unsigned long long diff = kmin ^ kmax;
-      const int hb = diff ? 63 - __clzll((long long)diff) : 0;          // highest differing bit
-      unsigned long long mask = hb >= 63 ? 0ULL : ~((2ULL << hb) - 1ULL);  // bits above hb: common to all keys
-      if (tid == 0) { s_prefix = kmax & mask; s_krem = W; s_done = 0; }
-      __syncthreads();
+      const int hb = 63;
       int shift = hb - 7 > 0 ? hb - 7 : 0;
       for (int pass = 0;; pass++) {
         int* hcur = hist + (pass & 1) * 256;
@@ -554,8 +550,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
           int c4[4], s4 = 0;
 #pragma unroll
           for (int j = 0; j < 4; j++) { c4[j] = hcur[255 - 4 * lane - j]; s4 += c4[j]; }
-          int inc4 = s4;
-          for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc4, o, 64); if (lane >= o) inc4 += v; }
+          const int inc4 = wave_scan_i(s4);
           int above = inc4 - s4;                      // elements with a larger digit than this lane's first
           const int k = s_krem;
 #pragma unroll
@@ -584,11 +579,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       const int d0 = min(tid * per, ntot), d1 = min(d0 + per, ntot);
       int ngt = 0, neq = 0;
       for (int d = d0; d < d1; d++) { const unsigned long long u = OKEY_CMP(okey(key[d])); ngt += u > Tk; neq += u == Tk; }
-      int ig = ngt, ie = neq;
-      for (int o = 1; o < 64; o <<= 1) {
-        const int vg = __shfl_up(ig, o, 64), ve = __shfl_up(ie, o, 64);
-        if (lane >= o) { ig += vg; ie += ve; }
-      }
+      const int ig = wave_scan_i(ngt), ie = wave_scan_i(neq);
       if (lane == 63) { s_part[wid] = ig; s_part[16 + wid] = ie; }
       __syncthreads();
       int bg = 0, be = 0, tg = 0;
