@@ -515,10 +515,8 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   else if (wave == 1) chain_wave<PPL, 1>(p, b, T, S, lds, lane);
   else if (wave == 4 || wave == 5) return;
   else {
-    const int dir = (wave & 1) ^ 0;              // waves 2,6 -> alpha (dir 0), waves 3,7 -> beta (dir 1)
-    const int d = (wave == 2 || wave == 6) ? 0 : 1;
-    const int first = wave >= 6 ? 1 : 0;
-    (void)dir;
+    const int d = (wave == 2 || wave == 6) ? 0 : 1;     // waves 2,6 -> alpha rows, waves 3,7 -> beta rows
+    const int first = wave >= 6 ? 1 : 0;                 // the two producers of a direction take alternate blocks
     if (V <= 16) prep_wave<1>(p, b, T, d, first, 2, lds, lane);
     else if (V <= 32) prep_wave<2>(p, b, T, d, first, 2, lds, lane);
     else if (V <= 48) prep_wave<3>(p, b, T, d, first, 2, lds, lane);
@@ -609,7 +607,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
   constexpr int NC = 2 * PPL;
   constexpr int kSlope = 3 * NC;    // exponent drop allowed per lane (see the alpha load below)
   constexpr int PROW = F2Lds<PPL>::PROW;
-  const int V = p.V, blank = p.blank, L = 2 * S + 1, t0 = seg * kSeg;
+  const int blank = p.blank, L = 2 * S + 1, t0 = seg * kSeg;
   const float* ys = lds.ys;
   float* Ps = lds.Ps;
   const float rr = lc.r;
