@@ -22,6 +22,8 @@
 //     targets that contain the blank id.
 //
 // Reference semantics restated: src/losses/ctc_loss.cpp:33-117 (recurrences, loss, gradient).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -35,6 +37,7 @@ namespace {
 constexpr int kSeg = 16;        // steps per F2 segment == checkpoint spacing
 constexpr int kBlk = 8;         // prep -> chain hand-off block and rescale period
 constexpr int kRingBlks = 8;    // ring depth (blocks)
+constexpr int kRow = 12;        // floats per label row of a ring block: 8 steps + pad (48 B: labels 16 apart share banks, not 8 apart)
 constexpr int kMaxSmallV = 96;  // alphabet columns the lattice kernels take (prep: <= 6 columns per lane)
 
 struct FastParams {
@@ -60,20 +63,25 @@ __device__ __forceinline__ int dpp_i(int old, int v) {
   return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);
 }
 // lane n <- lane n-1 (lane 0 keeps 0)
+// (bound_ctrl: the lane without a source reads 0 and the compiler need not materialise an `old` operand)
+template <int CTRL>
+__device__ __forceinline__ int dpp_z(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
 __device__ __forceinline__ double from_prev_lane(double v) {
-  const int lo = dpp_i<0x138>(0, __double2loint(v)), hi = dpp_i<0x138>(0, __double2hiint(v));
+  const int lo = dpp_z<0x138>(__double2loint(v)), hi = dpp_z<0x138>(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ float from_prev_lane(float v) {
-  return __int_as_float(dpp_i<0x138>(0, __float_as_int(v)));
+  return __int_as_float(dpp_z<0x138>(__float_as_int(v)));
 }
 // lane n <- lane n+1 (lane 63 keeps 0)
 __device__ __forceinline__ double from_next_lane(double v) {
-  const int lo = dpp_i<0x130>(0, __double2loint(v)), hi = dpp_i<0x130>(0, __double2hiint(v));
+  const int lo = dpp_z<0x130>(__double2loint(v)), hi = dpp_z<0x130>(__double2hiint(v));
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ float from_next_lane(float v) {
-  return __int_as_float(dpp_i<0x130>(0, __float_as_int(v)));
+  return __int_as_float(dpp_z<0x130>(__float_as_int(v)));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -85,14 +93,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+// maximum over the wave, all VALU (no ds_bpermute round trips); the result is wave-uniform
 __device__ __forceinline__ int wave_max(int v) {
   v = max(v, dpp_i<0xB1>(0, v));
   v = max(v, dpp_i<0x4E>(0, v));
   v = max(v, dpp_i<0x141>(0, v));
-  v = max(v, dpp_i<0x140>(0, v));
-  v = max(v, __shfl_xor(v, 16, 64));
-  v = max(v, __shfl_xor(v, 32, 64));
-  return v;
+  v = max(v, dpp_i<0x140>(0, v));                                                   // every lane: its row's maximum
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));            // row_bcast:15 -> rows 1, 3
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));            // row_bcast:31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
 // inclusive prefix sum over the 64 lanes, all DPP
 __device__ __forceinline__ float wave_scan(float v) {
@@ -205,11 +214,11 @@ struct F1Lds {
   int* flags;        // filled[2][kRingBlks], freed[2][kRingBlks]
   int blk_floats;
   __device__ F1Lds(unsigned char* smem, int V) {
-    blk_floats = (V + 1) * kBlk;
+    blk_floats = (V + 1) * kRow;
     ring = reinterpret_cast<float*>(smem);
     flags = reinterpret_cast<int*>(ring + 2 * kRingBlks * blk_floats);
   }
-  static size_t bytes(int V) { return sizeof(float) * 2 * kRingBlks * (V + 1) * kBlk + sizeof(int) * 4 * kRingBlks; }
+  static size_t bytes(int V) { return sizeof(float) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * 4 * kRingBlks; }
 };
 
 // Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
@@ -299,7 +308,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 #pragma unroll
       for (int k = 0; k < NV; k++) {
         if (col_live[k]) {
-          blk[(l16 + 16 * k) * kBlk + tt] = row_live ? y[k] : 0.f;        // transposed: [label][step]
+          blk[(l16 + 16 * k) * kRow + tt] = row_live ? y[k] : 0.f;        // transposed: [label][step]
           if (dir == 0 && row_live) yrow[l16 + 16 * k] = y[k];
         }
       }
@@ -355,11 +364,11 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
     f4 eraw[PPL][2], braw[2];
 #pragma unroll
     for (int r = 0; r < PPL; r++) {
-      const f4* src = reinterpret_cast<const f4*>(blk + lc.lab[r] * kBlk);
+      const f4* src = reinterpret_cast<const f4*>(blk + lc.lab[r] * kRow);
       eraw[r][0] = src[0]; eraw[r][1] = src[1];
     }
     {
-      const f4* src = reinterpret_cast<const f4*>(blk + blank * kBlk);
+      const f4* src = reinterpret_cast<const f4*>(blk + blank * kRow);
       braw[0] = src[0]; braw[1] = src[1];
     }
     double yb[kBlk], e[kBlk][PPL];
@@ -370,7 +379,17 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
       for (int r = 0; r < PPL; r++) e[tt][r] = (double)eraw[r][tt >> 2][tt & 3];
     }
 #ifdef E2E_FAST_PROFILE
-    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+    unsigned long long ts0, ts1;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts0) :: "memory");   // spin done, loads issued
+    {
+      // force the loads to have landed before the second stamp
+      float sink = braw[0][0] + braw[1][3];
+#pragma unroll
+      for (int r = 0; r < PPL; r++) sink += eraw[r][0][0] + eraw[r][1][3];
+      asm volatile("" :: "v"(sink));
+    }
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts1) :: "memory");
+    prof_load += ts1 - ts0;
 #endif
     const int tbase = block_time(DIR, n, 0, T);          // t of tt = 0; t = tbase +/- tt
 #pragma unroll
@@ -447,8 +466,15 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
       }
     }
 #ifdef E2E_FAST_PROFILE
-    const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
-    prof_steps += ts2 - ts1;
+    {
+      double sink = 0.0;
+#pragma unroll
+      for (int k = 0; k < NC; k++) sink += c[k];
+      asm volatile("" :: "v"(sink));
+      unsigned long long ts2;
+      asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts2) :: "memory");
+      prof_steps += ts2 - ts1;
+    }
 #endif
     publish(&myfreed[slot], n + 1);
   };
@@ -507,7 +533,7 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   const int T = (int)Tq, S = (int)Sq;
   if (tid < 2 * 2 * kRingBlks) lds.flags[tid] = 0;
   for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
-    lds.ring[(size_t)(i / kBlk) * lds.blk_floats + V * kBlk + (i % kBlk)] = 0.f;
+    lds.ring[(size_t)(i / kBlk) * lds.blk_floats + V * kRow + (i % kBlk)] = 0.f;
   __syncthreads();
 
   const int wave = __builtin_amdgcn_readfirstlane(wid);
@@ -855,6 +881,332 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   }
 }
 
+// ============================================================================================
+// F2, multi-wave form: NW waves share one (utterance, segment); wave w owns the cells of global lanes 64w..64w+63
+// (PPLW = PPL/NW pairs per lane).  Per wave this halves (NW=2) the alpha rows kept in registers and the serial work,
+// which is what lets 3 waves per SIMD hide the latencies that bound the single-wave form.  The only coupling is the
+// one (alpha) / two (beta) boundary cells per step, exchanged through LDS around one workgroup barrier per step.
+// ============================================================================================
+template <int PPLW, int NW>
+struct F2MLds {
+  static constexpr int PPL = PPLW * NW;
+  static constexpr int PROW = 64 * PPL + 64 * NW;   // label cells in label order, then 64*NW blank partial sums
+  float* Ps; float* ys; float* invs; float* btot; float* xa; float* xb; int* starts; int* misc;
+  __device__ F2MLds(unsigned char* smem, int V) {
+    Ps = reinterpret_cast<float*>(smem);
+    ys = Ps + kHalf * PROW;
+    invs = ys + kYs * (V + 1);
+    btot = invs + kHalf;
+    xa = btot + kHalf;                 // [2][NW]     alpha hand-over (last label cell of each wave's lane 63)
+    xb = xa + 2 * NW;                  // [2][NW][2]  beta hand-over (first blank / label cell of each wave's lane 0)
+    starts = reinterpret_cast<int*>(xb + 4 * NW);      // [130]
+    misc = starts + 130;               // [4*NW] exponent hand-over, maxima
+  }
+  static size_t bytes(int V) {
+    return sizeof(float) * (kHalf * PROW + kYs * (V + 1) + 2 * kHalf + 6 * NW) + sizeof(int) * (130 + 4 * NW);
+  }
+};
+
+template <int PPLW, int NW>
+__global__ __launch_bounds__(64 * NW) void ctc_fast_segment_mw_kernel(FastParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int PPL = PPLW * NW, NC = 2 * PPLW, kSlope = 3 * NC;
+  constexpr int PROW = F2MLds<PPLW, NW>::PROW;
+  const int b = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gl = 64 * w + lane;                       // global lane: owns pairs PPLW*gl .. PPLW*gl+PPLW-1
+  const int V = p.V, blank = p.blank, Tmax = p.T, t0 = seg * kSeg;
+  const F2MLds<PPLW, NW> lds(smem, V);
+  float* grads = p.grads + (size_t)b * Tmax * V;
+  const float* x = p.x + (int64_t)b * p.sB;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+
+  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
+  if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
+  const int T = (int)Tq, S = (int)Sq, L = 2 * S + 1;
+  if (t0 >= Tmax) return;
+  const int tend = min(t0 + kSeg, Tmax);
+  // frames past the utterance's end: exp(lp) in log-prob mode (quirk Q1), zero for fused logits
+  for (int t = max(t0, T) + w; t < tend; t += NW)
+    for (int v = lane; v < V; v += 64)
+      grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : 0.f;
+  if (t0 >= T) return;
+  const int n = min(t0 + kSeg, T) - t0;
+  const bool FULLR = (seg > 0 && n == kSeg && t0 + n < T);      // interior segment (runtime; guards are cheap here)
+  const bool cond = (T > 1 || L == 1);
+
+  // ---- set-up shared by the waves: probability tile (transposed), label order ----
+  for (int i = threadIdx.x; i < kYs * (V + 1); i += 64 * NW) lds.ys[i] = 0.f;
+  for (int i = threadIdx.x; i < 130; i += 64 * NW) lds.starts[i] = 0;
+  __syncthreads();
+  {
+    const float* ytab = p.ytab + ((size_t)b * Tmax + t0) * V;
+    for (int i = threadIdx.x; i < n * V; i += 64 * NW) { const int tt = i / V, v = i - tt * V; lds.ys[v * kYs + tt] = ytab[i]; }
+  }
+  LaneCells<PPLW> lc;
+  lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, gl);
+  const float rr = lc.r;
+  int rank[PPLW];
+#pragma unroll
+  for (int r = 0; r < PPLW; r++) {
+    const int i = PPLW * gl + r;
+    rank[r] = (i < S && lc.lab[r] < V) ? atomicAdd(&lds.starts[lc.lab[r]], 1) : 0;
+  }
+  __syncthreads();
+  if (w == 0) {
+    const int c0 = lds.starts[lane], c1 = lds.starts[64 + lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int i0 = wave_scan(c0);
+    const int tot0 = __builtin_amdgcn_readlane(i0, 63);
+    const int i1 = wave_scan(c1) + tot0;
+    lds.starts[lane] = i0 - c0;
+    lds.starts[64 + lane] = i1 - c1;
+    if (lane == 63) lds.starts[128] = i1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < PPLW; r++) {
+    const int i = PPLW * gl + r;
+    // NOTE: ranks inside one label are in atomic-arrival order (any order gives the same per-label sum up to rounding)
+    rank[r] = (i < S && lc.lab[r] < V) ? lds.starts[lc.lab[r]] + rank[r] : i;
+  }
+
+  // ---- alpha checkpoint, per-lane exponents (slope-limited scan across all NW*64 lanes) ----
+  float A[kSeg][NC], a[NC];
+  int eA = 0;
+  if (seg == 0) {
+#pragma unroll
+    for (int k = 0; k < NC; k++) a[k] = 0.f;
+  } else {
+    const float* src = p.ckA + ((size_t)b * p.NS + seg) * p.CELLS + gl * NC;
+#pragma unroll
+    for (int k = 0; k < NC; k++) a[k] = src[k];
+    const int own = p.ckE[(((size_t)b * p.NS + seg) * 2 + 0) * 64 + gl / NW];   // F1 stores one exponent per 2*PPL cells
+    eA = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(eA, d, 64);
+      if (lane >= d) eA = max(eA, v - kSlope * d);
+    }
+    // carry across waves: wave w starts from wave w-1's last lane
+    for (int ww = 1; ww < NW; ww++) {
+      if (w == ww - 1 && lane == 63) lds.misc[ww - 1] = eA;
+      __syncthreads();
+      if (w == ww) eA = max(eA, lds.misc[ww - 1] - kSlope * (lane + 1));
+      __syncthreads();
+    }
+    const int sh = max(own - eA, -200);
+#pragma unroll
+    for (int k = 0; k < NC; k++) a[k] = ldexpf(a[k], sh);
+  }
+  // hand-over factors (alpha from lane-1, beta from lane+1), across the wave boundary too
+  if (lane == 0) lds.misc[NW + w] = eA;            // first lane's exponent of each wave
+  if (lane == 63) lds.misc[2 * NW + w] = eA;       // last lane's exponent of each wave
+  __syncthreads();
+  float fA, fB;
+  {
+    int ep = __shfl_up(eA, 1, 64), en = __shfl_down(eA, 1, 64);
+    if (lane == 0 && w > 0) ep = lds.misc[2 * NW + w - 1];
+    if (lane == 63 && w < NW - 1) en = lds.misc[NW + w + 1];
+    fA = gl > 0 ? ldexpf(1.f, max(min(ep - eA, 126), -126)) : 0.f;
+    fB = gl < 64 * NW - 1 ? ldexpf(1.f, max(min(eA - en, 126), -126)) : 0.f;
+  }
+  const f4* ylab[PPLW];
+#pragma unroll
+  for (int r = 0; r < PPLW; r++) ylab[r] = reinterpret_cast<const f4*>(lds.ys + lc.lab[r] * kYs);
+  const f4* yblank = reinterpret_cast<const f4*>(lds.ys + blank * kYs);
+  f4 e4[PPLW], b4;
+  const int eA7 = p.escA[(size_t)b * p.NB + (t0 >> 3)], eA15 = p.escA[(size_t)b * p.NB + (t0 >> 3) + 1];
+  const int eB0 = p.escB[(size_t)b * p.NB + (t0 >> 3)], eB8 = p.escB[(size_t)b * p.NB + (t0 >> 3) + 1];
+
+  // ---- alpha rows of the segment ----
+  if (lane == 63) lds.xa[NW + w] = a[NC - 1];      // buffer 1 holds "step -1" (the checkpoint row)
+  __syncthreads();
+#pragma unroll
+  for (int tt = 0; tt < kSeg; tt++) {
+    if ((tt & 3) == 0) {
+      b4 = yblank[tt >> 2];
+#pragma unroll
+      for (int r = 0; r < PPLW; r++) e4[r] = ylab[r][tt >> 2];
+    }
+    if (tt < n) {
+      const float yb = b4[tt & 3];
+      if (t0 + tt == 0) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) a[k] = 0.f;
+        if (gl == 0) { a[0] = cond ? yb : 0.f; a[1] = rr * e4[0][tt & 3]; }
+      } else {
+        float pl = from_prev_lane(a[NC - 1]);
+        if (lane == 0) pl = w > 0 ? lds.xa[((tt + 1) & 1) * NW + w - 1] : 0.f;
+        pl *= fA;
+#pragma unroll
+        for (int r = 0; r < PPLW; r++) {
+          const float ob = a[2 * r], ol = a[2 * r + 1];
+          a[2 * r] = (ob + rr * pl) * yb;
+          a[2 * r + 1] = (ol + rr * ob + lc.skp[r] * pl) * e4[r][tt & 3];
+          pl = ol;
+        }
+      }
+      if ((tt & 7) == 7) {
+        const int e = tt == 7 ? eA7 : eA15;
+        if (e != 0) {
+#pragma unroll
+          for (int k = 0; k < NC; k++) a[k] = ldexpf(a[k], -e);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; k++) A[tt][k] = a[k];
+    if (NW > 1) {
+      if (lane == 63) lds.xa[(tt & 1) * NW + w] = a[NC - 1];
+      __syncthreads();
+    }
+  }
+
+  // ---- beta checkpoint in the reciprocal units of the alpha lanes ----
+  float q[NC];
+  const bool last_seg = (t0 + n == T);
+  float end_unit = 1.f;
+  if (!last_seg) {
+    const float* src = p.ckQ + ((size_t)b * p.NS + seg + 1) * p.CELLS + gl * NC;
+#pragma unroll
+    for (int k = 0; k < NC; k++) q[k] = src[k];
+    const int ownB = p.ckE[(((size_t)b * p.NS + seg + 1) * 2 + 1) * 64 + gl / NW];
+    const int E = eA + ownB;
+    int emax = wave_max(E);
+    if (NW > 1) {
+      if (lane == 0) lds.misc[3 * NW + w] = emax;
+      __syncthreads();
+      for (int ww = 0; ww < NW; ww++) emax = max(emax, lds.misc[3 * NW + ww]);
+    }
+    const int sh = max(E - emax, -200);
+#pragma unroll
+    for (int k = 0; k < NC; k++) q[k] = ldexpf(q[k], sh);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NC; k++) q[k] = 0.f;
+    const int holder = (L - 1) / NC;                    // global lane holding cell L-1
+    if (gl == holder) lds.misc[3 * NW] = eA;
+    __syncthreads();
+    end_unit = ldexpf(1.f, max(min(eA - lds.misc[3 * NW], 126), -126));
+  }
+  if (NW > 1) {
+    if (lane == 0) { lds.xb[(0 * NW + w) * 2 + 0] = q[0]; lds.xb[(0 * NW + w) * 2 + 1] = q[1]; }   // buffer 0 = "step 16": the checkpoint row
+    __syncthreads();
+  }
+  float smin = __builtin_huge_valf(), smax = 0.f;
+#pragma unroll
+  for (int h = kSeg / kHalf - 1; h >= 0; h--) {
+#pragma unroll
+    for (int k = kHalf - 1; k >= 0; k--) {
+      const int tt = h * kHalf + k;
+      if ((tt & 3) == 3) {
+        b4 = yblank[tt >> 2];
+#pragma unroll
+        for (int r = 0; r < PPLW; r++) e4[r] = ylab[r][tt >> 2];
+      }
+      if (tt < n) {
+        const int t = t0 + tt;
+        const float yb = b4[tt & 3];
+        float bs[NC];
+        if (t == T - 1) {
+#pragma unroll
+          for (int r = 0; r < PPLW; r++) {
+            const int i = PPLW * gl + r;
+            bs[2 * r] = (2 * i == L - 1 && cond) ? end_unit : 0.f;
+            bs[2 * r + 1] = (2 * i + 1 == L - 2) ? rr * end_unit : 0.f;
+          }
+        } else {
+          float nb = from_next_lane(q[0]), nl = from_next_lane(q[1]);
+          if (lane == 63) {
+            const bool hasn = w < NW - 1;
+            nb = hasn ? lds.xb[((((tt + 1) & 1)) * NW + w + 1) * 2 + 0] : 0.f;
+            nl = hasn ? lds.xb[((((tt + 1) & 1)) * NW + w + 1) * 2 + 1] : 0.f;
+          }
+          nb *= fB; nl *= fB;
+#pragma unroll
+          for (int r = PPLW - 1; r >= 0; r--) {
+            bs[2 * r + 1] = q[2 * r + 1] + rr * nb + lc.skn[r] * nl;
+            bs[2 * r] = q[2 * r] + rr * q[2 * r + 1];
+            nb = q[2 * r]; nl = q[2 * r + 1];
+          }
+        }
+        float pblank = 0.f;
+#pragma unroll
+        for (int r = 0; r < PPLW; r++) {
+          pblank += A[tt][2 * r] * bs[2 * r];
+          lds.Ps[k * PROW + rank[r]] = A[tt][2 * r + 1] * bs[2 * r + 1];
+        }
+        lds.Ps[k * PROW + 64 * PPL + gl] = pblank;
+#pragma unroll
+        for (int r = 0; r < PPLW; r++) {
+          q[2 * r] = bs[2 * r] * yb;
+          q[2 * r + 1] = bs[2 * r + 1] * e4[r][tt & 3];
+        }
+        if ((tt & 7) == 0) {
+          const int e = tt == 0 ? eB0 : eB8;
+          if (e != 0) {
+#pragma unroll
+            for (int kk = 0; kk < NC; kk++) q[kk] = ldexpf(q[kk], -e);
+          }
+        }
+      }
+      if (NW > 1) {
+        // buffer parity: step tt writes (tt & 1); the reader at step tt-1 reads ((tt-1)+1)&1 = tt&1
+        if (lane == 0) { lds.xb[((tt & 1) * NW + w) * 2 + 0] = q[0]; lds.xb[((tt & 1) * NW + w) * 2 + 1] = q[1]; }
+        __syncthreads();
+      }
+    }
+    // ---- rows [h*8, h*8+8): per-label sums, normaliser, gradient rows; row k is done by wave k % NW ----
+    __syncthreads();
+    if (h * kHalf < n) {
+      for (int k = w; k < kHalf; k += NW) {
+        const int tt = h * kHalf + k;
+        if (tt < n) {
+          float c[PPL];
+#pragma unroll
+          for (int r = 0; r < PPL; r++) c[r] = lds.Ps[k * PROW + PPL * lane + r];
+          float bl = 0.f;
+#pragma unroll
+          for (int u = 0; u < NW; u++) bl += lds.Ps[k * PROW + 64 * PPL + NW * lane + u];
+#pragma unroll
+          for (int r = 1; r < PPL; r++) c[r] += c[r - 1];
+          const float incl = wave_scan(c[PPL - 1]);
+          const float excl = incl - c[PPL - 1];
+#pragma unroll
+          for (int r = 0; r < PPL; r++) lds.Ps[k * PROW + PPL * lane + r] = c[r] + excl;
+          const float lab_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+          const float bl_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan(bl)), 63));
+          const float st = lab_total + bl_total;
+          smin = fminf(smin, st); smax = fmaxf(smax, st);
+          if (lane == 0) { lds.invs[k] = __builtin_amdgcn_rcpf(st); lds.btot[k] = bl_total; }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int k = w; k < kHalf; k += NW) {               // the wave that scanned a row also writes it out
+        const int tt = h * kHalf + k;
+        if (tt < n) {
+          for (int v = lane; v < V; v += 64) {
+            const int lo = lds.starts[v], hi = lds.starts[v + 1];
+            const float* pre = lds.Ps + k * PROW;
+            float pv = (hi > lo) ? pre[hi - 1] - (lo > 0 ? pre[lo - 1] : 0.f) : 0.f;
+            if (v == blank) pv += lds.btot[k];
+            grads[(size_t)(t0 + tt) * V + v] = lds.ys[v * kYs + tt] - pv * lds.invs[k];
+          }
+        }
+      }
+    }
+    __syncthreads();                                       // Ps / invs are rewritten by the next half
+  }
+  (void)FULLR;
+  const bool finite_ok = smax < __builtin_huge_valf();
+  if (!(smin >= 0x1p-90f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
+  if (seg == 0 && threadIdx.x == 0) {
+    const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
+    if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
+  }
+}
+
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds1 = F1Lds::bytes(p.V);
@@ -863,7 +1215,14 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds2 = F2Lds<PPL>::bytes(p.V);
   hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
-  hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3((p.NS + kSegPerWave - 1) / kSegPerWave, p.B), dim3(64), lds2, stream, p);
+  static const int f2_mode = getenv("E2E_F2") ? atoi(getenv("E2E_F2")) : 0;     // 0: one wave per segment, 2: two waves
+  if (f2_mode == 2 && PPL >= 2) {
+    constexpr int NW = 2, PPLW = PPL >= 2 ? PPL / 2 : 1;
+    const size_t ldsm = F2MLds<PPLW, NW>::bytes(p.V);
+    hipLaunchKernelGGL((ctc_fast_segment_mw_kernel<PPLW, NW>), dim3(p.NS, p.B), dim3(64 * NW), ldsm, stream, p);
+  } else {
+    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3((p.NS + kSegPerWave - 1) / kSegPerWave, p.B), dim3(64), lds2, stream, p);
+  }
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
   return E2E_OK;
 }
