@@ -22,8 +22,6 @@
 //     targets that contain the blank id.
 //
 // Reference semantics restated: src/losses/ctc_loss.cpp:33-117 (recurrences, loss, gradient).
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "common.h"
@@ -54,6 +52,8 @@ struct FastParams {
   short* escB;     // [B][NB]   exponent removed from the beta row at step 8n
   double* logz;    // [B][2]    alpha-side / beta-side log Z
   int* flags;      // [B]       != 0: redo with the exact kernel
+  unsigned* cinfo; // [B][CELLS/2]  per label pair: label | sorted slot << 8 | alpha skip << 16 | beta skip << 17
+  int* lstart;     // [B][130]  first label-sorted slot of every label (V+1 entries used)
   int NS, NB, CELLS;
 };
 
@@ -177,15 +177,31 @@ struct LaneCells {
   // maxima: out of f32 range.  Weighting a step of one cell by r = sqrt(rho/(1-rho)), rho = S/T (the change of
   // measure under which a frame starts a new label with probability rho), centres both rows on the diagonal.
   // It costs nothing: the recurrences keep their shape with multipliers (1, r, r^2) instead of (1, 1, 1).
+  __device__ void set_tilt(int S, int T) {
+    // the number of alignments of t frames to i labels grows by ~((t-i)/(2i))^2 per extra label, so the
+    // untilted maximum sits at i = t/3; r = 2*rho/(1-rho) moves it to i = rho*t
+    float rho = (float)S / (float)T;
+    rho = fminf(fmaxf(rho, 1.f / 33.f), 0.8f);
+    r = S > 0 ? 2.f * rho / (1.f - rho) : 1.f;
+  }
+  // the packed form F1 leaves in the workspace for F2 (one word per label pair; `slot` = label-sorted position)
+  __device__ static unsigned pack(int lab, int slot, float skp, float skn) {
+    return (unsigned)lab | ((unsigned)slot << 8) | (skp != 0.f ? 1u << 16 : 0u) | (skn != 0.f ? 1u << 17 : 0u);
+  }
+  __device__ void unpack(const unsigned* w, int S, int T, int (&slot)[PPL]) {
+    set_tilt(S, T);
+    has_blank_label = false;
+#pragma unroll
+    for (int q = 0; q < PPL; q++) {
+      lab[q] = (int)(w[q] & 0xffu);
+      slot[q] = (int)((w[q] >> 8) & 0xffu);
+      skp[q] = (w[q] >> 16) & 1u ? r * r : 0.f;
+      skn[q] = (w[q] >> 17) & 1u ? r * r : 0.f;
+    }
+  }
   __device__ void load(const int64_t* tg, int S, int T, int V, int blank, int lane) {
     has_blank_label = false;
-    {
-      // the number of alignments of t frames to i labels grows by ~((t-i)/(2i))^2 per extra label, so the
-      // untilted maximum sits at i = t/3; r = 2*rho/(1-rho) moves it to i = rho*t
-      float rho = (float)S / (float)T;
-      rho = fminf(fmaxf(rho, 1.f / 33.f), 0.8f);
-      r = S > 0 ? 2.f * rho / (1.f - rho) : 1.f;
-    }
+    set_tilt(S, T);
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
       const int i = PPL * lane + q;
@@ -212,13 +228,15 @@ struct LaneCells {
 struct F1Lds {
   float* ring;       // [2][kRingBlks][V+1][kBlk]
   int* flags;        // filled[2][kRingBlks], freed[2][kRingBlks]
+  int* sortcnt;      // [130] counting-sort scratch of the cell-info wave
   int blk_floats;
   __device__ F1Lds(unsigned char* smem, int V) {
     blk_floats = (V + 1) * kRow;
     ring = reinterpret_cast<float*>(smem);
     flags = reinterpret_cast<int*>(ring + 2 * kRingBlks * blk_floats);
+    sortcnt = flags + 4 * kRingBlks;
   }
-  static size_t bytes(int V) { return sizeof(float) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * 4 * kRingBlks; }
+  static size_t bytes(int V) { return sizeof(float) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * (4 * kRingBlks + 130); }
 };
 
 // Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
@@ -512,11 +530,52 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
   }
 }
 
+// Per-utterance lattice description for F2, computed once here instead of once per 16-step segment there (63x at
+// T = 1000): label, skip flags and the label-sorted slot of every label pair, plus the first slot of every label.
+// Counting sort of the label cells by label: cell i -> start[label] + (its order inside the label); cells past
+// the utterance's S labels keep slot i (they only ever hold zeros).
+template <int PPL>
+__device__ __forceinline__ void cellinfo_wave(const FastParams& p, int b, int T, int S, int* cnt, int lane) {
+  const int V = p.V;
+  cnt[lane] = 0; cnt[64 + lane] = 0; if (lane < 2) cnt[128 + lane] = 0;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  LaneCells<PPL> lc;
+  lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, p.blank, lane);
+  int rank[PPL];
+#pragma unroll
+  for (int r = 0; r < PPL; r++) {
+    const int i = PPL * lane + r;
+    rank[r] = (i < S && lc.lab[r] < V) ? atomicAdd(&cnt[lc.lab[r]], 1) : 0;    // ds_add_rtn_u32
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  int* ls = p.lstart + (size_t)b * 130;
+  {
+    // exclusive prefix over the label counts, two chunks of 64 labels
+    const int c0 = cnt[lane], c1 = cnt[64 + lane];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int i0 = wave_scan(c0);
+    const int t0s = __builtin_amdgcn_readlane(i0, 63);
+    const int i1 = wave_scan(c1) + t0s;
+    cnt[lane] = i0 - c0; ls[lane] = i0 - c0;
+    cnt[64 + lane] = i1 - c1; ls[64 + lane] = i1 - c1;
+    if (lane == 63) { cnt[128] = i1; ls[128] = i1; ls[129] = i1; }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  unsigned* ci = p.cinfo + (size_t)b * (p.CELLS / 2) + PPL * lane;
+#pragma unroll
+  for (int r = 0; r < PPL; r++) {
+    const int i = PPL * lane + r;
+    const int slot = (i < S && lc.lab[r] < V) ? cnt[lc.lab[r]] + rank[r] : i;
+    ci[r] = LaneCells<PPL>::pack(lc.lab[r], slot, lc.skp[r], lc.skn[r]);
+  }
+}
+
 // ============================================================================================
 // F1: the two serial chains
 // ============================================================================================
 // Waves of a workgroup land on the SIMDs in the order 0,2,1,3,0,2,1,3: waves 0/1 (the chains) get SIMDs 0 and 2 to
-// themselves, waves 2,6 (alpha rows) share SIMD 1, waves 3,7 (beta rows) share SIMD 3, waves 4/5 retire at once.
+// themselves, waves 2,6 (alpha rows) share SIMD 1, waves 3,7 (beta rows) share SIMD 3; wave 4 writes the lattice
+// description for F2 and retires, wave 5 retires at once.
 template <int PPL>
 __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -539,7 +598,8 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(wid);
   if (wave == 0) chain_wave<PPL, 0>(p, b, T, S, lds, lane);
   else if (wave == 1) chain_wave<PPL, 1>(p, b, T, S, lds, lane);
-  else if (wave == 4 || wave == 5) return;
+  else if (wave == 4) cellinfo_wave<PPL>(p, b, T, S, lds.sortcnt, lane);
+  else if (wave == 5) return;
   else {
     const int d = (wave == 2 || wave == 6) ? 0 : 1;     // waves 2,6 -> alpha rows, waves 3,7 -> beta rows
     const int first = wave >= 6 ? 1 : 0;                 // the two producers of a direction take alternate blocks
@@ -815,38 +875,19 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   const int seg_first = blockIdx.x * kSegPerWave;
   if (seg_first * kSeg >= Tmax) return;
 
-  // counting sort of the label cells by label: cell i -> slot start[label] + (its order inside the label),
-  // cells past the utterance's S labels keep slot i (they only ever hold zeros).  Needed only by live segments.
+  // the utterance's lattice description, left in the workspace by F1 (cellinfo_wave): independent loads, one round trip
   LaneCells<PPL> lc;
   int rank[PPL];
   if (seg_first * kSeg < T) {
-    lds.starts[lane] = 0; lds.starts[64 + lane] = 0; if (lane < 2) lds.starts[128 + lane] = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, lane);
+    const unsigned* ci = p.cinfo + (size_t)b * (p.CELLS / 2) + PPL * lane;
+    unsigned w[PPL];
 #pragma unroll
-    for (int r = 0; r < PPL; r++) {
-      const int i = PPL * lane + r;
-      rank[r] = (i < S && lc.lab[r] < V) ? atomicAdd(&lds.starts[lc.lab[r]], 1) : 0;    // ds_add_rtn_u32
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
-      // exclusive prefix over the label counts, two chunks of 64 labels
-      const int c0 = lds.starts[lane], c1 = lds.starts[64 + lane];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int i0 = wave_scan(c0);
-      const int t0s = __builtin_amdgcn_readlane(i0, 63);
-      const int i1 = wave_scan(c1) + t0s;
-      lds.starts[lane] = i0 - c0;
-      lds.starts[64 + lane] = i1 - c1;
-      if (lane == 63) lds.starts[128] = i1;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int r = 0; r < PPL; r++) {
-      const int i = PPL * lane + r;
-      rank[r] = (i < S && lc.lab[r] < V) ? lds.starts[lc.lab[r]] + rank[r] : i;
-    }
-    for (int i = lane; i < kYs * (V + 1); i += 64) lds.ys[i] = 0.f;      // incl. the zero row V and dead steps
+    for (int r = 0; r < PPL; r++) w[r] = ci[r];
+    const int* ls = p.lstart + (size_t)b * 130;
+    const int s0 = ls[lane], s1 = ls[64 + lane];
+    lds.starts[lane] = s0; lds.starts[64 + lane] = s1; if (lane < 2) lds.starts[128 + lane] = ls[128 + lane];
+    lc.unpack(w, S, T, rank);
+    if (lane < kYs) lds.ys[V * kYs + lane] = 0.f;                           // the zero row V
   }
 
   float smin = __builtin_huge_valf(), smax = 0.f;
@@ -860,11 +901,30 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
         grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : 0.f;
     if (t0 >= T) continue;
     const int n = min(t0 + kSeg, T) - t0;
-    // stage the segment's probability rows
-    const float* ytab = p.ytab + ((size_t)b * Tmax + t0) * V;
+    // stage the segment's probability rows: they are n*V consecutive floats of ytab -> 16-byte loads from the
+    // aligned address below, scattered into the transposed tile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int tt = 0; tt < kSeg; tt++)
-      for (int v = lane; v < V; v += 64) lds.ys[v * kYs + tt] = tt < n ? ytab[tt * V + v] : 0.f;
+    if (n < kSeg)
+      for (int i = lane; i < kYs * V; i += 64) lds.ys[i] = 0.f;            // dead steps of a short last segment
+    {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const size_t g0 = ((size_t)b * Tmax + t0) * V;
+      const size_t a0 = g0 & ~(size_t)3;
+      const int skew = (int)(g0 - a0), count = n * V;
+      const unsigned magic = (1u << 20) / (unsigned)V + 1u;                // idx / V for idx < 2^20 / V
+      const f4* src = reinterpret_cast<const f4*>(p.ytab + a0);
+      for (int e = lane; 4 * e < count + skew; e += 64) {
+        const f4 v4 = src[e];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int idx = 4 * e + c - skew;
+          if (idx >= 0 && idx < count) {
+            const int tt = (int)(((unsigned)idx * magic) >> 20);
+            lds.ys[(idx - tt * V) * kYs + tt] = v4[c];
+          }
+        }
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
     const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
     if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, lds, lane, smin, smax);
@@ -881,332 +941,6 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   }
 }
 
-// ============================================================================================
-// F2, multi-wave form: NW waves share one (utterance, segment); wave w owns the cells of global lanes 64w..64w+63
-// (PPLW = PPL/NW pairs per lane).  Per wave this halves (NW=2) the alpha rows kept in registers and the serial work,
-// which is what lets 3 waves per SIMD hide the latencies that bound the single-wave form.  The only coupling is the
-// one (alpha) / two (beta) boundary cells per step, exchanged through LDS around one workgroup barrier per step.
-// ============================================================================================
-template <int PPLW, int NW>
-struct F2MLds {
-  static constexpr int PPL = PPLW * NW;
-  static constexpr int PROW = 64 * PPL + 64 * NW;   // label cells in label order, then 64*NW blank partial sums
-  float* Ps; float* ys; float* invs; float* btot; float* xa; float* xb; int* starts; int* misc;
-  __device__ F2MLds(unsigned char* smem, int V) {
-    Ps = reinterpret_cast<float*>(smem);
-    ys = Ps + kHalf * PROW;
-    invs = ys + kYs * (V + 1);
-    btot = invs + kHalf;
-    xa = btot + kHalf;                 // [2][NW]     alpha hand-over (last label cell of each wave's lane 63)
-    xb = xa + 2 * NW;                  // [2][NW][2]  beta hand-over (first blank / label cell of each wave's lane 0)
-    starts = reinterpret_cast<int*>(xb + 4 * NW);      // [130]
-    misc = starts + 130;               // [4*NW] exponent hand-over, maxima
-  }
-  static size_t bytes(int V) {
-    return sizeof(float) * (kHalf * PROW + kYs * (V + 1) + 2 * kHalf + 6 * NW) + sizeof(int) * (130 + 4 * NW);
-  }
-};
-
-template <int PPLW, int NW>
-__global__ __launch_bounds__(64 * NW) void ctc_fast_segment_mw_kernel(FastParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int PPL = PPLW * NW, NC = 2 * PPLW, kSlope = 3 * NC;
-  constexpr int PROW = F2MLds<PPLW, NW>::PROW;
-  const int b = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gl = 64 * w + lane;                       // global lane: owns pairs PPLW*gl .. PPLW*gl+PPLW-1
-  const int V = p.V, blank = p.blank, Tmax = p.T, t0 = seg * kSeg;
-  const F2MLds<PPLW, NW> lds(smem, V);
-  float* grads = p.grads + (size_t)b * Tmax * V;
-  const float* x = p.x + (int64_t)b * p.sB;
-  typedef float f4 __attribute__((ext_vector_type(4)));
-
-  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
-  if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
-  const int T = (int)Tq, S = (int)Sq, L = 2 * S + 1;
-  if (t0 >= Tmax) return;
-  const int tend = min(t0 + kSeg, Tmax);
-  // frames past the utterance's end: exp(lp) in log-prob mode (quirk Q1), zero for fused logits
-  for (int t = max(t0, T) + w; t < tend; t += NW)
-    for (int v = lane; v < V; v += 64)
-      grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : 0.f;
-  if (t0 >= T) return;
-  const int n = min(t0 + kSeg, T) - t0;
-  const bool FULLR = (seg > 0 && n == kSeg && t0 + n < T);      // interior segment (runtime; guards are cheap here)
-  const bool cond = (T > 1 || L == 1);
-
-  // ---- set-up shared by the waves: probability tile (transposed), label order ----
-  for (int i = threadIdx.x; i < kYs * (V + 1); i += 64 * NW) lds.ys[i] = 0.f;
-  for (int i = threadIdx.x; i < 130; i += 64 * NW) lds.starts[i] = 0;
-  __syncthreads();
-  {
-    const float* ytab = p.ytab + ((size_t)b * Tmax + t0) * V;
-    for (int i = threadIdx.x; i < n * V; i += 64 * NW) { const int tt = i / V, v = i - tt * V; lds.ys[v * kYs + tt] = ytab[i]; }
-  }
-  LaneCells<PPLW> lc;
-  lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, gl);
-  const float rr = lc.r;
-  int rank[PPLW];
-#pragma unroll
-  for (int r = 0; r < PPLW; r++) {
-    const int i = PPLW * gl + r;
-    rank[r] = (i < S && lc.lab[r] < V) ? atomicAdd(&lds.starts[lc.lab[r]], 1) : 0;
-  }
-  __syncthreads();
-  if (w == 0) {
-    const int c0 = lds.starts[lane], c1 = lds.starts[64 + lane];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int i0 = wave_scan(c0);
-    const int tot0 = __builtin_amdgcn_readlane(i0, 63);
-    const int i1 = wave_scan(c1) + tot0;
-    lds.starts[lane] = i0 - c0;
-    lds.starts[64 + lane] = i1 - c1;
-    if (lane == 63) lds.starts[128] = i1;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < PPLW; r++) {
-    const int i = PPLW * gl + r;
-    // NOTE: ranks inside one label are in atomic-arrival order (any order gives the same per-label sum up to rounding)
-    rank[r] = (i < S && lc.lab[r] < V) ? lds.starts[lc.lab[r]] + rank[r] : i;
-  }
-
-  // ---- alpha checkpoint, per-lane exponents (slope-limited scan across all NW*64 lanes) ----
-  float A[kSeg][NC], a[NC];
-  int eA = 0;
-  if (seg == 0) {
-#pragma unroll
-    for (int k = 0; k < NC; k++) a[k] = 0.f;
-  } else {
-    const float* src = p.ckA + ((size_t)b * p.NS + seg) * p.CELLS + gl * NC;
-#pragma unroll
-    for (int k = 0; k < NC; k++) a[k] = src[k];
-    const int own = p.ckE[(((size_t)b * p.NS + seg) * 2 + 0) * 64 + gl / NW];   // F1 stores one exponent per 2*PPL cells
-    eA = own;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int v = __shfl_up(eA, d, 64);
-      if (lane >= d) eA = max(eA, v - kSlope * d);
-    }
-    // carry across waves: wave w starts from wave w-1's last lane
-    for (int ww = 1; ww < NW; ww++) {
-      if (w == ww - 1 && lane == 63) lds.misc[ww - 1] = eA;
-      __syncthreads();
-      if (w == ww) eA = max(eA, lds.misc[ww - 1] - kSlope * (lane + 1));
-      __syncthreads();
-    }
-    const int sh = max(own - eA, -200);
-#pragma unroll
-    for (int k = 0; k < NC; k++) a[k] = ldexpf(a[k], sh);
-  }
-  // hand-over factors (alpha from lane-1, beta from lane+1), across the wave boundary too
-  if (lane == 0) lds.misc[NW + w] = eA;            // first lane's exponent of each wave
-  if (lane == 63) lds.misc[2 * NW + w] = eA;       // last lane's exponent of each wave
-  __syncthreads();
-  float fA, fB;
-  {
-    int ep = __shfl_up(eA, 1, 64), en = __shfl_down(eA, 1, 64);
-    if (lane == 0 && w > 0) ep = lds.misc[2 * NW + w - 1];
-    if (lane == 63 && w < NW - 1) en = lds.misc[NW + w + 1];
-    fA = gl > 0 ? ldexpf(1.f, max(min(ep - eA, 126), -126)) : 0.f;
-    fB = gl < 64 * NW - 1 ? ldexpf(1.f, max(min(eA - en, 126), -126)) : 0.f;
-  }
-  const f4* ylab[PPLW];
-#pragma unroll
-  for (int r = 0; r < PPLW; r++) ylab[r] = reinterpret_cast<const f4*>(lds.ys + lc.lab[r] * kYs);
-  const f4* yblank = reinterpret_cast<const f4*>(lds.ys + blank * kYs);
-  f4 e4[PPLW], b4;
-  const int eA7 = p.escA[(size_t)b * p.NB + (t0 >> 3)], eA15 = p.escA[(size_t)b * p.NB + (t0 >> 3) + 1];
-  const int eB0 = p.escB[(size_t)b * p.NB + (t0 >> 3)], eB8 = p.escB[(size_t)b * p.NB + (t0 >> 3) + 1];
-
-  // ---- alpha rows of the segment ----
-  if (lane == 63) lds.xa[NW + w] = a[NC - 1];      // buffer 1 holds "step -1" (the checkpoint row)
-  __syncthreads();
-#pragma unroll
-  for (int tt = 0; tt < kSeg; tt++) {
-    if ((tt & 3) == 0) {
-      b4 = yblank[tt >> 2];
-#pragma unroll
-      for (int r = 0; r < PPLW; r++) e4[r] = ylab[r][tt >> 2];
-    }
-    if (tt < n) {
-      const float yb = b4[tt & 3];
-      if (t0 + tt == 0) {
-#pragma unroll
-        for (int k = 0; k < NC; k++) a[k] = 0.f;
-        if (gl == 0) { a[0] = cond ? yb : 0.f; a[1] = rr * e4[0][tt & 3]; }
-      } else {
-        float pl = from_prev_lane(a[NC - 1]);
-        if (lane == 0) pl = w > 0 ? lds.xa[((tt + 1) & 1) * NW + w - 1] : 0.f;
-        pl *= fA;
-#pragma unroll
-        for (int r = 0; r < PPLW; r++) {
-          const float ob = a[2 * r], ol = a[2 * r + 1];
-          a[2 * r] = (ob + rr * pl) * yb;
-          a[2 * r + 1] = (ol + rr * ob + lc.skp[r] * pl) * e4[r][tt & 3];
-          pl = ol;
-        }
-      }
-      if ((tt & 7) == 7) {
-        const int e = tt == 7 ? eA7 : eA15;
-        if (e != 0) {
-#pragma unroll
-          for (int k = 0; k < NC; k++) a[k] = ldexpf(a[k], -e);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NC; k++) A[tt][k] = a[k];
-    if (NW > 1) {
-      if (lane == 63) lds.xa[(tt & 1) * NW + w] = a[NC - 1];
-      __syncthreads();
-    }
-  }
-
-  // ---- beta checkpoint in the reciprocal units of the alpha lanes ----
-  float q[NC];
-  const bool last_seg = (t0 + n == T);
-  float end_unit = 1.f;
-  if (!last_seg) {
-    const float* src = p.ckQ + ((size_t)b * p.NS + seg + 1) * p.CELLS + gl * NC;
-#pragma unroll
-    for (int k = 0; k < NC; k++) q[k] = src[k];
-    const int ownB = p.ckE[(((size_t)b * p.NS + seg + 1) * 2 + 1) * 64 + gl / NW];
-    const int E = eA + ownB;
-    int emax = wave_max(E);
-    if (NW > 1) {
-      if (lane == 0) lds.misc[3 * NW + w] = emax;
-      __syncthreads();
-      for (int ww = 0; ww < NW; ww++) emax = max(emax, lds.misc[3 * NW + ww]);
-    }
-    const int sh = max(E - emax, -200);
-#pragma unroll
-    for (int k = 0; k < NC; k++) q[k] = ldexpf(q[k], sh);
-  } else {
-#pragma unroll
-    for (int k = 0; k < NC; k++) q[k] = 0.f;
-    const int holder = (L - 1) / NC;                    // global lane holding cell L-1
-    if (gl == holder) lds.misc[3 * NW] = eA;
-    __syncthreads();
-    end_unit = ldexpf(1.f, max(min(eA - lds.misc[3 * NW], 126), -126));
-  }
-  if (NW > 1) {
-    if (lane == 0) { lds.xb[(0 * NW + w) * 2 + 0] = q[0]; lds.xb[(0 * NW + w) * 2 + 1] = q[1]; }   // buffer 0 = "step 16": the checkpoint row
-    __syncthreads();
-  }
-  float smin = __builtin_huge_valf(), smax = 0.f;
-#pragma unroll
-  for (int h = kSeg / kHalf - 1; h >= 0; h--) {
-#pragma unroll
-    for (int k = kHalf - 1; k >= 0; k--) {
-      const int tt = h * kHalf + k;
-      if ((tt & 3) == 3) {
-        b4 = yblank[tt >> 2];
-#pragma unroll
-        for (int r = 0; r < PPLW; r++) e4[r] = ylab[r][tt >> 2];
-      }
-      if (tt < n) {
-        const int t = t0 + tt;
-        const float yb = b4[tt & 3];
-        float bs[NC];
-        if (t == T - 1) {
-#pragma unroll
-          for (int r = 0; r < PPLW; r++) {
-            const int i = PPLW * gl + r;
-            bs[2 * r] = (2 * i == L - 1 && cond) ? end_unit : 0.f;
-            bs[2 * r + 1] = (2 * i + 1 == L - 2) ? rr * end_unit : 0.f;
-          }
-        } else {
-          float nb = from_next_lane(q[0]), nl = from_next_lane(q[1]);
-          if (lane == 63) {
-            const bool hasn = w < NW - 1;
-            nb = hasn ? lds.xb[((((tt + 1) & 1)) * NW + w + 1) * 2 + 0] : 0.f;
-            nl = hasn ? lds.xb[((((tt + 1) & 1)) * NW + w + 1) * 2 + 1] : 0.f;
-          }
-          nb *= fB; nl *= fB;
-#pragma unroll
-          for (int r = PPLW - 1; r >= 0; r--) {
-            bs[2 * r + 1] = q[2 * r + 1] + rr * nb + lc.skn[r] * nl;
-            bs[2 * r] = q[2 * r] + rr * q[2 * r + 1];
-            nb = q[2 * r]; nl = q[2 * r + 1];
-          }
-        }
-        float pblank = 0.f;
-#pragma unroll
-        for (int r = 0; r < PPLW; r++) {
-          pblank += A[tt][2 * r] * bs[2 * r];
-          lds.Ps[k * PROW + rank[r]] = A[tt][2 * r + 1] * bs[2 * r + 1];
-        }
-        lds.Ps[k * PROW + 64 * PPL + gl] = pblank;
-#pragma unroll
-        for (int r = 0; r < PPLW; r++) {
-          q[2 * r] = bs[2 * r] * yb;
-          q[2 * r + 1] = bs[2 * r + 1] * e4[r][tt & 3];
-        }
-        if ((tt & 7) == 0) {
-          const int e = tt == 0 ? eB0 : eB8;
-          if (e != 0) {
-#pragma unroll
-            for (int kk = 0; kk < NC; kk++) q[kk] = ldexpf(q[kk], -e);
-          }
-        }
-      }
-      if (NW > 1) {
-        // buffer parity: step tt writes (tt & 1); the reader at step tt-1 reads ((tt-1)+1)&1 = tt&1
-        if (lane == 0) { lds.xb[((tt & 1) * NW + w) * 2 + 0] = q[0]; lds.xb[((tt & 1) * NW + w) * 2 + 1] = q[1]; }
-        __syncthreads();
-      }
-    }
-    // ---- rows [h*8, h*8+8): per-label sums, normaliser, gradient rows; row k is done by wave k % NW ----
-    __syncthreads();
-    if (h * kHalf < n) {
-      for (int k = w; k < kHalf; k += NW) {
-        const int tt = h * kHalf + k;
-        if (tt < n) {
-          float c[PPL];
-#pragma unroll
-          for (int r = 0; r < PPL; r++) c[r] = lds.Ps[k * PROW + PPL * lane + r];
-          float bl = 0.f;
-#pragma unroll
-          for (int u = 0; u < NW; u++) bl += lds.Ps[k * PROW + 64 * PPL + NW * lane + u];
-#pragma unroll
-          for (int r = 1; r < PPL; r++) c[r] += c[r - 1];
-          const float incl = wave_scan(c[PPL - 1]);
-          const float excl = incl - c[PPL - 1];
-#pragma unroll
-          for (int r = 0; r < PPL; r++) lds.Ps[k * PROW + PPL * lane + r] = c[r] + excl;
-          const float lab_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
-          const float bl_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan(bl)), 63));
-          const float st = lab_total + bl_total;
-          smin = fminf(smin, st); smax = fmaxf(smax, st);
-          if (lane == 0) { lds.invs[k] = __builtin_amdgcn_rcpf(st); lds.btot[k] = bl_total; }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      for (int k = w; k < kHalf; k += NW) {               // the wave that scanned a row also writes it out
-        const int tt = h * kHalf + k;
-        if (tt < n) {
-          for (int v = lane; v < V; v += 64) {
-            const int lo = lds.starts[v], hi = lds.starts[v + 1];
-            const float* pre = lds.Ps + k * PROW;
-            float pv = (hi > lo) ? pre[hi - 1] - (lo > 0 ? pre[lo - 1] : 0.f) : 0.f;
-            if (v == blank) pv += lds.btot[k];
-            grads[(size_t)(t0 + tt) * V + v] = lds.ys[v * kYs + tt] - pv * lds.invs[k];
-          }
-        }
-      }
-    }
-    __syncthreads();                                       // Ps / invs are rewritten by the next half
-  }
-  (void)FULLR;
-  const bool finite_ok = smax < __builtin_huge_valf();
-  if (!(smin >= 0x1p-90f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
-  if (seg == 0 && threadIdx.x == 0) {
-    const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
-    if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
-  }
-}
-
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds1 = F1Lds::bytes(p.V);
@@ -1215,14 +949,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds2 = F2Lds<PPL>::bytes(p.V);
   hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
-  static const int f2_mode = getenv("E2E_F2") ? atoi(getenv("E2E_F2")) : 0;     // 0: one wave per segment, 2: two waves
-  if (f2_mode == 2 && PPL >= 2) {
-    constexpr int NW = 2, PPLW = PPL >= 2 ? PPL / 2 : 1;
-    const size_t ldsm = F2MLds<PPLW, NW>::bytes(p.V);
-    hipLaunchKernelGGL((ctc_fast_segment_mw_kernel<PPLW, NW>), dim3(p.NS, p.B), dim3(64 * NW), ldsm, stream, p);
-  } else {
-    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3((p.NS + kSegPerWave - 1) / kSegPerWave, p.B), dim3(64), lds2, stream, p);
-  }
+  hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3((p.NS + kSegPerWave - 1) / kSegPerWave, p.B), dim3(64), lds2, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
   return E2E_OK;
 }
@@ -1236,7 +963,7 @@ int ppl_for(int Smax) {
 }
 
 struct FastLayout {
-  size_t ytab, ckA, ckQ, ckE, escA, escB, logz, flags, total;
+  size_t ytab, ckA, ckQ, ckE, escA, escB, logz, flags, cinfo, lstart, total;
   int NS, NB, CELLS;
 };
 
@@ -1255,6 +982,8 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
   l.escB = o; o += align_up((size_t)B * l.NB * sizeof(short), 256);
   l.logz = o; o += align_up((size_t)B * 2 * sizeof(double), 256);
   l.flags = o; o += align_up((size_t)B * sizeof(int), 256);
+  l.cinfo = o; o += align_up((size_t)B * (l.CELLS / 2) * sizeof(unsigned), 256);
+  l.lstart = o; o += align_up((size_t)B * 130 * sizeof(int), 256);
   l.total = o;
   return l;
 }
@@ -1289,6 +1018,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.ckE = reinterpret_cast<short*>(ws + l.ckE);
   p.escA = reinterpret_cast<short*>(ws + l.escA); p.escB = reinterpret_cast<short*>(ws + l.escB);
   p.logz = reinterpret_cast<double*>(ws + l.logz); p.flags = reinterpret_cast<int*>(ws + l.flags);
+  p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart);
   p.NS = l.NS; p.NB = l.NB; p.CELLS = l.CELLS;
   E2E_HIP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)a.B * sizeof(int), a.stream), "hipMemsetAsync(flags)");
   int rc;

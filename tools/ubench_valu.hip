@@ -80,16 +80,30 @@ __global__ void bench(unsigned long long* out, double* sink, int zero) {
   r[11] = timed([&] { for (int i = 0; i < N_ITER; i++) {
 #pragma unroll
     for (int k = 0; k < 8; k++) fa[0] += __shfl_xor(fa[0], 16, 64); } });
+  // 12: 8 x v_cvt_f64_f32 (independent)
+  r[12] = timed([&] { for (int i = 0; i < N_ITER; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) { asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a[k]) : "v"(fa[k])); } } });
+  // 13: 8 x v_cvt_f32_f64
+  r[13] = timed([&] { for (int i = 0; i < N_ITER; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) { asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(fa[k]) : "v"(a[k])); } } });
+  // 14: 8 x v_mov_b32_dpp (independent)
+  int ia[8]; for (int k = 0; k < 8; k++) ia[k] = lane + k;
+  r[14] = timed([&] { for (int i = 0; i < N_ITER; i++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) ia[k] = __builtin_amdgcn_update_dpp(0, ia[k], 0x138, 0xf, 0xf, true); } });
+  for (int k = 0; k < 8; k++) fa[k] += ia[k];
   double s = 0; for (int k = 0; k < 8; k++) s += a[k] + fa[k] + pa[k].x + pa[k].y;
   sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if (threadIdx.x == 0) for (int k = 0; k < 12; k++) out[blockIdx.x * 16 + k] = r[k];
+  if (threadIdx.x == 0) for (int k = 0; k < 15; k++) out[blockIdx.x * 16 + k] = r[k];
 }
 
 int main() {
-  const char* names[12] = {"f64 fma x8 indep", "f64 fma dependent", "f64 mul x8 indep", "f64 add x8 indep", "f32 fma x8 indep",
+  const char* names[15] = {"f64 fma x8 indep", "f64 fma dependent", "f64 mul x8 indep", "f64 add x8 indep", "f32 fma x8 indep",
                            "f32 fma dependent", "f64 ldexp x8", "ds_read_b64 x8 + add", "dpp64 + fma dependent", "v_exp_f32 x8",
-                           "v_pk_fma_f32 x8", "shfl_xor(bpermute)+add dep"};
-  for (int waves : {1, 2, 4, 8}) {
+                           "v_pk_fma_f32 x8", "shfl_xor(bpermute)+add dep", "v_cvt_f64_f32 x8", "v_cvt_f32_f64 x8", "v_mov_b32_dpp x8"};
+  for (int waves : {1, 4}) {
     unsigned long long* out; double* sink;
     hipMalloc(&out, 16 * 8 * 1024); hipMalloc(&sink, 8 * 64 * 1024 * 8);
     bench<<<1, 64 * waves>>>(out, sink, 0);
@@ -97,7 +111,7 @@ int main() {
     std::vector<unsigned long long> h(16);
     hipMemcpy(h.data(), out, 16 * 8, hipMemcpyDeviceToHost);
     printf("== %d wave(s) in one workgroup (one CU): cycles (s_memtime ticks) per wave-instruction, wave 0\n", waves);
-    for (int k = 0; k < 12; k++) printf("  %-28s %7.2f\n", names[k], (double)h[k] / (N_ITER * 8.0));
+    for (int k = 0; k < 15; k++) printf("  %-28s %7.2f\n", names[k], (double)h[k] / (N_ITER * 8.0));
   }
   return 0;
 }
