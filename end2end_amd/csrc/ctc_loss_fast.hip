@@ -22,6 +22,7 @@
 //     targets that contain the blank id.
 //
 // Reference semantics restated: src/losses/ctc_loss.cpp:33-117 (recurrences, loss, gradient).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -55,6 +56,7 @@ struct FastParams {
   unsigned* cinfo; // [B][CELLS/2]  per label pair: label | sorted slot << 8 | alpha skip << 16 | beta skip << 17
   int* lstart;     // [B][130]  first label-sorted slot of every label (V+1 entries used)
   int NS, NB, CELLS;
+  int dbg;         // diagnostics only: stop F2 early (timing experiments)
 };
 
 // ---- cross-lane helpers (wave64) ------------------------------------------------------------
@@ -145,11 +147,20 @@ __device__ __forceinline__ float row16_sum(float v) {
 // the wave's outstanding GLOBAL stores -- checkpoints, probability rows -- once per 8-step block.)
 #ifdef E2E_FAST_PROFILE
 } __device__ unsigned long long g_prof[256 * 4 * 4]; namespace {   // [wg][wave][total, spin, nspin, -]
+} __device__ unsigned long long g_prof2[16384 * 8]; namespace {      // F2 phase cycles per workgroup (first 16384)
+__shared__ unsigned long long s_prof_prev;
+__shared__ unsigned long long s_prof_acc[8];
+#define F2_STAMP(i) { unsigned long long _t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
+    if (threadIdx.x == 0) { if ((i) < 0) { for (int _k = 0; _k < 8; _k++) s_prof_acc[_k] = 0; } else s_prof_acc[(i) < 0 ? 0 : (i)] += _t - s_prof_prev; } \
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); if (threadIdx.x == 0) s_prof_prev = _t; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#define F2_FLUSH { const unsigned _wg = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x < 8 && _wg < 16384) g_prof2[_wg * 8 + threadIdx.x] = s_prof_acc[threadIdx.x]; }
 #define PROF_SPIN_BEGIN unsigned long long _t0 = __builtin_amdgcn_s_memtime();
 #define PROF_SPIN_END(acc) acc += __builtin_amdgcn_s_memtime() - _t0;
 #else
 #define PROF_SPIN_BEGIN
 #define PROF_SPIN_END(acc)
+#define F2_STAMP(i)
+#define F2_FLUSH
 #endif
 typedef __attribute__((address_space(3))) int lds_int;
 // (the flags must be addressed as LDS: through a generic pointer the poll becomes a flat load with sc0 sc1 and
@@ -637,50 +648,71 @@ struct F2Lds {
   static size_t bytes(int V) { return sizeof(float) * (kHalf * PROW + kYs * (V + 1) + 2 * kHalf) + sizeof(int) * 130; }
 };
 
-// rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows
-template <int PPL>
+// rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows.  FULL: all 8 rows are live.
+template <int PPL, bool FULL>
 __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, int n, int h, const F2Lds<PPL>& lds,
                                             int lane, float& smin, float& smax) {
   constexpr int PROW = F2Lds<PPL>::PROW;
   const int V = p.V, blank = p.blank;
-  float* grads = p.grads + (size_t)b * p.T * V;
+  const int rows = FULL ? kHalf : min(kHalf, n - h * kHalf);      // live rows of this half (>= 1)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // prefix sums over the label-sorted cells, totals, s_t = sum_j alpha_t[j]*beta_t[j]
-#pragma unroll 4
-  for (int k = 0; k < kHalf; k++) {
-    const int tt = h * kHalf + k;
-    if (tt < n) {
-      float c[PPL];
+  auto scan_row = [&](int k, float& st, float& bl_total) {
+    float c[PPL];
 #pragma unroll
-      for (int r = 0; r < PPL; r++) c[r] = lds.Ps[k * PROW + PPL * lane + r];
-      const float bl = lds.Ps[k * PROW + 64 * PPL + lane];
+    for (int r = 0; r < PPL; r++) c[r] = lds.Ps[k * PROW + PPL * lane + r];
+    const float bl = lds.Ps[k * PROW + 64 * PPL + lane];
 #pragma unroll
-      for (int r = 1; r < PPL; r++) c[r] += c[r - 1];
-      const float incl = wave_scan(c[PPL - 1]);
-      const float excl = incl - c[PPL - 1];
+    for (int r = 1; r < PPL; r++) c[r] += c[r - 1];
+    const float incl = wave_scan(c[PPL - 1]);
+    const float excl = incl - c[PPL - 1];
 #pragma unroll
-      for (int r = 0; r < PPL; r++) lds.Ps[k * PROW + PPL * lane + r] = c[r] + excl;
-      const float lab_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
-      const float bl_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan(bl)), 63));
-      const float st = lab_total + bl_total;
-      smin = fminf(smin, st); smax = fmaxf(smax, st);
-      if (lane == 0) { lds.invs[k] = __builtin_amdgcn_rcpf(st); lds.btot[k] = bl_total; }
+    for (int r = 0; r < PPL; r++) lds.Ps[k * PROW + PPL * lane + r] = c[r] + excl;
+    const float lab_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+    bl_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan(bl)), 63));
+    st = lab_total + bl_total;
+    smin = fminf(smin, st); smax = fmaxf(smax, st);
+  };
+  if (FULL) {
+    // straight-line code for the 8 rows (their dependent scan chains interleave); the per-row results are
+    // written by lane k afterwards instead of by lane 0 inside eight conditional blocks
+    float my_st = 1.f, my_bt = 0.f;
+#pragma unroll
+    for (int k = 0; k < kHalf; k++) {
+      float st, bt;
+      scan_row(k, st, bt);
+      my_st = lane == k ? st : my_st;
+      my_bt = lane == k ? bt : my_bt;
+    }
+    if (lane < kHalf) { lds.invs[lane] = __builtin_amdgcn_rcpf(my_st); lds.btot[lane] = my_bt; }
+  } else {
+    for (int k = 0; k < rows; k++) {
+      float st, bt;
+      scan_row(k, st, bt);
+      if (lane == 0) { lds.invs[k] = __builtin_amdgcn_rcpf(st); lds.btot[k] = bt; }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // gradient rows: y - posterior (d loss/d logits in fused mode; exp(lp) - posterior otherwise)
-  for (int v = lane; v < V; v += 64) {
-    const int lo = lds.starts[v], hi = lds.starts[v + 1];     // label v owns the sorted slots [lo, hi)
-#pragma unroll
-    for (int k = 0; k < kHalf; k++) {
-      const int tt = h * kHalf + k;
-      if (tt < n) {
-        const float* pre = lds.Ps + k * PROW;
-        float pv = (hi > lo) ? pre[hi - 1] - (lo > 0 ? pre[lo - 1] : 0.f) : 0.f;
-        if (v == blank) pv += lds.btot[k];
-        grads[(size_t)(t0 + tt) * V + v] = lds.ys[v * kYs + tt] - pv * lds.invs[k];
-      }
-    }
+  F2_STAMP(5)
+  if (p.dbg == 4) return;
+  // gradient rows: y - posterior (d loss/d logits in fused mode; exp(lp) - posterior otherwise).  The live rows of
+  // this half are rows*V consecutive floats of the output: one lane per element, fully coalesced stores.
+  float* grads = p.grads + ((size_t)b * p.T + t0 + h * kHalf) * V;
+  const unsigned magic = (1u << 20) / (unsigned)V + 1u;                    // o / V for o < 2^20 / V
+  const int count = rows * V;
+  // branch-free: every lane reads from clamped addresses and only the store is predicated, so that the LDS reads of
+  // a pass (and of neighbouring passes) are in flight together instead of one round trip per conditional read
+#pragma unroll 4
+  for (int ob = 0; ob < count; ob += 64) {
+    const int o = min(ob + lane, count - 1);
+    const int k = (int)(((unsigned)o * magic) >> 20), v = o - k * V;
+    const int lo = lds.starts[v], hi = lds.starts[v + 1];       // label v owns the sorted slots [lo, hi)
+    const float* pre = lds.Ps + k * PROW;
+    const float a1 = pre[max(hi - 1, 0)], a0 = pre[max(lo - 1, 0)];
+    const float bt = lds.btot[k], iv = lds.invs[k], yv = lds.ys[v * kYs + h * kHalf + k];
+    float pv = hi > lo ? a1 - (lo > 0 ? a0 : 0.f) : 0.f;
+    pv += v == blank ? bt : 0.f;
+    if (ob + lane < count) grads[ob + lane] = yv - pv * iv;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ps / invs are rewritten by the next half
 }
@@ -737,6 +769,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
     fA = lane > 0 ? ldexpf(1.f, max(min(ep - eA, 126), -126)) : 0.f;
     fB = lane < 63 ? ldexpf(1.f, max(min(eA - en, 126), -126)) : 0.f;
   }
+  F2_STAMP(1)
   // this lane's label rows (and the blank row) in the transposed tile: one 16-byte read fetches 4 time steps
   typedef float f4 __attribute__((ext_vector_type(4)));
   const f4* ylab[PPL];
@@ -780,6 +813,8 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
     for (int k = 0; k < NC; k++) A[tt][k] = a[k];
   }
 
+  F2_STAMP(2)
+  if (p.dbg == 2) return;
   // ---- beta backwards through the segment, posteriors, per-label accumulation ----
   // beta rows live in the reciprocal units of the alpha lanes (lane n: 2^(emax - eA_n)), so that alpha*beta is
   // in one common unit across the wave; the hand-over factor from lane n+1 is then 2^(eA_n - eA_{n+1}) <= 2^kSlope
@@ -802,6 +837,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
     const int eA_ref = __shfl(eA, (L - 1) / NC, 64);          // lane holding cell L-1
     end_unit = ldexpf(1.f, max(min(eA - eA_ref, 126), -126));
   }
+  F2_STAMP(3)
 #pragma unroll
   for (int h = kSeg / kHalf - 1; h >= 0; h--) {
     if (!FULL && h * kHalf >= n) continue;
@@ -856,7 +892,9 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
         }
       }
     }
-    finish_rows<PPL>(p, b, t0, n, h, lds, lane, smin, smax);
+    F2_STAMP(4)
+    if (p.dbg != 3) finish_rows<PPL, FULL>(p, b, t0, n, h, lds, lane, smin, smax);
+    F2_STAMP(6)
   }
 }
 
@@ -869,6 +907,7 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   float* grads = p.grads + (size_t)b * Tmax * V;
   const float* x = p.x + (int64_t)b * p.sB;
 
+  F2_STAMP(-1)
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
   const int T = (int)Tq, S = (int)Sq;
@@ -926,10 +965,13 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
+    F2_STAMP(0)
+    if (p.dbg == 1) return;
     const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
     if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, lds, lane, smin, smax);
     else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, lds, lane, smin, smax);
   }
+  F2_FLUSH
   // range check: everything that carries posterior mass was representable (see the header comment)
   if (seg_first * kSeg < T) {
     const bool finite_ok = smax < __builtin_huge_valf();
@@ -965,6 +1007,7 @@ int ppl_for(int Smax) {
 struct FastLayout {
   size_t ytab, ckA, ckQ, ckE, escA, escB, logz, flags, cinfo, lstart, total;
   int NS, NB, CELLS;
+  int dbg;         // diagnostics only: stop F2 early (timing experiments)
 };
 
 FastLayout fast_layout(int B, int T, int V, int Smax) {
@@ -1020,6 +1063,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.logz = reinterpret_cast<double*>(ws + l.logz); p.flags = reinterpret_cast<int*>(ws + l.flags);
   p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart);
   p.NS = l.NS; p.NB = l.NB; p.CELLS = l.CELLS;
+  { static const int dbg = getenv("E2E_F2_DBG") ? atoi(getenv("E2E_F2_DBG")) : 0; p.dbg = dbg; }
   E2E_HIP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)a.B * sizeof(int), a.stream), "hipMemsetAsync(flags)");
   int rc;
   switch (ppl_for(a.Smax)) {
@@ -1038,6 +1082,12 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
 }  // namespace e2e
 
 #ifdef E2E_FAST_PROFILE
+extern "C" int e2e_debug_fast_profile2(unsigned long long* host, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
+  if (reset) { void* ptr; if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(e2e::g_prof2)) != hipSuccess) return E2E_ERR_HIP;
+    return hipMemset(ptr, 0, sizeof(unsigned long long) * 16384 * 8) == hipSuccess ? 0 : E2E_ERR_HIP; }
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(e2e::g_prof2), sizeof(unsigned long long) * 16384 * 8) == hipSuccess ? 0 : E2E_ERR_HIP;
+}
 extern "C" int e2e_debug_fast_profile(unsigned long long* host, int n) {
   if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(e2e::g_prof), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : E2E_ERR_HIP;
