@@ -22,7 +22,6 @@
 //     targets that contain the blank id.
 //
 // Reference semantics restated: src/losses/ctc_loss.cpp:33-117 (recurrences, loss, gradient).
-#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -56,7 +55,6 @@ struct FastParams {
   unsigned* cinfo; // [B][CELLS/2]  per label pair: label | sorted slot << 8 | alpha skip << 16 | beta skip << 17
   int* lstart;     // [B][130]  first label-sorted slot of every label (V+1 entries used)
   int NS, NB, CELLS;
-  int dbg;         // diagnostics only: stop F2 early (timing experiments)
 };
 
 // ---- cross-lane helpers (wave64) ------------------------------------------------------------
@@ -170,10 +168,16 @@ __device__ __forceinline__ void spin_until(volatile int* p, int want) {
   while (*q != want) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
 }
+__device__ __forceinline__ void spin_until_ge(volatile int* p, int want) {
+  volatile lds_int* q = (volatile lds_int*)p;
+  while (*q < want) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ void publish(volatile int* p, int v) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("" ::: "memory");          // (compiler ordering only: the LDS itself runs a wave's operations in order)
   *(volatile lds_int*)p = v;
 }
+__device__ __forceinline__ int peek(volatile int* p) { return *(volatile lds_int*)p; }
 
 // per-lane lattice description shared by F1 and F2: lane holds pairs i = PPL*lane + r
 template <int PPL>
@@ -237,17 +241,20 @@ struct LaneCells {
 // width), so the per-lane gather is arranged to pull 4 consecutive time steps of the lane's label per instruction:
 // 2 reads per label cell and block instead of 8, and the producers need no gather at all.
 struct F1Lds {
-  float* ring;       // [2][kRingBlks][V+1][kBlk]
-  int* flags;        // filled[2][kRingBlks], freed[2][kRingBlks]
+  float* ring;       // [2][kRingBlks][V+1][kRow]
+  int* filled;       // [2][kRingBlks]   probability block n of a direction is complete (== n+1)
+  int* took;         // [2]              the direction's chain has read the probabilities of blocks < took
   int* sortcnt;      // [130] counting-sort scratch of the cell-info wave
   int blk_floats;
+  static constexpr int kSyncInts = 2 * kRingBlks + 2;
   __device__ F1Lds(unsigned char* smem, int V) {
     blk_floats = (V + 1) * kRow;
     ring = reinterpret_cast<float*>(smem);
-    flags = reinterpret_cast<int*>(ring + 2 * kRingBlks * blk_floats);
-    sortcnt = flags + 4 * kRingBlks;
+    filled = reinterpret_cast<int*>(ring + 2 * kRingBlks * blk_floats);
+    took = filled + 2 * kRingBlks;
+    sortcnt = took + 2;
   }
-  static size_t bytes(int V) { return sizeof(float) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * (4 * kRingBlks + 130); }
+  static size_t bytes(int V) { return sizeof(float) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * (kSyncInts + 130); }
 };
 
 // Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
@@ -277,8 +284,8 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
   const int V = p.V;
   const int nblk = (T + kBlk - 1) / kBlk;
   float* myring = lds.ring + (size_t)dir * kRingBlks * lds.blk_floats;
-  volatile int* myfilled = lds.flags + dir * kRingBlks;
-  volatile int* myfreed = lds.flags + 2 * kRingBlks + dir * kRingBlks;
+  volatile int* myfilled = lds.filled + dir * kRingBlks;
+  volatile int* took = lds.took + dir;
   const float* x = p.x + (int64_t)b * p.sB;
   float* ytab = p.ytab + (size_t)b * p.T * V;
   const int q = lane >> 4, l16 = lane & 15;
@@ -308,7 +315,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     float xn[NP][NV];
     load_block(n + stride, xn);
     const int slot = n % kRingBlks;
-    if (n >= kRingBlks) { PROF_SPIN_BEGIN spin_until(&myfreed[slot], n - kRingBlks + 1); PROF_SPIN_END(prof_spin) }
+    if (n >= kRingBlks) { PROF_SPIN_BEGIN spin_until_ge(took, n - kRingBlks + 1); PROF_SPIN_END(prof_spin) }
     float* blk = myring + (size_t)slot * lds.blk_floats;
 #pragma unroll
     for (int pass = 0; pass < NP; pass++) {
@@ -354,17 +361,23 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 }
 
 // One serial chain (DIR 0: alpha forward, DIR 1: beta-with-emission backward).
+//
+// A lone wave issues at most one instruction every ~4.5 cycles whatever its kind, so the chain's speed is its
+// instruction count; LDS and flag latencies must not add to it.  Hence: (a) the hand-over words are polled one
+// block ahead and looked at late; (b) the block's probabilities sit in ONE register set that is refilled in halves
+// while the other half is in use (steps 4..7 of block n at the start of block n, steps 0..3 of block n+1 at step 4
+// of block n), every read being issued four steps before its first use; (c) the steady blocks have a loop of their
+// own, one straight-line body without liveness tests.
 template <int PPL, int DIR>
 __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, int S, const F1Lds& lds, int lane) {
   constexpr int NC = 2 * PPL;
   const int V = p.V, blank = p.blank, L = 2 * S + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
   const float* myring = lds.ring + (size_t)DIR * kRingBlks * lds.blk_floats;
-  volatile int* myfilled = lds.flags + DIR * kRingBlks;
-  volatile int* myfreed = lds.flags + 2 * kRingBlks + DIR * kRingBlks;
+  volatile int* myfilled = lds.filled + DIR * kRingBlks;
   __builtin_amdgcn_s_setprio(3);
-  unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime(), prof_load = 0, prof_steps = 0;
-  (void)prof_spin; (void)prof_t0; (void)prof_load; (void)prof_steps;
+  unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime(), prof_steps = 0;
+  (void)prof_spin; (void)prof_t0; (void)prof_steps;
   LaneCells<PPL> lc;
   lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, blank, lane);
   const double rr = (double)lc.r;
@@ -382,48 +395,45 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
   float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
   short* esc = (DIR == 0 ? p.escA : p.escB) + (size_t)b * p.NB;
 
+  // the probabilities of a block: per label cell (and for the blank) two wide reads of 4 steps each
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 eraw[PPL][2], braw[2];
+  auto load_half = [&](int n, auto half_tag) {
+    constexpr int H = decltype(half_tag)::value;
+    const float* blk = myring + (size_t)(n % kRingBlks) * lds.blk_floats;
+#pragma unroll
+    for (int r = 0; r < PPL; r++) eraw[r][H] = reinterpret_cast<const f4*>(blk + lc.lab[r] * kRow)[H];
+    braw[H] = reinterpret_cast<const f4*>(blk + blank * kRow)[H];
+  };
+
   // One block of 8 steps.  STEADY: all 8 rows are live and none is the chain's first row -- no per-step tests.
   auto run_block = [&](int n, auto steady_tag) {
     constexpr bool STEADY = decltype(steady_tag)::value;
-    const int slot = n % kRingBlks;
-    { PROF_SPIN_BEGIN spin_until(&myfilled[slot], n + 1); PROF_SPIN_END(prof_spin) }
-    // all of the block's probabilities up front: per label cell (and for the blank) two wide reads fetch the 8 steps
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const float* blk = myring + (size_t)slot * lds.blk_floats;
-    f4 eraw[PPL][2], braw[2];
-#pragma unroll
-    for (int r = 0; r < PPL; r++) {
-      const f4* src = reinterpret_cast<const f4*>(blk + lc.lab[r] * kRow);
-      eraw[r][0] = src[0]; eraw[r][1] = src[1];
-    }
-    {
-      const f4* src = reinterpret_cast<const f4*>(blk + blank * kRow);
-      braw[0] = src[0]; braw[1] = src[1];
-    }
+    load_half(n, std::integral_constant<int, 1>{});
+    // the LDS runs this wave's operations in order, so the producers' next writes cannot overtake the reads above
+    publish(lds.took + DIR, n + 1);
+    const bool want_next = n + 1 < nblk;
+    int next_filled = 0;
+    if (want_next) next_filled = peek(&myfilled[(n + 1) % kRingBlks]);
     double yb[kBlk], e[kBlk][PPL];
-#pragma unroll
-    for (int tt = 0; tt < kBlk; tt++) {
-      yb[tt] = (double)braw[tt >> 2][tt & 3];
-#pragma unroll
-      for (int r = 0; r < PPL; r++) e[tt][r] = (double)eraw[r][tt >> 2][tt & 3];
-    }
-#ifdef E2E_FAST_PROFILE
-    unsigned long long ts0, ts1;
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts0) :: "memory");   // spin done, loads issued
-    {
-      // force the loads to have landed before the second stamp
-      float sink = braw[0][0] + braw[1][3];
-#pragma unroll
-      for (int r = 0; r < PPL; r++) sink += eraw[r][0][0] + eraw[r][1][3];
-      asm volatile("" :: "v"(sink));
-    }
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts1) :: "memory");
-    prof_load += ts1 - ts0;
-#endif
     const int tbase = block_time(DIR, n, 0, T);          // t of tt = 0; t = tbase +/- tt
+#ifdef E2E_FAST_PROFILE
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int tt = 0; tt < kBlk; tt++) {
       const int t = DIR == 0 ? tbase + tt : tbase - tt;
+      yb[tt] = (double)braw[tt >> 2][tt & 3];
+#pragma unroll
+      for (int r = 0; r < PPL; r++) e[tt][r] = (double)eraw[r][tt >> 2][tt & 3];
+      if (tt == 4) {
+        // the halves for steps 0..3 are dead by now.  The producers normally run several blocks ahead; if not, the
+        // wave waits here.  (Behind the last block the read fetches a stale slot that nobody uses.)
+        if (want_next && __builtin_amdgcn_readfirstlane(next_filled) != n + 2) {
+          PROF_SPIN_BEGIN spin_until(&myfilled[(n + 1) % kRingBlks], n + 2); PROF_SPIN_END(prof_spin)
+        }
+        load_half(n + 1, std::integral_constant<int, 0>{});
+      }
       if (STEADY || t < T) {
         const bool first = !STEADY && (DIR == 0 ? t == 0 : t == T - 1);
         if (DIR == 0) {
@@ -488,30 +498,25 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
 #pragma unroll
           for (int k = 0; k < NC; k++) hi = max(hi, __double2hiint(c[k]));   // positive doubles order like ints
           hi = wave_max(hi);
-          hi = __builtin_amdgcn_readfirstlane(hi);
           e_pending = hi > 0 ? ((hi >> 20) & 0x7ff) - 1023 : 0;
           if (e_pending < -1000) e_pending = -1000;
         }
       }
     }
 #ifdef E2E_FAST_PROFILE
-    {
-      double sink = 0.0;
-#pragma unroll
-      for (int k = 0; k < NC; k++) sink += c[k];
-      asm volatile("" :: "v"(sink));
-      unsigned long long ts2;
-      asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts2) :: "memory");
-      prof_steps += ts2 - ts1;
-    }
+    prof_steps += __builtin_amdgcn_s_memtime() - ts0;
 #endif
-    publish(&myfreed[slot], n + 1);
   };
-  for (int n = 0; n < nblk; n++) {
-    // alpha: block 0 holds the first row, the last block may be short; beta: block 0 holds the first row
-    // (and possibly dead rows), every later block is whole
-    const bool steady = DIR == 0 ? (n > 0 && (n + 1) * kBlk <= T) : (n > 0);
-    if (steady) run_block(n, std::true_type{}); else run_block(n, std::false_type{});
+  // alpha: block 0 holds the first row, the last block may be short; beta: block 0 holds the first row (and
+  // possibly dead rows), every later block is whole
+  {
+    { PROF_SPIN_BEGIN spin_until(&myfilled[0], 1); PROF_SPIN_END(prof_spin) }
+    load_half(0, std::integral_constant<int, 0>{});
+    const int steady_end = DIR == 0 ? T / kBlk : nblk;         // blocks [1, steady_end) are steady
+    run_block(0, std::false_type{});
+    int n = 1;
+    for (; n < steady_end; n++) run_block(n, std::true_type{});
+    for (; n < nblk; n++) run_block(n, std::false_type{});
   }
 
   // ---- log Z from this side ----
@@ -528,7 +533,7 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
   }
 #ifdef E2E_FAST_PROFILE
   if (lane == 0 && b < 256) { g_prof[(b * 4 + DIR) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + DIR) * 4 + 1] = prof_spin;
-    g_prof[(b * 4 + DIR) * 4 + 2] = prof_load; g_prof[(b * 4 + DIR) * 4 + 3] = prof_steps; }
+    g_prof[(b * 4 + DIR) * 4 + 2] = 0; g_prof[(b * 4 + DIR) * 4 + 3] = prof_steps; }
 #endif
   for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
   if (lane == 0) {
@@ -587,6 +592,8 @@ __device__ __forceinline__ void cellinfo_wave(const FastParams& p, int b, int T,
 // Waves of a workgroup land on the SIMDs in the order 0,2,1,3,0,2,1,3: waves 0/1 (the chains) get SIMDs 0 and 2 to
 // themselves, waves 2,6 (alpha rows) share SIMD 1, waves 3,7 (beta rows) share SIMD 3; wave 4 writes the lattice
 // description for F2 and retires, wave 5 retires at once.
+// (Splitting a chain's lanes over two pipelined waves was tried and does not pay: the per-block bookkeeping does not
+// shrink with the cells, and a lone wave's speed is its instruction count.)
 template <int PPL>
 __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
     return;
   }
   const int T = (int)Tq, S = (int)Sq;
-  if (tid < 2 * 2 * kRingBlks) lds.flags[tid] = 0;
+  if (tid < F1Lds::kSyncInts) lds.filled[tid] = 0;
   for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
     lds.ring[(size_t)(i / kBlk) * lds.blk_floats + V * kRow + (i % kBlk)] = 0.f;
   __syncthreads();
@@ -694,7 +701,6 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   F2_STAMP(5)
-  if (p.dbg == 4) return;
   // gradient rows: y - posterior (d loss/d logits in fused mode; exp(lp) - posterior otherwise).  The live rows of
   // this half are rows*V consecutive floats of the output: one lane per element, fully coalesced stores.
   float* grads = p.grads + ((size_t)b * p.T + t0 + h * kHalf) * V;
@@ -814,7 +820,6 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
   }
 
   F2_STAMP(2)
-  if (p.dbg == 2) return;
   // ---- beta backwards through the segment, posteriors, per-label accumulation ----
   // beta rows live in the reciprocal units of the alpha lanes (lane n: 2^(emax - eA_n)), so that alpha*beta is
   // in one common unit across the wave; the hand-over factor from lane n+1 is then 2^(eA_n - eA_{n+1}) <= 2^kSlope
@@ -893,7 +898,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
       }
     }
     F2_STAMP(4)
-    if (p.dbg != 3) finish_rows<PPL, FULL>(p, b, t0, n, h, lds, lane, smin, smax);
+    finish_rows<PPL, FULL>(p, b, t0, n, h, lds, lane, smin, smax);
     F2_STAMP(6)
   }
 }
@@ -902,7 +907,7 @@ template <int PPL>
 __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.y, lane = threadIdx.x;
-  const int V = p.V, blank = p.blank, Tmax = p.T;
+  const int V = p.V, Tmax = p.T;
   const F2Lds<PPL> lds(smem, V);
   float* grads = p.grads + (size_t)b * Tmax * V;
   const float* x = p.x + (int64_t)b * p.sB;
@@ -966,7 +971,6 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
     F2_STAMP(0)
-    if (p.dbg == 1) return;
     const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
     if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, lds, lane, smin, smax);
     else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, lds, lane, smin, smax);
@@ -1007,7 +1011,6 @@ int ppl_for(int Smax) {
 struct FastLayout {
   size_t ytab, ckA, ckQ, ckE, escA, escB, logz, flags, cinfo, lstart, total;
   int NS, NB, CELLS;
-  int dbg;         // diagnostics only: stop F2 early (timing experiments)
 };
 
 FastLayout fast_layout(int B, int T, int V, int Smax) {
@@ -1063,7 +1066,6 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.logz = reinterpret_cast<double*>(ws + l.logz); p.flags = reinterpret_cast<int*>(ws + l.flags);
   p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart);
   p.NS = l.NS; p.NB = l.NB; p.CELLS = l.CELLS;
-  { static const int dbg = getenv("E2E_F2_DBG") ? atoi(getenv("E2E_F2_DBG")) : 0; p.dbg = dbg; }
   E2E_HIP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)a.B * sizeof(int), a.stream), "hipMemsetAsync(flags)");
   int rc;
   switch (ppl_for(a.Smax)) {

@@ -80,6 +80,7 @@ __global__ void bench(unsigned long long* out, double* sink, int zero) {
   r[11] = timed([&] { for (int i = 0; i < N_ITER; i++) {
 #pragma unroll
     for (int k = 0; k < 8; k++) fa[0] += __shfl_xor(fa[0], 16, 64); } });
+  double keep = 0; for (int k = 0; k < 8; k++) keep += a[k];
   // 12: 8 x v_cvt_f64_f32 (independent)
   r[12] = timed([&] { for (int i = 0; i < N_ITER; i++) {
 #pragma unroll
@@ -94,7 +95,7 @@ __global__ void bench(unsigned long long* out, double* sink, int zero) {
 #pragma unroll
     for (int k = 0; k < 8; k++) ia[k] = __builtin_amdgcn_update_dpp(0, ia[k], 0x138, 0xf, 0xf, true); } });
   for (int k = 0; k < 8; k++) fa[k] += ia[k];
-  double s = 0; for (int k = 0; k < 8; k++) s += a[k] + fa[k] + pa[k].x + pa[k].y;
+  double s = keep; for (int k = 0; k < 8; k++) s += a[k] + fa[k] + pa[k].x + pa[k].y;
   sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0) for (int k = 0; k < 15; k++) out[blockIdx.x * 16 + k] = r[k];
 }
