@@ -35,7 +35,7 @@ namespace {
 constexpr int kSeg = 16;        // steps per F2 segment == checkpoint spacing
 constexpr int kBlk = 8;         // prep -> chain hand-off block and rescale period
 constexpr int kRingBlks = 8;    // ring depth (blocks)
-constexpr int kRow = 12;        // floats per label row of a ring block: 8 steps + pad (48 B: labels 16 apart share banks, not 8 apart)
+constexpr int kRow = 10;        // doubles per label row of a ring block: 8 steps + pad (80 B spreads the 16-byte gathers over the banks)
 constexpr int kMaxSmallV = 96;  // alphabet columns the lattice kernels take (prep: <= 6 columns per lane)
 
 struct FastParams {
@@ -120,6 +120,17 @@ __device__ __forceinline__ int wave_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
+// inclusive prefix maximum over the 64 lanes, all DPP (lanes without a source keep their own value)
+__device__ __forceinline__ int wave_scan_max(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31
   return v;
 }
 
@@ -241,20 +252,20 @@ struct LaneCells {
 // width), so the per-lane gather is arranged to pull 4 consecutive time steps of the lane's label per instruction:
 // 2 reads per label cell and block instead of 8, and the producers need no gather at all.
 struct F1Lds {
-  float* ring;       // [2][kRingBlks][V+1][kRow]
+  double* ring;      // [2][kRingBlks][V+1][kRow]  (f64: the chains would otherwise spend 15% of their issue slots converting)
   int* filled;       // [2][kRingBlks]   probability block n of a direction is complete (== n+1)
   int* took;         // [2]              the direction's chain has read the probabilities of blocks < took
   int* sortcnt;      // [130] counting-sort scratch of the cell-info wave
-  int blk_floats;
+  int blk_elems;
   static constexpr int kSyncInts = 2 * kRingBlks + 2;
   __device__ F1Lds(unsigned char* smem, int V) {
-    blk_floats = (V + 1) * kRow;
-    ring = reinterpret_cast<float*>(smem);
-    filled = reinterpret_cast<int*>(ring + 2 * kRingBlks * blk_floats);
+    blk_elems = (V + 1) * kRow;
+    ring = reinterpret_cast<double*>(smem);
+    filled = reinterpret_cast<int*>(ring + 2 * kRingBlks * blk_elems);
     took = filled + 2 * kRingBlks;
     sortcnt = took + 2;
   }
-  static size_t bytes(int V) { return sizeof(float) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * (kSyncInts + 130); }
+  static size_t bytes(int V) { return sizeof(double) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * (kSyncInts + 130); }
 };
 
 // Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
@@ -283,7 +294,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
                                           const F1Lds& lds, int lane) {
   const int V = p.V;
   const int nblk = (T + kBlk - 1) / kBlk;
-  float* myring = lds.ring + (size_t)dir * kRingBlks * lds.blk_floats;
+  double* myring = lds.ring + (size_t)dir * kRingBlks * lds.blk_elems;
   volatile int* myfilled = lds.filled + dir * kRingBlks;
   volatile int* took = lds.took + dir;
   const float* x = p.x + (int64_t)b * p.sB;
@@ -316,7 +327,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     load_block(n + stride, xn);
     const int slot = n % kRingBlks;
     if (n >= kRingBlks) { PROF_SPIN_BEGIN spin_until_ge(took, n - kRingBlks + 1); PROF_SPIN_END(prof_spin) }
-    float* blk = myring + (size_t)slot * lds.blk_floats;
+    double* blk = myring + (size_t)slot * lds.blk_elems;
 #pragma unroll
     for (int pass = 0; pass < NP; pass++) {
       const int tt = pass * 4 + q;
@@ -344,7 +355,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 #pragma unroll
       for (int k = 0; k < NV; k++) {
         if (col_live[k]) {
-          blk[(l16 + 16 * k) * kRow + tt] = row_live ? y[k] : 0.f;        // transposed: [label][step]
+          blk[(l16 + 16 * k) * kRow + tt] = row_live ? (double)y[k] : 0.0;   // transposed: [label][step]
           if (dir == 0 && row_live) yrow[l16 + 16 * k] = y[k];
         }
       }
@@ -373,7 +384,7 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
   constexpr int NC = 2 * PPL;
   const int V = p.V, blank = p.blank, L = 2 * S + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
-  const float* myring = lds.ring + (size_t)DIR * kRingBlks * lds.blk_floats;
+  const double* myring = lds.ring + (size_t)DIR * kRingBlks * lds.blk_elems;
   volatile int* myfilled = lds.filled + DIR * kRingBlks;
   __builtin_amdgcn_s_setprio(3);
   unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime(), prof_steps = 0;
@@ -395,15 +406,19 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
   float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
   short* esc = (DIR == 0 ? p.escA : p.escB) + (size_t)b * p.NB;
 
-  // the probabilities of a block: per label cell (and for the blank) two wide reads of 4 steps each
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  f4 eraw[PPL][2], braw[2];
+  // the probabilities of a block: per label cell (and for the blank) four wide reads of 2 steps each
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 eraw[PPL][4], braw[4];
   auto load_half = [&](int n, auto half_tag) {
     constexpr int H = decltype(half_tag)::value;
-    const float* blk = myring + (size_t)(n % kRingBlks) * lds.blk_floats;
+    const double* blk = myring + (size_t)(n % kRingBlks) * lds.blk_elems;
 #pragma unroll
-    for (int r = 0; r < PPL; r++) eraw[r][H] = reinterpret_cast<const f4*>(blk + lc.lab[r] * kRow)[H];
-    braw[H] = reinterpret_cast<const f4*>(blk + blank * kRow)[H];
+    for (int r = 0; r < PPL; r++) {
+      const d2* src = reinterpret_cast<const d2*>(blk + lc.lab[r] * kRow);
+      eraw[r][2 * H] = src[2 * H]; eraw[r][2 * H + 1] = src[2 * H + 1];
+    }
+    const d2* srcb = reinterpret_cast<const d2*>(blk + blank * kRow);
+    braw[2 * H] = srcb[2 * H]; braw[2 * H + 1] = srcb[2 * H + 1];
   };
 
   // One block of 8 steps.  STEADY: all 8 rows are live and none is the chain's first row -- no per-step tests.
@@ -423,9 +438,9 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
 #pragma unroll
     for (int tt = 0; tt < kBlk; tt++) {
       const int t = DIR == 0 ? tbase + tt : tbase - tt;
-      yb[tt] = (double)braw[tt >> 2][tt & 3];
+      yb[tt] = braw[tt >> 1][tt & 1];
 #pragma unroll
-      for (int r = 0; r < PPL; r++) e[tt][r] = (double)eraw[r][tt >> 2][tt & 3];
+      for (int r = 0; r < PPL; r++) e[tt][r] = eraw[r][tt >> 1][tt & 1];
       if (tt == 4) {
         // the halves for steps 0..3 are dead by now.  The producers normally run several blocks ahead; if not, the
         // wave waits here.  (Behind the last block the read fetches a stale slot that nobody uses.)
@@ -610,7 +625,7 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   const int T = (int)Tq, S = (int)Sq;
   if (tid < F1Lds::kSyncInts) lds.filled[tid] = 0;
   for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
-    lds.ring[(size_t)(i / kBlk) * lds.blk_floats + V * kRow + (i % kBlk)] = 0.f;
+    lds.ring[(size_t)(i / kBlk) * lds.blk_elems + V * kRow + (i % kBlk)] = 0.0;
   __syncthreads();
 
   const int wave = __builtin_amdgcn_readfirstlane(wid);
@@ -630,9 +645,8 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
 }
 
 // ============================================================================================
-// F2: one wave per (utterance, group of kSegPerWave consecutive 16-step segments)
+// F2: one wave per (utterance, 16-step segment)
 // ============================================================================================
-constexpr int kSegPerWave = 1;     // segments handled back to back by one wave (labels / label order set up once)
 constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before they are summed and written out
 constexpr int kYs = kSeg + 4;      // row stride (floats) of the transposed probability tile: 80 B spreads the
                                    // 16-byte gathers of different labels over the LDS bank row
@@ -723,10 +737,36 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ps / invs are rewritten by the next half
 }
 
+// what a segment needs from F1's workspace besides the probabilities; requested before the tile is staged so that
+// the two round trips overlap
+template <int PPL>
+struct SegIn {
+  float a[2 * PPL];                 // alpha checkpoint row (this lane's cells), segment > 0
+  int ownA;                         // its per-lane exponent
+  int eA7, eA15, eB0, eB8;          // rescale exponents inside the segment
+  __device__ void load(const FastParams& p, int b, int seg, int lane) {
+    const int t0 = seg * kSeg;
+    const short* escA = p.escA + (size_t)b * p.NB;
+    const short* escB = p.escB + (size_t)b * p.NB;
+    eA7 = escA[(t0 >> 3)]; eA15 = escA[(t0 >> 3) + 1];
+    eB0 = escB[(t0 >> 3)]; eB8 = escB[(t0 >> 3) + 1];
+    ownA = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * PPL; k++) a[k] = 0.f;
+    if (seg > 0) {
+      const float* src = p.ckA + ((size_t)b * p.NS + seg) * p.CELLS + lane * 2 * PPL;
+#pragma unroll
+      for (int k = 0; k < 2 * PPL; k++) a[k] = src[k];
+      ownA = p.ckE[(((size_t)b * p.NS + seg) * 2 + 0) * 64 + lane];
+    }
+  }
+};
+
 // FULL: an interior segment (16 live steps, neither t = 0 nor t = T-1 inside): no guards in the loops.
 template <int PPL, bool FULL>
 __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg, int T, int S, int n,
                                              const LaneCells<PPL>& lc, const int (&rank)[PPL],
+                                             const SegIn<PPL>& in,
                                              const F2Lds<PPL>& lds, int lane, float& smin, float& smax) {
   constexpr int NC = 2 * PPL;
   constexpr int kSlope = 3 * NC;    // exponent drop allowed per lane (see the alpha load below)
@@ -736,11 +776,8 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
   float* Ps = lds.Ps;
   const float rr = lc.r;
   const bool cond = (T > 1 || L == 1);
-  // the four rescale exponents that fall inside this segment (alpha at t%8 == 7, beta at t%8 == 0), fetched early
-  const short* escA = p.escA + (size_t)b * p.NB;
-  const short* escB = p.escB + (size_t)b * p.NB;
-  const int eA7 = escA[(t0 >> 3)], eA15 = escA[(t0 >> 3) + 1];
-  const int eB0 = escB[(t0 >> 3)], eB8 = escB[(t0 >> 3) + 1];
+  // the four rescale exponents that fall inside this segment (alpha at t%8 == 7, beta at t%8 == 0)
+  const int eA7 = in.eA7, eA15 = in.eA15, eB0 = in.eB0, eB8 = in.eB8;
 
   // ---- alpha rows of the segment, kept in registers ----
   float A[kSeg][NC];
@@ -750,21 +787,16 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
 #pragma unroll
     for (int k = 0; k < NC; k++) a[k] = 0.f;
   } else {
-    const float* src = p.ckA + ((size_t)b * p.NS + seg) * p.CELLS + lane * NC;
 #pragma unroll
-    for (int k = 0; k < NC; k++) a[k] = src[k];
-    const int own = p.ckE[(((size_t)b * p.NS + seg) * 2 + 0) * 64 + lane];
+    for (int k = 0; k < NC; k++) a[k] = in.a[k];
+    const int own = in.ownA;
     // Mass flows from lane n-1 to lane n and can cross 2 cells per step, i.e. 32/NC lanes within the segment;
     // every lane crossed multiplies the stored value by the hand-over factor 2^(eA[n-1]-eA[n]).  Limiting the
     // exponent drop to 3 bits per cell (kSlope per lane) bounds the worst growth over a segment by 2^96.  A lane
     // whose own cells lie further below its left neighbour than that takes the neighbour's unit minus kSlope and
     // keeps its cells as small numbers (still exact down to 2^-126 of that unit).
-    eA = own;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int v = __shfl_up(eA, d, 64);
-      if (lane >= d) eA = max(eA, v - kSlope * d);
-    }
+    // (eA_n = max_{m <= n} (own_m - kSlope*(n - m)): a prefix maximum of own_m + kSlope*m)
+    eA = wave_scan_max(own + kSlope * lane) - kSlope * lane;
     const int sh = max(own - eA, -200);
 #pragma unroll
     for (int k = 0; k < NC; k++) a[k] = ldexpf(a[k], sh);
@@ -906,84 +938,94 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
 template <int PPL>
 __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int b = blockIdx.y, lane = threadIdx.x;
-  const int V = p.V, Tmax = p.T;
+  const int b = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
+  const int V = p.V, Tmax = p.T, t0 = seg * kSeg;
   const F2Lds<PPL> lds(smem, V);
-  float* grads = p.grads + (size_t)b * Tmax * V;
-  const float* x = p.x + (int64_t)b * p.sB;
-
+  typedef float f4 __attribute__((ext_vector_type(4)));
   F2_STAMP(-1)
-  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
-  if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
-  const int T = (int)Tq, S = (int)Sq;
-  const int seg_first = blockIdx.x * kSegPerWave;
-  if (seg_first * kSeg >= Tmax) return;
 
-  // the utterance's lattice description, left in the workspace by F1 (cellinfo_wave): independent loads, one round trip
-  LaneCells<PPL> lc;
-  int rank[PPL];
-  if (seg_first * kSeg < T) {
+  // Everything the wave needs from global memory is requested up front, BEFORE the utterance's lengths are known
+  // (no address depends on them; what a dead or flagged segment reads stays inside the workspace and is dropped):
+  // one memory round trip instead of three in a kernel whose waves live for only ~10 us.
+  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
+  // (a) the utterance's lattice description, left in the workspace by F1 (cellinfo_wave)
+  unsigned w[PPL];
+  {
     const unsigned* ci = p.cinfo + (size_t)b * (p.CELLS / 2) + PPL * lane;
-    unsigned w[PPL];
 #pragma unroll
     for (int r = 0; r < PPL; r++) w[r] = ci[r];
-    const int* ls = p.lstart + (size_t)b * 130;
-    const int s0 = ls[lane], s1 = ls[64 + lane];
-    lds.starts[lane] = s0; lds.starts[64 + lane] = s1; if (lane < 2) lds.starts[128 + lane] = ls[128 + lane];
-    lc.unpack(w, S, T, rank);
-    if (lane < kYs) lds.ys[V * kYs + lane] = 0.f;                           // the zero row V
   }
+  const int* ls = p.lstart + (size_t)b * 130;
+  const int s0 = ls[lane], s1 = ls[64 + lane], s2 = ls[128 + (lane & 1)];
+  // (b) the segment's 16 probability rows: 16*V consecutive floats of ytab, as 16-byte loads from the aligned
+  //     address below (<= 6 per lane for V <= 96)
+  constexpr int kTileLoads = (kSeg * kMaxSmallV + 3 + 255) / 256;
+  const size_t g0 = ((size_t)b * Tmax + t0) * V;
+  const size_t a0 = g0 & ~(size_t)3;
+  const int skew = (int)(g0 - a0);
+  f4 tile[kTileLoads];
+  {
+    const f4* src = reinterpret_cast<const f4*>(p.ytab + a0);
+#pragma unroll
+    for (int j = 0; j < kTileLoads; j++)
+      if (4 * 64 * j < kSeg * V + skew) tile[j] = src[64 * j + lane];       // (uniform test)
+  }
+  // (c) alpha checkpoint and the rescale exponents
+  SegIn<PPL> in;
+  in.load(p, b, seg, lane);
 
-  float smin = __builtin_huge_valf(), smax = 0.f;
-  for (int g = 0; g < kSegPerWave; g++) {
-    const int seg = seg_first + g, t0 = seg * kSeg;
-    if (t0 >= Tmax) break;
-    const int tend = min(t0 + kSeg, Tmax);
+  if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
+  const int T = (int)Tq, S = (int)Sq;
+  {
     // frames past the utterance's end: exp(lp) in log-prob mode (quirk Q1), zero for fused logits
+    float* grads = p.grads + (size_t)b * Tmax * V;
+    const float* x = p.x + (int64_t)b * p.sB;
+    const int tend = min(t0 + kSeg, Tmax);
     for (int t = max(t0, T); t < tend; t++)
       for (int v = lane; v < V; v += 64)
         grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : 0.f;
-    if (t0 >= T) continue;
-    const int n = min(t0 + kSeg, T) - t0;
-    // stage the segment's probability rows: they are n*V consecutive floats of ytab -> 16-byte loads from the
-    // aligned address below, scattered into the transposed tile
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (n < kSeg)
-      for (int i = lane; i < kYs * V; i += 64) lds.ys[i] = 0.f;            // dead steps of a short last segment
-    {
-      typedef float f4 __attribute__((ext_vector_type(4)));
-      const size_t g0 = ((size_t)b * Tmax + t0) * V;
-      const size_t a0 = g0 & ~(size_t)3;
-      const int skew = (int)(g0 - a0), count = n * V;
-      const unsigned magic = (1u << 20) / (unsigned)V + 1u;                // idx / V for idx < 2^20 / V
-      const f4* src = reinterpret_cast<const f4*>(p.ytab + a0);
-      for (int e = lane; 4 * e < count + skew; e += 64) {
-        const f4 v4 = src[e];
+  }
+  if (t0 >= T) return;
+  const int n = min(t0 + kSeg, T) - t0;
+
+  LaneCells<PPL> lc;
+  int rank[PPL];
+  lc.unpack(w, S, T, rank);
+  lds.starts[lane] = s0; lds.starts[64 + lane] = s1; if (lane < 2) lds.starts[128 + lane] = s2;
+  if (lane < kYs) lds.ys[V * kYs + lane] = 0.f;                           // the zero row V
+  if (n < kSeg)
+    for (int i = lane; i < kYs * V; i += 64) lds.ys[i] = 0.f;            // dead steps of a short last segment
+  {
+    // scatter the rows into the transposed tile
+    const int count = n * V;
+    const unsigned magic = (1u << 20) / (unsigned)V + 1u;                // idx / V for idx < 2^20 / V
+#pragma unroll
+    for (int j = 0; j < kTileLoads; j++) {
+      if (4 * 64 * j < kSeg * V + skew) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-          const int idx = 4 * e + c - skew;
+          const int idx = 4 * (64 * j + lane) + c - skew;
           if (idx >= 0 && idx < count) {
             const int tt = (int)(((unsigned)idx * magic) >> 20);
-            lds.ys[(idx - tt * V) * kYs + tt] = v4[c];
+            lds.ys[(idx - tt * V) * kYs + tt] = tile[j][c];
           }
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
-    F2_STAMP(0)
-    const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
-    if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, lds, lane, smin, smax);
-    else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, lds, lane, smin, smax);
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
+  F2_STAMP(0)
+  float smin = __builtin_huge_valf(), smax = 0.f;
+  const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
+  if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, in, lds, lane, smin, smax);
+  else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, in, lds, lane, smin, smax);
   F2_FLUSH
   // range check: everything that carries posterior mass was representable (see the header comment)
-  if (seg_first * kSeg < T) {
-    const bool finite_ok = smax < __builtin_huge_valf();
-    if (!(smin >= 0x1p-90f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
-    if (seg_first == 0 && lane == 0) {
-      const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
-      if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
-    }
+  const bool finite_ok = smax < __builtin_huge_valf();
+  if (!(smin >= 0x1p-90f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
+  if (seg == 0 && lane == 0) {
+    const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
+    if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
   }
 }
 
@@ -995,7 +1037,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds2 = F2Lds<PPL>::bytes(p.V);
   hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
-  hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3((p.NS + kSegPerWave - 1) / kSegPerWave, p.B), dim3(64), lds2, stream, p);
+  hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
   return E2E_OK;
 }
