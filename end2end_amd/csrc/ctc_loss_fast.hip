@@ -93,14 +93,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+// The two cross-row steps of a wave-wide DPP scan / reduction.  Written as fused DPP instructions by hand: lanes of
+// the rows that are masked off keep their value (dst is also the second source), which the update_dpp builtin can
+// only express with an extra zeroed register and a separate add.  (s_nop 1: VALU write -> DPP read hazard.)
+#define E2E_ROW_BCAST_STEPS(OP, v)                                                              \
+  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+               "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v))
+
 // maximum over the wave, all VALU (no ds_bpermute round trips); the result is wave-uniform
 __device__ __forceinline__ int wave_max(int v) {
   v = max(v, dpp_i<0xB1>(0, v));
   v = max(v, dpp_i<0x4E>(0, v));
   v = max(v, dpp_i<0x141>(0, v));
   v = max(v, dpp_i<0x140>(0, v));                                                   // every lane: its row's maximum
-  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));            // row_bcast:15 -> rows 1, 3
-  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));            // row_bcast:31 -> rows 2, 3
+  E2E_ROW_BCAST_STEPS("v_max_i32_dpp", v);                                          // lane 63: the wave's
   return __builtin_amdgcn_readlane(v, 63);
 }
 // inclusive prefix sum over the 64 lanes, all DPP
@@ -109,8 +115,7 @@ __device__ __forceinline__ float wave_scan(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));   // row_shr:2
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));   // row_shr:4
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));   // row_shr:8
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast:15
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));  // row_bcast:31
+  E2E_ROW_BCAST_STEPS("v_add_f32_dpp", v);
   return v;
 }
 __device__ __forceinline__ int wave_scan(int v) {
@@ -118,20 +123,50 @@ __device__ __forceinline__ int wave_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  E2E_ROW_BCAST_STEPS("v_add_u32_dpp", v);
   return v;
 }
-
 // inclusive prefix maximum over the 64 lanes, all DPP (lanes without a source keep their own value)
 __device__ __forceinline__ int wave_scan_max(int v) {
   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));   // row_shr:1
   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));   // row_shr:2
   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));   // row_shr:4
   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));   // row_shr:8
-  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15
-  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31
+  E2E_ROW_BCAST_STEPS("v_max_i32_dpp", v);
   return v;
+}
+
+// Wave-wide sums of 8 per-lane values at once (result: wave-uniform).  Instead of 8 reductions of 6 steps, the
+// first two butterfly steps HALVE the number of values a lane carries (each lane pair / quad shares the rows between
+// its members), so the whole thing is ~30 operations plus 8 readlanes.
+__device__ __forceinline__ void wave_sum8(const float (&v)[8], float (&tot)[8], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float w[4], u[2];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {            // partner lane^1: even lanes keep rows 0..3, odd lanes rows 4..7
+    const float keep = b0 ? v[j + 4] : v[j], send = b0 ? v[j] : v[j + 4];
+    w[j] = keep + __int_as_float(dpp_i<0xB1>(0, __float_as_int(send)));
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {            // partner lane^2: row = 4*b0 + 2*b1 + j
+    const float keep = b1 ? w[j + 2] : w[j], send = b1 ? w[j] : w[j + 2];
+    u[j] = keep + __int_as_float(dpp_i<0x4E>(0, __float_as_int(send)));
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {            // the 4 quads of a 16-lane row: rotations by 4 and 8 keep (b1, b0)
+    u[j] += __int_as_float(dpp_i<0x124>(0, __float_as_int(u[j])));     // row_ror:4
+    u[j] += __int_as_float(dpp_i<0x128>(0, __float_as_int(u[j])));     // row_ror:8
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) u[j] += __shfl_xor(u[j], 16, 64);        // the 4 rows (row_bcast would mix the classes)
+#pragma unroll
+  for (int j = 0; j < 2; j++) u[j] += __shfl_xor(u[j], 32, 64);
+#pragma unroll
+  for (int c = 0; c < 4; c++) {            // lane c holds the rows of class c = (b1, b0)
+    const int row = 4 * (c & 1) + 2 * (c >> 1);
+    tot[row] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u[0]), c));
+    tot[row + 1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u[1]), c));
+  }
 }
 
 // all-reduce inside each 16-lane DPP row (pure VALU, no LDS crossbar)
@@ -653,7 +688,7 @@ constexpr int kYs = kSeg + 4;      // row stride (floats) of the transposed prob
 
 template <int PPL>
 struct F2Lds {
-  static constexpr int PROW = 64 * PPL + 64;   // label cells in label order, then 64 blank partial sums
+  static constexpr int PROW = 64 * PPL;        // label cells in label order
   float* Ps;        // [kHalf][PROW]
   float* ys;        // [V+1][kYs]   probabilities of the segment, TRANSPOSED (label-major, 16 steps + pad), row V = 0
   float* invs;      // [kHalf]
@@ -672,17 +707,18 @@ struct F2Lds {
 // rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows.  FULL: all 8 rows are live.
 template <int PPL, bool FULL>
 __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, int n, int h, const F2Lds<PPL>& lds,
-                                            int lane, float& smin, float& smax) {
+                                            const float (&pb)[kHalf], int lane, float& smin, float& smax) {
   constexpr int PROW = F2Lds<PPL>::PROW;
   const int V = p.V, blank = p.blank;
   const int rows = FULL ? kHalf : min(kHalf, n - h * kHalf);      // live rows of this half (>= 1)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // prefix sums over the label-sorted cells, totals, s_t = sum_j alpha_t[j]*beta_t[j]
+  float btot8[kHalf];                     // blank cells: the lanes' partial sums never went through the LDS
+  wave_sum8(pb, btot8, lane);
   auto scan_row = [&](int k, float& st, float& bl_total) {
     float c[PPL];
 #pragma unroll
     for (int r = 0; r < PPL; r++) c[r] = lds.Ps[k * PROW + PPL * lane + r];
-    const float bl = lds.Ps[k * PROW + 64 * PPL + lane];
 #pragma unroll
     for (int r = 1; r < PPL; r++) c[r] += c[r - 1];
     const float incl = wave_scan(c[PPL - 1]);
@@ -690,7 +726,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
 #pragma unroll
     for (int r = 0; r < PPL; r++) lds.Ps[k * PROW + PPL * lane + r] = c[r] + excl;
     const float lab_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
-    bl_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_scan(bl)), 63));
+    bl_total = btot8[k];
     st = lab_total + bl_total;
     smin = fminf(smin, st); smax = fmaxf(smax, st);
   };
@@ -707,10 +743,13 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
     }
     if (lane < kHalf) { lds.invs[lane] = __builtin_amdgcn_rcpf(my_st); lds.btot[lane] = my_bt; }
   } else {
-    for (int k = 0; k < rows; k++) {
-      float st, bt;
-      scan_row(k, st, bt);
-      if (lane == 0) { lds.invs[k] = __builtin_amdgcn_rcpf(st); lds.btot[k] = bt; }
+#pragma unroll
+    for (int k = 0; k < kHalf; k++) {
+      if (k < rows) {
+        float st, bt;
+        scan_row(k, st, bt);
+        if (lane == 0) { lds.invs[k] = __builtin_amdgcn_rcpf(st); lds.btot[k] = bt; }
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -743,6 +782,8 @@ template <int PPL>
 struct SegIn {
   float a[2 * PPL];                 // alpha checkpoint row (this lane's cells), segment > 0
   int ownA;                         // its per-lane exponent
+  float q[2 * PPL];                 // beta-with-emission checkpoint row at the segment's end (not the last segment)
+  int ownB;
   int eA7, eA15, eB0, eB8;          // rescale exponents inside the segment
   __device__ void load(const FastParams& p, int b, int seg, int lane) {
     const int t0 = seg * kSeg;
@@ -758,6 +799,15 @@ struct SegIn {
 #pragma unroll
       for (int k = 0; k < 2 * PPL; k++) a[k] = src[k];
       ownA = p.ckE[(((size_t)b * p.NS + seg) * 2 + 0) * 64 + lane];
+    }
+    ownB = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * PPL; k++) q[k] = 0.f;
+    if (seg + 1 < p.NS) {            // (row seg+1 exists; whether it is meaningful depends on the utterance's length)
+      const float* src = p.ckQ + ((size_t)b * p.NS + seg + 1) * p.CELLS + lane * 2 * PPL;
+#pragma unroll
+      for (int k = 0; k < 2 * PPL; k++) q[k] = src[k];
+      ownB = p.ckE[(((size_t)b * p.NS + seg + 1) * 2 + 1) * 64 + lane];
     }
   }
 };
@@ -859,10 +909,9 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
   const bool last_seg = (t0 + n == T);
   float end_unit = 1.f;
   if (FULL || !last_seg) {
-    const float* src = p.ckQ + ((size_t)b * p.NS + seg + 1) * p.CELLS + lane * NC;
 #pragma unroll
-    for (int k = 0; k < NC; k++) q[k] = src[k];
-    const int ownB = p.ckE[(((size_t)b * p.NS + seg + 1) * 2 + 1) * 64 + lane];
+    for (int k = 0; k < NC; k++) q[k] = in.q[k];
+    const int ownB = in.ownB;
     const int E = eA + ownB;
     const int emax = wave_max(E);
     const int sh = max(E - emax, -200);
@@ -878,6 +927,9 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
 #pragma unroll
   for (int h = kSeg / kHalf - 1; h >= 0; h--) {
     if (!FULL && h * kHalf >= n) continue;
+    float pb[kHalf];                 // this lane's blank-cell part of sum alpha*beta, per row of the half
+#pragma unroll
+    for (int k = 0; k < kHalf; k++) pb[k] = 0.f;
 #pragma unroll
     for (int k = kHalf - 1; k >= 0; k--) {
       const int tt = h * kHalf + k;
@@ -913,7 +965,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
           pblank += A[tt][2 * r] * bs[2 * r];
           Ps[k * PROW + rank[r]] = A[tt][2 * r + 1] * bs[2 * r + 1];
         }
-        Ps[k * PROW + 64 * PPL + lane] = pblank;
+        pb[k] = pblank;
         // q_t = beta_t * y_t
 #pragma unroll
         for (int r = 0; r < PPL; r++) {
@@ -930,7 +982,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
       }
     }
     F2_STAMP(4)
-    finish_rows<PPL, FULL>(p, b, t0, n, h, lds, lane, smin, smax);
+    finish_rows<PPL, FULL>(p, b, t0, n, h, lds, pb, lane, smin, smax);
     F2_STAMP(6)
   }
 }
