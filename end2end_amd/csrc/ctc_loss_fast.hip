@@ -658,6 +658,7 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
     return;
   }
   const int T = (int)Tq, S = (int)Sq;
+  if (tid == 0) p.flags[b] = 0;    // (the barrier below orders this before the waves' atomicOr; saves a memset launch)
   if (tid < F1Lds::kSyncInts) lds.filled[tid] = 0;
   for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
     lds.ring[(size_t)(i / kBlk) * lds.blk_elems + V * kRow + (i % kBlk)] = 0.0;
@@ -1160,7 +1161,6 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.logz = reinterpret_cast<double*>(ws + l.logz); p.flags = reinterpret_cast<int*>(ws + l.flags);
   p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart);
   p.NS = l.NS; p.NB = l.NB; p.CELLS = l.CELLS;
-  E2E_HIP_CHECK(hipMemsetAsync(p.flags, 0, (size_t)a.B * sizeof(int), a.stream), "hipMemsetAsync(flags)");
   int rc;
   switch (ppl_for(a.Smax)) {
     case 1: rc = launch_fast_ppl<1>(p, a.stream); break;
