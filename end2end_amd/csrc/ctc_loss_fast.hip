@@ -831,6 +831,9 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
   const int eA7 = in.eA7, eA15 = in.eA15, eB0 = in.eB0, eB8 = in.eB8;
 
   // ---- alpha rows of the segment, kept in registers ----
+  // (Keeping only 8 rows and recomputing the other 8 was tried: 168 VGPRs, three waves per SIMD -- and slower.  With
+  // two waves per SIMD the kernel already saturates the VALU issue slots; the 8 extra steps cost more than the
+  // third wave hides.)
   float A[kSeg][NC];
   float a[NC];
   int eA = 0;                       // this lane's exponent for its alpha cells during the segment
