@@ -284,6 +284,8 @@ namespace {
 constexpr int kThreads = 1024;
 constexpr int kMaxCand = 8192;     // W*V + W candidates per step (LDS key array)
 constexpr int kLdsBudget = 158 * 1024;
+constexpr int kSelBits = 11, kSelBins = 1 << kSelBits;   // radix-select digit (two alternating histograms in LDS)
+constexpr int kSelSmall = 64;                           // a threshold bin this small is finished exactly by one wave
 
 // LM-related state of a prefix (Prefix::lm_*, num_*, last_word, ctc_decoder.h:79-86)
 struct LmFields {
@@ -294,12 +296,13 @@ struct LmFields {
   int st_n, stb_n;
 };
 
-// tree node in HBM: structure + LM state.  The four log-probabilities of a prefix matter only while it is in the beam
-// and live in LDS (a pruned-but-alive prefix still "receives" probability upstream, but nothing ever reads it: quirk Q7
-// reduces to "its (parent, char) slot stays occupied").
+// tree node in HBM: the structure only (16 bytes).  Everything a prefix needs while it is in the beam -- the four
+// log-probabilities, the LM state, its child table, its parent's id -- lives in LDS; a pruned-but-alive prefix still
+// "receives" probability upstream, but nothing ever reads it: quirk Q7 reduces to "its (parent, char) slot stays
+// occupied".  Nodes are never reused: at most W prefixes are created per step, so W*(T+3) nodes cover an utterance
+// and allocation is a counter (no free list to initialise, read or write).
 struct BeamNode {
-  int parent, last_char, refs, slot, tab, pad;
-  LmFields lm;
+  int parent, last_char, refs, pad;
 };
 
 struct BeamParams {
@@ -307,8 +310,8 @@ struct BeamParams {
   int B, T, V, blank, W, space_id;
   int has_lm; LmView lm; double lmwt, wip, oov;
   int64_t* out; int64_t max_out; int64_t* out_len;
-  BeamNode* nodes; int* free_nodes; int* status;      // per-utterance workspace
-  int NCAP, TCAP, CMAX, WP2;
+  BeamNode* nodes; int* status;                       // per-utterance workspace
+  int NCAP, TCAP, CMAX, WP2, HS;
 };
 
 __device__ __forceinline__ double ninf() { return -__builtin_huge_val(); }
@@ -330,6 +333,17 @@ __device__ __forceinline__ int wave_scan_i(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
   return v;
+}
+
+// maximum over the 64 lanes, all DPP; every lane of row 3 (lanes 48..63) ends with it, returned wave-uniform
+__device__ __forceinline__ int wave_max_i(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));   // row_mirror
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // order-preserving map double -> uint64 (larger double <=> larger key)
@@ -389,6 +403,7 @@ struct Members {
   double* inc;                 // contribution to prob_not_blank arriving from the parent (if it is in the beam)
   double* full;                // log_sum_exp(prev_pnb, prev_pb), once per member and step
   int* node; int* last; int* tab; int* kept;
+  int* par;                    // node id of the parent prefix (-1: the root)
   LmFields* lm;
   __device__ unsigned char* carve(unsigned char* q, int W) {
     ppb = (double*)q; q += sizeof(double) * W; ppnb = (double*)q; q += sizeof(double) * W;
@@ -397,15 +412,40 @@ struct Members {
     lm = (LmFields*)q; q += sizeof(LmFields) * W;
     node = (int*)q; q += sizeof(int) * W; last = (int*)q; q += sizeof(int) * W;
     tab = (int*)q; q += sizeof(int) * W; kept = (int*)q; q += sizeof(int) * W;
+    par = (int*)q; q += sizeof(int) * W;
+    q += sizeof(int) * W;        // (pad: the next member set starts 8-byte aligned for any W)
     return q;
   }
-  static size_t bytes(int W) { return (size_t)W * (6 * sizeof(double) + sizeof(LmFields) + 4 * sizeof(int)); }
+  static size_t bytes(int W) { return (size_t)W * (6 * sizeof(double) + sizeof(LmFields) + 6 * sizeof(int)); }
 };
 
 struct BeamLds {
-  static size_t bytes(int W, int V, int CMAX, int TCAP, int WP2) {
-    return sizeof(double) * ((size_t)CMAX + V + WP2) + sizeof(int) * ((size_t)CMAX + WP2 + (size_t)TCAP * V + TCAP + 512 + 64) +
+  static size_t bytes(int W, int V, int CMAX, int TCAP, int WP2, int HS) {
+    return sizeof(double) * ((size_t)CMAX + 2 * V + WP2) +
+           sizeof(int) * ((size_t)CMAX + WP2 + (size_t)TCAP * V + TCAP + 2 * kSelBins + 64 + 4 * (size_t)HS) +
            2 * Members::bytes(W) + 64;
+  }
+};
+
+// node id -> position in the beam, for the <= W members: open addressing in LDS, one table per member set (the
+// table of the set that is being built is cleared a phase earlier).  Replaces a `slot` field in the HBM nodes that
+// cost a global round trip per step to read.
+struct SlotMap {
+  int* key; int* val; int mask;
+  __device__ static unsigned hash(int k) { return (unsigned)k * 2654435761u; }
+  __device__ void insert(int k, int j) const {
+    unsigned h = (hash(k) >> 8) & mask;
+    while (atomicCAS(&key[h], -1, k) != -1) h = (h + 1) & mask;
+    val[h] = j;
+  }
+  __device__ int find(int k) const {
+    unsigned h = (hash(k) >> 8) & mask;
+    for (;;) {
+      const int kk = key[h];
+      if (kk == k) return val[h];
+      if (kk == -1) return -1;
+      h = (h + 1) & mask;
+    }
   }
 };
 
@@ -426,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   // ---- LDS carve-up ----
   unsigned char* q8 = smem;
   double* key = (double*)q8; q8 += sizeof(double) * p.CMAX;          // score of candidate d (dense: old members, then new)
-  double* srow = (double*)q8; q8 += sizeof(double) * V;
+  double* srow2 = (double*)q8; q8 += sizeof(double) * 2 * V;         // this step's and the next step's log-probabilities
   double* skey = (double*)q8; q8 += sizeof(double) * p.WP2;          // the selected W, for the final ordering
   Members M[2];
   q8 = M[0].carve(q8, W); q8 = M[1].carve(q8, W);
@@ -434,32 +474,37 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   int* sidx = (int*)q8; q8 += sizeof(int) * p.WP2;
   int* ctab = (int*)q8; q8 += sizeof(int) * (size_t)p.TCAP * V;      // child tables of the beam members (weak next_data)
   int* free_tabs = (int*)q8; q8 += sizeof(int) * p.TCAP;
-  int* hist = (int*)q8; q8 += sizeof(int) * 512;
+  int* hist = (int*)q8; q8 += sizeof(int) * 2 * kSelBins;
   int* s_part = (int*)q8; q8 += sizeof(int) * 64;
-  __shared__ int s_free_nodes, s_free_tabs, s_err, s_krem, s_done;
+  SlotMap SM[2];
+  for (int k = 0; k < 2; k++) { SM[k].key = (int*)q8; q8 += sizeof(int) * p.HS; SM[k].val = (int*)q8; q8 += sizeof(int) * p.HS; SM[k].mask = p.HS - 1; }
+  __shared__ int s_next_node, s_free_tabs, s_err, s_krem, s_done, s_bin;
+  __shared__ unsigned s_hi, s_lo;
   __shared__ unsigned long long s_prefix;
 
   BeamNode* nodes = p.nodes + (size_t)b * p.NCAP;
-  int* free_nodes = p.free_nodes + (size_t)b * p.NCAP;
   const IO* lp = reinterpret_cast<const IO*>(p.lp) + (int64_t)b * p.sB;
   int64_t Tq = p.x_len[b];
   const int T = Tq < 0 ? 0 : (Tq > p.T ? p.T : (int)Tq);
 
   // ---- pools, root prefix (get_initial_prefix, :222-230) ----
-  for (int i = tid; i < p.NCAP; i += kThreads) free_nodes[i] = p.NCAP - 1 - i;     // pop order 0,1,2,...
   for (int i = tid; i < p.TCAP; i += kThreads) free_tabs[i] = p.TCAP - 1 - i;
   for (int c = tid; c < V; c += kThreads) ctab[c] = -1;                              // table 0 = the root's
+  for (int h = tid; h < p.HS; h += kThreads) { SM[0].key[h] = -1; SM[1].key[h] = -1; }
+  if (T > 0) for (int c = tid; c < V; c += kThreads) srow2[c] = (double)lp[(int64_t)c * p.sV];
   if (tid == 0) {
-    s_free_nodes = p.NCAP - 1; s_free_tabs = p.TCAP - 1; s_err = 0;                 // node 0 / table 0 are taken
+    s_next_node = 1; s_free_tabs = p.TCAP - 1; s_err = 0;                           // node 0 / table 0 are taken
     BeamNode& r = nodes[0];
-    r.parent = -1; r.last_char = -1; r.refs = 1; r.slot = 0; r.tab = 0;
+    r.parent = -1; r.last_char = -1; r.refs = 1; r.pad = 0;
     LmFields l;
     l.lm_score = 0.0; l.lm_before = 0.0; l.num_words = 0; l.num_oov = 0; l.num_oov_before = 0; l.word_len = 0;
     l.word_hash = kFnvInit; l.st_n = 0; l.stb_n = 0;
     if (p.has_lm) { l.st[0] = p.lm.bos; l.st_n = 1; l.stb[0] = p.lm.bos; l.stb_n = 1; }
-    r.lm = l;
-    M[0].ppb[0] = 0.0; M[0].ppnb[0] = ninf(); M[0].node[0] = 0; M[0].last[0] = -1; M[0].tab[0] = 0; M[0].lm[0] = l;
+    M[0].ppb[0] = 0.0; M[0].ppnb[0] = ninf(); M[0].node[0] = 0; M[0].last[0] = -1; M[0].tab[0] = 0; M[0].par[0] = -1;
+    M[0].lm[0] = l;
   }
+  __syncthreads();
+  if (tid == 0) SM[0].insert(0, 0);
   __syncthreads();
   int n = 1, cur = 0;
 #ifdef E2E_BEAM_PROFILE
@@ -470,8 +515,15 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   for (int t = 0; t < T; t++) {
     Members& A = M[cur];
     Members& Bm = M[cur ^ 1];
-    for (int c = tid; c < V; c += kThreads) srow[c] = (double)lp[(int64_t)t * p.sT + (int64_t)c * p.sV];
+    const SlotMap& mapA = SM[cur];                   // node -> position among the current members
+    const SlotMap& mapB = SM[cur ^ 1];               // ... among the members this step selects (filled in the rebuild)
+    double* const srow = srow2 + (t & 1) * V;
+    // the next step's row is requested now and parked in LDS at the end of the step: no global round trip at a
+    // step's start
+    double next_lp = 0.0;
+    if (tid < V && t + 1 < T) next_lp = (double)lp[(int64_t)(t + 1) * p.sT + (int64_t)tid * p.sV];
     for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; A.full[i] = lse2(A.ppnb[i], A.ppb[i]); }
+    for (int h = tid; h < p.HS; h += kThreads) mapB.key[h] = -1;
     __syncthreads();
     // pairs in the reference's order: character outer, prefix inner (:370-395): q = c*n + i
     const int npairs = n * V;
@@ -499,7 +551,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       const double val = curp + (c == A.last[i] ? A.ppb[i] : full);            // :383-385 / :389-391
       const int k = ctab[A.tab[i] * V + c];
       if (k >= 0) {
-        const int j = nodes[k].slot;
+        const int j = mapA.find(k);
         if (j >= 0) A.inc[j] = val;            // the child is a beam member: its share from this parent
         // else: alive but pruned (Q7) -- the probability is lost and the slot stays taken
       } else {
@@ -524,57 +576,92 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     BPROF(2);
     const int ntot = n + total_new;
     const int nsel = ntot > W ? W : ntot;
+    int* const sel = hist + kSelBins;               // the selected candidates in beam order (valid after the block below)
     if (ntot > W) {                                                              // :405-415
-      // ---- radix select of the W-th largest score (8 bits per pass), ties broken by position ----
-      // Two histograms alternate (the idle one is cleared while the other is scanned), wave 0 scans the bins and
-      // publishes the digit / prefix itself: two barriers per pass.  As soon as the bin of the chosen digit is taken
-      // whole (count == remaining k) the threshold is known to the bits decided so far and the passes stop.
-      for (int h = tid; h < 512; h += kThreads) hist[h] = 0;
-      if (tid == 0) { s_prefix = 0ULL; s_krem = W; s_done = 0; }
-      unsigned long long mask = 0ULL;
+      // ---- radix select of the W-th largest score on the order-preserving 64-bit key, 11 bits per pass ----
+      // Scores differ in their mantissas, so the first digit (sign + exponent) hardly splits them and the second
+      // normally isolates the threshold: as soon as the bin of the chosen digit holds exactly the remaining k
+      // (taken whole) or at most 64 candidates (finished exactly by one wave) the passes stop -- two passes in
+      // practice, six at most.  Two histograms alternate (the idle one is cleared while the other is scanned).
+      for (int h = tid; h < 2 * kSelBins; h += kThreads) hist[h] = 0;
+      if (tid == 0) { s_krem = W; s_done = 0; s_bin = 0; s_hi = 0u; s_lo = 0xffffffffu; }
       __syncthreads();
-      const int hb = 63;
-      int shift = hb - 7 > 0 ? hb - 7 : 0;
+      // Where to start: the threshold lies between the smallest score of a full beam's old members (W candidates are
+      // at least that good) and the largest score of all, so it shares their common leading bits -- found on the keys'
+      // high words with two cheap reductions.  Starting below them, the first digit already spreads the candidates
+      // that matter over the bins (a pass over the sign/exponent bits would put all of them into one).
+      {
+        unsigned hi = 0u, lo = 0xffffffffu;
+        for (int d = tid; d < ntot; d += kThreads) {
+          const unsigned h32 = (unsigned)(okey(key[d]) >> 32);
+          hi = max(hi, h32);
+          if (d < n) lo = min(lo, h32);
+        }
+        hi = (unsigned)wave_max_i((int)(hi ^ 0x80000000u)) ^ 0x80000000u;      // (signed max on biased values)
+        lo = ~((unsigned)wave_max_i((int)((~lo) ^ 0x80000000u)) ^ 0x80000000u);
+        if (lane == 0) { atomicMax(&s_hi, hi); atomicMin(&s_lo, lo); }
+      }
+      __syncthreads();
+      const unsigned H32 = s_hi, L32 = n == W ? s_lo : 0u;
+      const unsigned xdiff = H32 ^ L32;
+      const int hb = xdiff ? 63 - __builtin_clz(xdiff) : 31;                    // highest bit that may differ
+      unsigned long long mask = hb == 63 ? 0ULL : ~0ULL << (hb + 1);
+      if (tid == 0) s_prefix = ((unsigned long long)H32 << 32) & mask;
+      __syncthreads();
+      int shift = hb + 1 - kSelBits;                                            // >= 21
       for (int pass = 0;; pass++) {
-        int* hcur = hist + (pass & 1) * 256;
-        int* hnext = hist + ((pass & 1) ^ 1) * 256;
+        int* hcur = hist + (pass & 1) * kSelBins;
+        int* hnext = hist + ((pass & 1) ^ 1) * kSelBins;
+        const int nbits = 64 - __builtin_popcountll(mask) - shift;                    // (the last digit may be short)
+        const int width = nbits < kSelBits ? nbits : kSelBits;
+        const unsigned long long dmask = (1ULL << width) - 1ULL;
         const unsigned long long prefix = s_prefix;
         for (int d = tid; d < ntot; d += kThreads) {
           const unsigned long long u = okey(key[d]);
-          if ((u & mask) == prefix) atomicAdd(&hcur[(int)((u >> shift) & 255ULL)], 1);
+          if ((u & mask) == prefix) atomicAdd(&hcur[(int)((u >> shift) & dmask)], 1);
         }
         __syncthreads();
-        const unsigned long long digit_mask = 255ULL << shift;
+        const unsigned long long digit_mask = dmask << shift;
         if (wid == 0) {
-          // lane l owns digits 255-4l .. 252-4l (descending); find the digit where the running count reaches k
-          int c4[4], s4 = 0;
-#pragma unroll
-          for (int j = 0; j < 4; j++) { c4[j] = hcur[255 - 4 * lane - j]; s4 += c4[j]; }
-          const int inc4 = wave_scan_i(s4);
-          int above = inc4 - s4;                      // elements with a larger digit than this lane's first
+          // lane l owns the 32 digits 2047-32l .. 2016-32l (descending); find the digit where the running count reaches k
+          constexpr int kPer = kSelBins / 64;
+          const int top = kSelBins - 1 - kPer * lane;
+          int s32 = 0;
+          for (int j = 0; j < kPer; j++) s32 += hcur[top - j];
+          const int inc = wave_scan_i(s32);
+          int above = inc - s32;                      // elements with a larger digit than this lane's first
           const int k = s_krem;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (above < k && above + c4[j] >= k) {
-              s_krem = k - above;
-              s_prefix = (prefix & ~digit_mask) | ((unsigned long long)(255 - 4 * lane - j) << shift);
-              if (c4[j] == k - above) s_done = 1;     // the whole bin survives: no finer threshold needed
+          if (above < k && inc >= k) {                // the threshold digit is one of this lane's
+            for (int j = 0; j < kPer; j++) {
+              const int cj = hcur[top - j];
+              if (above + cj >= k) {
+                s_krem = k - above;
+                s_prefix = (prefix & ~digit_mask) | ((unsigned long long)(top - j) << shift);
+                s_bin = cj;
+                if (cj == k - above) s_done = 1;      // the whole bin survives: no finer threshold needed
+                break;
+              }
+              above += cj;
             }
-            above += c4[j];
           }
-        } else if (wid == 1) {
-          for (int h = lane; h < 256; h += 64) hnext[h] = 0;
+        } else {
+          for (int h = tid - 64; h < kSelBins; h += kThreads - 64) hnext[h] = 0;
         }
         mask |= digit_mask;
         __syncthreads();
-        if (s_done || shift == 0) break;
-        shift = shift - 8 > 0 ? shift - 8 : 0;
+        if (s_done || shift == 0 || s_bin <= kSelSmall) break;
+        shift = shift - kSelBits > 0 ? shift - kSelBits : 0;
       }
-      // survivors: keys whose decided bits are above the threshold prefix, plus s_krem keys equal to it (all of them
-      // when the passes stopped early)
+      BPROF(7);
+      // survivors: keys whose decided bits are above the threshold prefix, plus s_krem of those equal to it --
+      // all of them (taken whole), the first by position (every bit decided: exact ties), or the best s_krem by
+      // (score, position) of a small bin, which one wave works out below.
       const unsigned long long Tk = s_prefix;
+      const int krem = s_krem;
+      const bool small_bin = !s_done && shift != 0;           // (then s_bin <= kSelSmall and s_bin > krem)
+      int* const glist = hist;                                 // candidates of the small bin, by position
 #define OKEY_CMP(u) ((u) & mask)
-      // ---- compaction: larger keys first, then the first s_krem equal ones (by position) ----
+      // ---- compaction: larger keys first, then the equal ones ----
       const int per = (ntot + kThreads - 1) / kThreads;
       const int d0 = min(tid * per, ntot), d1 = min(d0 + per, ntot);
       int ngt = 0, neq = 0;
@@ -585,80 +672,106 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       int bg = 0, be = 0, tg = 0;
       for (int w = 0; w < kThreads / 64; w++) { if (w < wid) { bg += s_part[w]; be += s_part[16 + w]; } tg += s_part[w]; }
       int og = bg + ig - ngt, oe = be + ie - neq;
-      const int krem = s_krem;
       for (int d = d0; d < d1; d++) {
         const unsigned long long u = OKEY_CMP(okey(key[d]));
         if (u > Tk) { skey[og] = key[d]; sidx[og] = d; og++; }
-        else if (u == Tk) { if (oe < krem) { skey[tg + oe] = key[d]; sidx[tg + oe] = d; } oe++; }
+        else if (u == Tk) {
+          if (small_bin) glist[oe] = d;
+          else if (oe < krem) { skey[tg + oe] = key[d]; sidx[tg + oe] = d; }
+          oe++;
+        }
       }
 #undef OKEY_CMP
-      for (int j = W + tid; j < p.WP2; j += kThreads) { skey[j] = ninf(); sidx[j] = 0x7fffffff; }
-      __syncthreads();
-      // ---- order the survivors: (score desc, position asc), one wavefront, no workgroup barriers ----
-      if (wid == 0) {
-        for (int k = 2; k <= p.WP2; k <<= 1) {
-          for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int e = lane; e < p.WP2; e += 64) {
-              const int partner = e ^ j;
-              if (partner > e) {
-                const bool up = (e & k) == 0;
-                const double ka = skey[e], kb = skey[partner];
-                const int ia = sidx[e], ib = sidx[partner];
-                const bool a_first = ka > kb || (ka == kb && ia < ib);
-                if (up ? !a_first : a_first) { skey[e] = kb; skey[partner] = ka; sidx[e] = ib; sidx[partner] = ia; }
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+      if (small_bin) {
+        __syncthreads();
+        if (wid == 0) {
+          // the best krem of the bin's g <= 64 candidates: one per lane, rank by counting
+          const int g = s_bin;
+          const int myd = lane < g ? glist[lane] : 0x7fffffff;
+          const double myk = lane < g ? key[lane < g ? myd : 0] : ninf();
+          int rank = 0;
+          for (int j = 0; j < g; j++) {
+            const int dj = glist[j];
+            const double kj = key[dj];
+            rank += (kj > myk || (kj == myk && dj < myd)) ? 1 : 0;
           }
+          if (lane < g && rank < krem) { skey[tg + rank] = myk; sidx[tg + rank] = myd; }
         }
       }
       __syncthreads();
+      BPROF(8);
+      // ---- order the survivors: (score desc, position asc), rank by counting with every thread ----
+      {
+        for (int e = tid; e < W; e += kThreads) hist[e] = 0;            // (glist is dead; W <= kSelBins, checked by the host)
+        __syncthreads();
+        const int P = kThreads / W > 0 ? kThreads / W : 1;              // threads per survivor
+        for (int e = tid / P; e < W; e += kThreads / P) {
+          const int part = tid % P;
+          const double ke = skey[e];
+          const int de = sidx[e];
+          int cnt = 0;
+          for (int j = part; j < W; j += P) {
+            const double kj = skey[j];
+            const int dj = sidx[j];
+            cnt += (kj > ke || (kj == ke && dj < de)) ? 1 : 0;
+          }
+          if (cnt) atomicAdd(&hist[e], cnt);
+        }
+        __syncthreads();
+        for (int e = tid; e < W; e += kThreads) sel[hist[e]] = sidx[e];
+      }
+      __syncthreads();
     } else {
-      for (int j = tid; j < ntot; j += kThreads) sidx[j] = j;                     // unchanged order: old members, then new
+      for (int j = tid; j < ntot; j += kThreads) sel[j] = j;                      // unchanged order: old members, then new
       __syncthreads();
     }
     BPROF(3);
     // ---- rebuild the beam in the other member set ----
     for (int j = tid; j < nsel; j += kThreads) {
-      const int d = sidx[j];
+      const int d = sel[j];
       if (d < n) {
         const int i = d;
         A.kept[i] = 1;
         Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i];
-        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; Bm.tab[j] = A.tab[i]; Bm.lm[j] = A.lm[i];
-        nodes[A.node[i]].slot = j;
+        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; Bm.tab[j] = A.tab[i]; Bm.par[j] = A.par[i]; Bm.lm[j] = A.lm[i];
+        mapB.insert(A.node[i], j);
       } else {
         const int q = newq[d - n];
         const int c = q / n, i = q - c * n;
         const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : A.full[i]);
         LmFields nl;
         child_lm(p, A.lm[i], A.last[i], c, nl);
-        const int fi = atomicSub(&s_free_nodes, 1) - 1;                           // make_shared<Prefix>, :254
-        int k = 0;
-        if (fi < 0) s_err = 1; else k = free_nodes[fi];
-        BeamNode& nn = nodes[k];
-        nn.parent = A.node[i]; nn.last_char = c; nn.refs = 1; nn.slot = j; nn.tab = -1; nn.lm = nl;
-        atomicAdd(&nodes[A.node[i]].refs, 1);
-        ctab[A.tab[i] * V + c] = k;
-        Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.node[j] = k; Bm.last[j] = c; Bm.tab[j] = -1; Bm.lm[j] = nl;
+        int k = atomicAdd(&s_next_node, 1);                                       // make_shared<Prefix>, :254
+        if (k >= p.NCAP) { s_err = 1; k = 0; }
+        else {
+          BeamNode nn;
+          nn.parent = A.node[i]; nn.last_char = c; nn.refs = 1; nn.pad = 0;
+          nodes[k] = nn;
+          atomicAdd(&nodes[A.node[i]].refs, 1);
+          ctab[A.tab[i] * V + c] = k;
+          mapB.insert(k, j);
+        }
+        Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.node[j] = k; Bm.last[j] = c; Bm.tab[j] = -1; Bm.par[j] = A.node[i];
+        Bm.lm[j] = nl;
       }
     }
     __threadfence_block();
     __syncthreads();
     BPROF(4);
     // ---- members that left the beam: give the table back, drop the beam's reference, cascade (shared_ptr release) ----
+    // A prefix that dies expires in its parent's child table (weak_ptr); the parent holds a table only while it is
+    // a member of the beam this step started with, which the LDS map answers.  The first level needs no global read
+    // at all (the parent's id is cached with the member), only the reference-count atomics.
     for (int i = tid; i < n; i += kThreads) {
       if (A.kept[i]) continue;
-      int k = A.node[i];
       free_tabs[atomicAdd(&s_free_tabs, 1)] = A.tab[i];
-      nodes[k].tab = -1; nodes[k].slot = -1;
+      int k = A.node[i], par = A.par[i], lc = A.last[i];
+      bool known = true;                             // (par, lc) of k are at hand
       while (k >= 0) {
         if (atomicSub(&nodes[k].refs, 1) != 1) break;
-        const int par = nodes[k].parent;
-        if (par >= 0) { const int pt = nodes[par].tab; if (pt >= 0) ctab[pt * V + nodes[k].last_char] = -1; }   // weak_ptr expires
-        free_nodes[atomicAdd(&s_free_nodes, 1)] = k;
-        k = par;
+        if (!known) { const BeamNode nd = nodes[k]; par = nd.parent; lc = nd.last_char; }
+        if (par >= 0) { const int pi = mapA.find(par); if (pi >= 0) ctab[A.tab[pi] * V + lc] = -1; }   // weak_ptr expires
+        k = par; known = false;
       }
     }
     __threadfence_block();
@@ -670,13 +783,14 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         const int ti = atomicSub(&s_free_tabs, 1) - 1;
         int tb = 0;
         if (ti < 0) s_err = 2; else tb = free_tabs[ti];
-        Bm.tab[j] = tb; nodes[Bm.node[j]].tab = tb;
+        Bm.tab[j] = tb;
         for (int c = 0; c < V; c++) ctab[tb * V + c] = -1;
       }
     }
     __threadfence_block();
     __syncthreads();
     BPROF(6);
+    if (tid < V) srow2[((t + 1) & 1) * V + tid] = next_lp;          // (read after the first barrier of the next step)
     n = nsel; cur ^= 1;
     if (s_err) break;
   }
@@ -707,7 +821,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   }
 }
 
-struct BeamLayout { size_t nodes, free_nodes, status, total, lds; int NCAP, TCAP, CMAX, WP2; };
+struct BeamLayout { size_t nodes, status, total, lds; int NCAP, TCAP, CMAX, WP2, HS; };
 
 BeamLayout beam_layout(int B, int T, int V, int W) {
   BeamLayout l;
@@ -716,10 +830,10 @@ BeamLayout beam_layout(int B, int T, int V, int W) {
   l.NCAP = W * (T + 3) + 8;
   l.TCAP = 2 * W + 8;
   l.WP2 = 64; while (l.WP2 < W) l.WP2 <<= 1;
-  l.lds = BeamLds::bytes(W, V, l.CMAX, l.TCAP, l.WP2);
+  l.HS = 256; while (l.HS < 4 * W) l.HS <<= 1;
+  l.lds = BeamLds::bytes(W, V, l.CMAX, l.TCAP, l.WP2, l.HS);
   size_t o = 0;
   l.nodes = o; o += align_up((size_t)B * l.NCAP * sizeof(BeamNode), 256);
-  l.free_nodes = o; o += align_up((size_t)B * l.NCAP * sizeof(int), 256);
   l.status = o; o += align_up((size_t)B * sizeof(int), 256);
   l.total = o;
   return l;
@@ -745,7 +859,7 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   if (B > 0 && (!lp || !x_len || !out || !out_len)) { set_error("null pointer argument"); return E2E_ERR_ARG; }
   if (lm && !lm->d_ng) { set_error("the language model has no device tables (it was loaded without a GPU)"); return E2E_ERR_HIP; }
   const BeamLayout l = beam_layout(B, T, V, beam_width);
-  if (l.CMAX > kMaxCand || l.lds > (size_t)kLdsBudget) {
+  if (l.CMAX > kMaxCand || l.lds > (size_t)kLdsBudget || beam_width > kSelBins) {
     set_error("beam_width*alphabet = %d candidates per step (%zu B of LDS) exceed what one workgroup holds (%d, %d B)",
               l.CMAX, l.lds, kMaxCand, kLdsBudget);
     return E2E_ERR_UNSUPPORTED;
@@ -763,9 +877,9 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   p.lmwt = lm ? lmwt : 0.0;                       // ctc_decoder.cpp:72-74
   p.wip = wip; p.oov = oov_penalty;
   p.out = out; p.max_out = max_out; p.out_len = out_len;
-  p.nodes = reinterpret_cast<BeamNode*>(ws + l.nodes); p.free_nodes = reinterpret_cast<int*>(ws + l.free_nodes);
+  p.nodes = reinterpret_cast<BeamNode*>(ws + l.nodes);
   p.status = reinterpret_cast<int*>(ws + l.status);
-  p.NCAP = l.NCAP; p.TCAP = l.TCAP; p.CMAX = l.CMAX; p.WP2 = l.WP2;
+  p.NCAP = l.NCAP; p.TCAP = l.TCAP; p.CMAX = l.CMAX; p.WP2 = l.WP2; p.HS = l.HS;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == E2E_F32) {
     E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_beam_kernel<float>),

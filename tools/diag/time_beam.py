@@ -1,6 +1,8 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+import end2end_amd._lib as _lib
+if os.environ.get('E2E_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['E2E_LIB'])
 from end2end_amd import CTCDecoder
 d = torch.device("cuda", 0)
 labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
