@@ -346,6 +346,12 @@ __device__ __forceinline__ int wave_max_i(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL
+// operations (vmcnt(0)), which would expose a memory round trip at every phase that follows a fire-and-forget store or
+// the prefetch of the next row.  Two full barriers per step remain: after the rebuild (node stores and reference-count
+// atomics before the release) and at the end of the step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // order-preserving map double -> uint64 (larger double <=> larger key)
 __device__ __forceinline__ unsigned long long okey(double d) {
   unsigned long long u = (unsigned long long)__double_as_longlong(d);
@@ -416,7 +422,7 @@ struct Members {
     q += sizeof(int) * W;        // (pad: the next member set starts 8-byte aligned for any W)
     return q;
   }
-  static size_t bytes(int W) { return (size_t)W * (6 * sizeof(double) + sizeof(LmFields) + 6 * sizeof(int)); }
+  __host__ __device__ static size_t bytes(int W) { return (size_t)W * (6 * sizeof(double) + sizeof(LmFields) + 6 * sizeof(int)); }
 };
 
 struct BeamLds {
@@ -468,16 +474,21 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   double* key = (double*)q8; q8 += sizeof(double) * p.CMAX;          // score of candidate d (dense: old members, then new)
   double* srow2 = (double*)q8; q8 += sizeof(double) * 2 * V;         // this step's and the next step's log-probabilities
   double* skey = (double*)q8; q8 += sizeof(double) * p.WP2;          // the selected W, for the final ordering
-  Members M[2];
-  q8 = M[0].carve(q8, W); q8 = M[1].carve(q8, W);
+  // (the two member sets and the two slot maps are addressed as "base + set * size", never through an array of
+  // pointer structs: a pointer that went through memory loses its LDS address space and every access through it
+  // becomes a FLAT instruction -- slower, and not ordered by an LDS-only barrier)
+  unsigned char* const mem0 = q8;
+  const size_t mbytes = Members::bytes(W);
+  q8 += 2 * mbytes;
+  Members M0; M0.carve(mem0, W);
   int* newq = (int*)q8; q8 += sizeof(int) * p.CMAX;                  // pair index q = c*n + i of new candidate j
   int* sidx = (int*)q8; q8 += sizeof(int) * p.WP2;
   int* ctab = (int*)q8; q8 += sizeof(int) * (size_t)p.TCAP * V;      // child tables of the beam members (weak next_data)
   int* free_tabs = (int*)q8; q8 += sizeof(int) * p.TCAP;
   int* hist = (int*)q8; q8 += sizeof(int) * 2 * kSelBins;
   int* s_part = (int*)q8; q8 += sizeof(int) * 64;
-  SlotMap SM[2];
-  for (int k = 0; k < 2; k++) { SM[k].key = (int*)q8; q8 += sizeof(int) * p.HS; SM[k].val = (int*)q8; q8 += sizeof(int) * p.HS; SM[k].mask = p.HS - 1; }
+  int* const sm0 = (int*)q8; q8 += sizeof(int) * 4 * p.HS;            // [set][key | val][HS]
+  auto slot_map = [&](int set) { SlotMap m; m.key = sm0 + set * 2 * p.HS; m.val = m.key + p.HS; m.mask = p.HS - 1; return m; };
   __shared__ int s_next_node, s_free_tabs, s_err, s_krem, s_done, s_bin;
   __shared__ unsigned s_hi, s_lo;
   __shared__ unsigned long long s_prefix;
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   // ---- pools, root prefix (get_initial_prefix, :222-230) ----
   for (int i = tid; i < p.TCAP; i += kThreads) free_tabs[i] = p.TCAP - 1 - i;
   for (int c = tid; c < V; c += kThreads) ctab[c] = -1;                              // table 0 = the root's
-  for (int h = tid; h < p.HS; h += kThreads) { SM[0].key[h] = -1; SM[1].key[h] = -1; }
+  for (int h = tid; h < p.HS; h += kThreads) { sm0[h] = -1; sm0[2 * p.HS + h] = -1; }
   if (T > 0) for (int c = tid; c < V; c += kThreads) srow2[c] = (double)lp[(int64_t)c * p.sV];
   if (tid == 0) {
     s_next_node = 1; s_free_tabs = p.TCAP - 1; s_err = 0;                           // node 0 / table 0 are taken
@@ -500,11 +511,11 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     l.lm_score = 0.0; l.lm_before = 0.0; l.num_words = 0; l.num_oov = 0; l.num_oov_before = 0; l.word_len = 0;
     l.word_hash = kFnvInit; l.st_n = 0; l.stb_n = 0;
     if (p.has_lm) { l.st[0] = p.lm.bos; l.st_n = 1; l.stb[0] = p.lm.bos; l.stb_n = 1; }
-    M[0].ppb[0] = 0.0; M[0].ppnb[0] = ninf(); M[0].node[0] = 0; M[0].last[0] = -1; M[0].tab[0] = 0; M[0].par[0] = -1;
-    M[0].lm[0] = l;
+    M0.ppb[0] = 0.0; M0.ppnb[0] = ninf(); M0.node[0] = 0; M0.last[0] = -1; M0.tab[0] = 0; M0.par[0] = -1;
+    M0.lm[0] = l;
   }
   __syncthreads();
-  if (tid == 0) SM[0].insert(0, 0);
+  if (tid == 0) slot_map(0).insert(0, 0);
   __syncthreads();
   int n = 1, cur = 0;
 #ifdef E2E_BEAM_PROFILE
@@ -513,10 +524,11 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
 #endif
 
   for (int t = 0; t < T; t++) {
-    Members& A = M[cur];
-    Members& Bm = M[cur ^ 1];
-    const SlotMap& mapA = SM[cur];                   // node -> position among the current members
-    const SlotMap& mapB = SM[cur ^ 1];               // ... among the members this step selects (filled in the rebuild)
+    Members A, Bm;
+    A.carve(mem0 + (size_t)cur * mbytes, W);
+    Bm.carve(mem0 + (size_t)(cur ^ 1) * mbytes, W);
+    const SlotMap mapA = slot_map(cur);              // node -> position among the current members
+    const SlotMap mapB = slot_map(cur ^ 1);          // ... among the members this step selects (filled in the rebuild)
     double* const srow = srow2 + (t & 1) * V;
     // the next step's row is requested now and parked in LDS at the end of the step: no global round trip at a
     // step's start
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     if (tid < V && t + 1 < T) next_lp = (double)lp[(int64_t)(t + 1) * p.sT + (int64_t)tid * p.sV];
     for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; A.full[i] = lse2(A.ppnb[i], A.ppb[i]); }
     for (int h = tid; h < p.HS; h += kThreads) mapB.key[h] = -1;
-    __syncthreads();
+    lds_barrier();
     // pairs in the reference's order: character outer, prefix inner (:370-395): q = c*n + i
     const int npairs = n * V;
     const int chunk = (npairs + kThreads - 1) / kThreads;
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     }
     const int incl = wave_scan_i(my_new);
     if (lane == 63) s_part[wid] = incl;
-    __syncthreads();
+    lds_barrier();
     BPROF(0);
     int base = 0, total_new = 0;
     for (int w = 0; w < kThreads / 64; w++) { if (w < wid) base += s_part[w]; total_new += s_part[w]; }
@@ -562,7 +574,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         pos++;
       }
     }
-    __syncthreads();
+    lds_barrier();
     BPROF(1);
     // members: repeated-character share (:386-387), next_step (:337-342), score
     for (int i = tid; i < n; i += kThreads) {
@@ -572,7 +584,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       A.npnb[i] = pnb;
       key[i] = beam_score(p, pnb, A.npb[i], A.lm[i]);
     }
-    __syncthreads();
+    lds_barrier();
     BPROF(2);
     const int ntot = n + total_new;
     const int nsel = ntot > W ? W : ntot;
@@ -585,7 +597,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       // practice, six at most.  Two histograms alternate (the idle one is cleared while the other is scanned).
       for (int h = tid; h < 2 * kSelBins; h += kThreads) hist[h] = 0;
       if (tid == 0) { s_krem = W; s_done = 0; s_bin = 0; s_hi = 0u; s_lo = 0xffffffffu; }
-      __syncthreads();
+      lds_barrier();
       // Where to start: the threshold lies between the smallest score of a full beam's old members (W candidates are
       // at least that good) and the largest score of all, so it shares their common leading bits -- found on the keys'
       // high words with two cheap reductions.  Starting below them, the first digit already spreads the candidates
@@ -601,13 +613,13 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         lo = ~((unsigned)wave_max_i((int)((~lo) ^ 0x80000000u)) ^ 0x80000000u);
         if (lane == 0) { atomicMax(&s_hi, hi); atomicMin(&s_lo, lo); }
       }
-      __syncthreads();
+      lds_barrier();
       const unsigned H32 = s_hi, L32 = n == W ? s_lo : 0u;
       const unsigned xdiff = H32 ^ L32;
       const int hb = xdiff ? 63 - __builtin_clz(xdiff) : 31;                    // highest bit that may differ
       unsigned long long mask = hb == 63 ? 0ULL : ~0ULL << (hb + 1);
       if (tid == 0) s_prefix = ((unsigned long long)H32 << 32) & mask;
-      __syncthreads();
+      lds_barrier();
       int shift = hb + 1 - kSelBits;                                            // >= 21
       for (int pass = 0;; pass++) {
         int* hcur = hist + (pass & 1) * kSelBins;
@@ -620,7 +632,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
           const unsigned long long u = okey(key[d]);
           if ((u & mask) == prefix) atomicAdd(&hcur[(int)((u >> shift) & dmask)], 1);
         }
-        __syncthreads();
+        lds_barrier();
         const unsigned long long digit_mask = dmask << shift;
         if (wid == 0) {
           // lane l owns the 32 digits 2047-32l .. 2016-32l (descending); find the digit where the running count reaches k
@@ -648,7 +660,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
           for (int h = tid - 64; h < kSelBins; h += kThreads - 64) hnext[h] = 0;
         }
         mask |= digit_mask;
-        __syncthreads();
+        lds_barrier();
         if (s_done || shift == 0 || s_bin <= kSelSmall) break;
         shift = shift - kSelBits > 0 ? shift - kSelBits : 0;
       }
@@ -668,7 +680,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       for (int d = d0; d < d1; d++) { const unsigned long long u = OKEY_CMP(okey(key[d])); ngt += u > Tk; neq += u == Tk; }
       const int ig = wave_scan_i(ngt), ie = wave_scan_i(neq);
       if (lane == 63) { s_part[wid] = ig; s_part[16 + wid] = ie; }
-      __syncthreads();
+      lds_barrier();
       int bg = 0, be = 0, tg = 0;
       for (int w = 0; w < kThreads / 64; w++) { if (w < wid) { bg += s_part[w]; be += s_part[16 + w]; } tg += s_part[w]; }
       int og = bg + ig - ngt, oe = be + ie - neq;
@@ -683,7 +695,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       }
 #undef OKEY_CMP
       if (small_bin) {
-        __syncthreads();
+        lds_barrier();
         if (wid == 0) {
           // the best krem of the bin's g <= 64 candidates: one per lane, rank by counting
           const int g = s_bin;
@@ -698,12 +710,12 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
           if (lane < g && rank < krem) { skey[tg + rank] = myk; sidx[tg + rank] = myd; }
         }
       }
-      __syncthreads();
+      lds_barrier();
       BPROF(8);
       // ---- order the survivors: (score desc, position asc), rank by counting with every thread ----
       {
         for (int e = tid; e < W; e += kThreads) hist[e] = 0;            // (glist is dead; W <= kSelBins, checked by the host)
-        __syncthreads();
+        lds_barrier();
         const int P = kThreads / W > 0 ? kThreads / W : 1;              // threads per survivor
         for (int e = tid / P; e < W; e += kThreads / P) {
           const int part = tid % P;
@@ -717,13 +729,13 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
           }
           if (cnt) atomicAdd(&hist[e], cnt);
         }
-        __syncthreads();
+        lds_barrier();
         for (int e = tid; e < W; e += kThreads) sel[hist[e]] = sidx[e];
       }
-      __syncthreads();
+      lds_barrier();
     } else {
       for (int j = tid; j < ntot; j += kThreads) sel[j] = j;                      // unchanged order: old members, then new
-      __syncthreads();
+      lds_barrier();
     }
     BPROF(3);
     // ---- rebuild the beam in the other member set ----
@@ -768,14 +780,16 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       int k = A.node[i], par = A.par[i], lc = A.last[i];
       bool known = true;                             // (par, lc) of k are at hand
       while (k >= 0) {
+        int2 pl = make_int2(par, lc);
+        if (!known) pl = *reinterpret_cast<const int2*>(&nodes[k]);         // requested together with the atomic
         if (atomicSub(&nodes[k].refs, 1) != 1) break;
-        if (!known) { const BeamNode nd = nodes[k]; par = nd.parent; lc = nd.last_char; }
+        par = pl.x; lc = pl.y;
         if (par >= 0) { const int pi = mapA.find(par); if (pi >= 0) ctab[A.tab[pi] * V + lc] = -1; }   // weak_ptr expires
         k = par; known = false;
       }
     }
     __threadfence_block();
-    __syncthreads();
+    lds_barrier();
     BPROF(5);
     // ---- new members get a child table ----
     for (int j = tid; j < nsel; j += kThreads) {
@@ -797,7 +811,8 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
 
   // ---- final sort (:418-424) reduces to the best prefix; its sentence (:232-245) ----
   {
-    Members& A = M[cur];
+    Members A;
+    A.carve(mem0 + (size_t)cur * mbytes, W);
     for (int i = tid; i < n; i += kThreads) key[i] = beam_score(p, A.ppnb[i], A.ppb[i], A.lm[i]);
     __syncthreads();
   }
@@ -808,7 +823,9 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   if (tid == 0) {
     int bi = 0;
     for (int i = 1; i < n; i++) if (key[i] > key[bi]) bi = i;            // first maximum = (score desc, position asc)
-    const int best = M[cur].node[bi];
+    Members A;
+    A.carve(mem0 + (size_t)cur * mbytes, W);
+    const int best = A.node[bi];
     int64_t m = 0;
     for (int k = best; k >= 0; k = nodes[k].parent) if (k == best || nodes[k].parent >= 0) m++;
     int64_t at = m;
