@@ -414,6 +414,11 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 // while the other half is in use (steps 4..7 of block n at the start of block n, steps 0..3 of block n+1 at step 4
 // of block n), every read being issued four steps before its first use; (c) the steady blocks have a loop of their
 // own, one straight-line body without liveness tests.
+// (d) the row is kept in a form that needs 4 instead of 5 multiply-adds per label pair: a blank cell is held BEFORE its
+// emission (B~ = B / y_t[blank]) and a label cell pre-multiplied by the tilt (L^ = r L), so that
+//     B~' = B~ * yb + L^prev                         (yb: blank probability of the frame just processed)
+//     L^' = (L^ + (r^2 yb) * B~ + skip * L^prev) * y'[label]
+// -- the same recurrence, with the blank emission applied one step late.  Checkpoints and log Z convert back.
 template <int PPL, int DIR>
 __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, int S, const F1Lds& lds, int lane) {
   constexpr int NC = 2 * PPL;
@@ -433,9 +438,11 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
   for (int r = 0; r < PPL; r++) sk[r] = DIR == 0 ? (double)lc.skp[r] : (double)lc.skn[r];
   const bool cond = (T > 1 || L == 1);            // ctc_loss.cpp:39,76
 
-  double c[NC];                                    // the row: c[2r] blank cell 2i, c[2r+1] label cell 2i+1
+  double c[NC];                                    // the row: c[2r] = B~ of blank cell 2i, c[2r+1] = L^ of label cell 2i+1
 #pragma unroll
   for (int k = 0; k < NC; k++) c[k] = 0.0;
+  double yb_prev = 0.0;                            // blank probability of the frame processed last
+  const double rr2 = rr * rr, inv_rr = 1.0 / rr;
   int e_pending = 0;                               // exponent measured one step earlier
   int e_total = 0;                                 // sum of removed exponents
   float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
@@ -489,14 +496,15 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
         if (DIR == 0) {
           // alpha_t[j] = (alpha[j] + r*alpha[j-1] + r^2*skip*alpha[j-2]) * y_t[l_j], ctc_loss.cpp:47-60
           if (first) {
-            if (lane == 0) { c[0] = cond ? yb[tt] : 0.0; c[1] = rr * e[tt][0]; }   // ctc_loss.cpp:39-42
+            if (lane == 0) { c[0] = cond ? 1.0 : 0.0; c[1] = rr2 * e[tt][0]; }     // ctc_loss.cpp:39-42
           } else {
             double pl = from_prev_lane(c[NC - 1]);        // label cell just below this lane's first blank
+            const double w = rr2 * yb_prev;
 #pragma unroll
             for (int r = 0; r < PPL; r++) {
               const double ob = c[2 * r], ol = c[2 * r + 1];
-              c[2 * r] = (ob + rr * pl) * yb[tt];
-              c[2 * r + 1] = (ol + rr * ob + sk[r] * pl) * e[tt][r];
+              c[2 * r] = ob * yb_prev + pl;
+              c[2 * r + 1] = (ol + w * ob + sk[r] * pl) * e[tt][r];
               pl = ol;
             }
           }
@@ -506,20 +514,22 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
 #pragma unroll
             for (int r = 0; r < PPL; r++) {
               const int i = PPL * lane + r;
-              if (2 * i == L - 1 && cond) c[2 * r] = yb[tt];             // ctc_loss.cpp:76
-              if (2 * i + 1 == L - 2) c[2 * r + 1] = rr * e[tt][r];      // ctc_loss.cpp:78
+              if (2 * i == L - 1 && cond) c[2 * r] = 1.0;                 // ctc_loss.cpp:76
+              if (2 * i + 1 == L - 2) c[2 * r + 1] = rr2 * e[tt][r];      // ctc_loss.cpp:78
             }
           } else {
             double nb = from_next_lane(c[0]), nl = from_next_lane(c[1]);   // next lane's first blank / label
+            const double w = rr2 * yb_prev;
 #pragma unroll
             for (int r = PPL - 1; r >= 0; r--) {
               const double ob = c[2 * r], ol = c[2 * r + 1];
-              c[2 * r + 1] = (ol + rr * nb + sk[r] * nl) * e[tt][r];
-              c[2 * r] = (ob + rr * ol) * yb[tt];
+              c[2 * r + 1] = (ol + w * nb + sk[r] * nl) * e[tt][r];
+              c[2 * r] = ob * yb_prev + ol;
               nb = ob; nl = ol;
             }
           }
         }
+        yb_prev = yb[tt];
         // power-of-two rescale: measure the row's exponent at position 6 of the block, remove it at position 7
         // (alpha: t%8 == 6 / 7, beta: t%8 == 1 / 0)
         if (tt == 7) {
@@ -534,13 +544,16 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
           if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
             // block floating point: each lane stores its cells scaled by its own exponent (f32 keeps every
             // lane's cells however far apart the lanes' magnitudes are)
+            double cell[NC];                       // the true cells: blank with its emission, label without the tilt
+#pragma unroll
+            for (int r = 0; r < PPL; r++) { cell[2 * r] = c[2 * r] * yb_prev; cell[2 * r + 1] = c[2 * r + 1] * inv_rr; }
             int m = 0;
 #pragma unroll
-            for (int k = 0; k < NC; k++) m = max(m, __double2hiint(c[k]));
+            for (int k = 0; k < NC; k++) m = max(m, __double2hiint(cell[k]));
             const int own = m > 0 ? ((m >> 20) & 0x7ff) - 1023 : -30000;
             float* dst = ck + (size_t)(kk / kSeg) * p.CELLS + lane * NC;
 #pragma unroll
-            for (int k = 0; k < NC; k++) dst[k] = m > 0 ? (float)ldexp(c[k], -own) : 0.f;
+            for (int k = 0; k < NC; k++) dst[k] = m > 0 ? (float)ldexp(cell[k], -own) : 0.f;
             p.ckE[(((size_t)b * p.NS + kk / kSeg) * 2 + DIR) * 64 + lane] = (short)own;
           }
         } else if (tt == 6) {
@@ -575,11 +588,11 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
 #pragma unroll
     for (int k = 0; k < NC; k++) {
       const int j = NC * lane + k;
-      if (j == L - 1) z += c[k];                          // ctc_loss.cpp:63-70, un-tilted relative to cell L-1
-      if (j == L - 2) z += rr * c[k];
+      if (j == L - 1) z += c[k] * yb_prev;                // ctc_loss.cpp:63-70, un-tilted relative to cell L-1
+      if (j == L - 2) z += c[k];                          // (= r * the label cell)
     }
   } else if (lane == 0) {
-    z = (cond ? c[0] : 0.0) + rr * c[1];                  // sum_j alpha_0[j]*beta_0[j]
+    z = (cond ? c[0] * yb_prev : 0.0) + c[1];             // sum_j alpha_0[j]*beta_0[j]
   }
 #ifdef E2E_FAST_PROFILE
   if (lane == 0 && b < 256) { g_prof[(b * 4 + DIR) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + DIR) * 4 + 1] = prof_spin;
