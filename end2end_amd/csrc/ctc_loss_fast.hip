@@ -287,7 +287,9 @@ struct LaneCells {
 // width), so the per-lane gather is arranged to pull 4 consecutive time steps of the lane's label per instruction:
 // 2 reads per label cell and block instead of 8, and the producers need no gather at all.
 struct F1Lds {
-  double* ring;      // [2][kRingBlks][V+1][kRow]  (f64: the chains would otherwise spend 15% of their issue slots converting)
+  double* ring;      // [2][kRingBlks][V+1][kRow]  (f64: saves the chains' conversions, 2.5 % of the step at B = 256.  It
+                     //  costs them 30 VGPRs, though: at 146 a second workgroup does not fit on the CU, which an f32 ring
+                     //  (114) allows -- measured +7 % at B = 1024 with the second workgroup's roles rotated onto SIMDs 1/3)
   int* filled;       // [2][kRingBlks]   probability block n of a direction is complete (== n+1)
   int* took;         // [2]              the direction's chain has read the probabilities of blocks < took
   int* sortcnt;      // [130] counting-sort scratch of the cell-info wave
