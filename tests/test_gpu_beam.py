@@ -46,6 +46,22 @@ def test_random_no_lm_matches_oracle(W, wip):
     same_as_oracle(lp.float(), None, 0, W, None, wip=wip)                      # f32 input, no labels
 
 
+@pytest.mark.parametrize("W", [4, 70, 100])
+def test_massive_ties_are_broken_by_position_like_the_oracle(W):
+    # constant / two-valued emissions: most candidates of a step have EXACTLY equal scores, so the selection's
+    # tie handling (threshold bin taken whole, first-by-position among exact ties, the one-wave finish of a small bin)
+    # decides which prefixes survive; the oracle keeps (score desc, position asc)
+    labels = ["_", "a", "b", "c", "d", "e", "f", "g", "h", " "]
+    V = len(labels)
+    flat = torch.full((2, 9, V), float(np.log(1.0 / V)), dtype=torch.float64)
+    same_as_oracle(flat, [9, 6], 0, W, labels, wip=0.0)
+    two = torch.log(torch.tensor([0.3] + [0.7 / (V - 1)] * (V - 1), dtype=torch.float64)).repeat(2, 9, 1)
+    same_as_oracle(two, [9, 7], 0, W, labels, wip=1.0)
+    # ... and with impossible symbols (-inf) in the mix
+    holes = flat.clone(); holes[:, :, 3] = float("-inf"); holes[:, ::2, 5] = float("-inf")
+    same_as_oracle(holes, [9, 9], 0, W, labels, wip=0.0)
+
+
 def test_speech_shape_beam100_matches_oracle():
     labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
     lp = rand_lp(7, 3, 120, 29, sharp=3.0)

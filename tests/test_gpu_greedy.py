@@ -25,7 +25,8 @@ def test_known_answers(case):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-@pytest.mark.parametrize("shape", [(7, 300, 29), (3, 1500, 29), (4, 70, 5), (3, 40, 200), (2, 33, 8000), (5, 1, 3)])
+@pytest.mark.parametrize("shape", [(7, 300, 29), (3, 1500, 29), (4, 70, 5), (3, 40, 200), (2, 33, 8000), (5, 1, 3),
+                                   (3, 600, 32), (2, 257, 64), (3, 300, 30)])      # even alphabets: padded LDS rows
 def test_random_bit_exact(shape, dtype):
     g = torch.Generator().manual_seed(sum(shape))
     B, T, V = shape
