@@ -864,8 +864,14 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
     // exponent drop to 3 bits per cell (kSlope per lane) bounds the worst growth over a segment by 2^96.  A lane
     // whose own cells lie further below its left neighbour than that takes the neighbour's unit minus kSlope and
     // keeps its cells as small numbers (still exact down to 2^-126 of that unit).
-    // (eA_n = max_{m <= n} (own_m - kSlope*(n - m)): a prefix maximum of own_m + kSlope*m)
-    eA = wave_scan_max(own + kSlope * lane) - kSlope * lane;
+    // (eA_n = max_{m <= n} (own_m - kSlope*(n - m)): a prefix maximum of own_m + kSlope*m.)  Lanes whose cells are all
+    // zero -- above the band's upper edge early in an utterance -- take the unit of the last non-zero lane below them
+    // instead of sliding down kSlope bits per lane: the mass that reaches them within the segment fits that unit, and
+    // the beta rows, which live in the reciprocal units, are not pushed 24 bits per lane towards underflow.
+    const bool nz = own > -30000;
+    const int pmax = wave_scan_max(nz ? own + kSlope * lane : -0x20000000);
+    const int mstar = wave_scan_max(nz ? lane : -1);
+    eA = mstar >= 0 ? pmax - kSlope * mstar : own;
     const int sh = max(own - eA, -200);
 #pragma unroll
     for (int k = 0; k < NC; k++) a[k] = ldexpf(a[k], sh);

@@ -1,0 +1,50 @@
+"""Randomised parity sweep on the GPU: the fast path (E2E_ALGO_FAST, no fallback) against the exact f64-log-domain kernel
+(E2E_ALGO_EXACT, itself pinned to the oracle by the tests) over random shapes, lengths, alphabets, blank positions and
+emission sharpness.  Utterances the fast path flags (NaN) are counted, not compared.  Prints the worst deviations."""
+import sys, os
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np, torch
+import gpu_util as U
+from end2end_amd import _lib
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dense = len(sys.argv) > 3 and sys.argv[3] == 'dense'
+verbose = os.environ.get('FUZZ_VERBOSE') == '1'       # target lengths close to the input lengths
+worst_l, worst_g, flagged, total = 0.0, 0.0, 0, 0
+import collections
+tally = collections.Counter(); feas = collections.Counter()
+for case in range(n_cases):
+    B = int(rng.integers(1, 9)); T = int(rng.integers(1, 700)); V = int(rng.integers(2, 97))
+    Smax = int(rng.integers(0, min(255, T) + 1))
+    if dense and T > 4: Smax = int(min(255, max(1, T * rng.uniform(0.45, 0.98))))
+    sharp = float(rng.choice([0.1, 1.0, 3.0] if dense else [0.1, 1.0, 3.0, 8.0, 20.0]))
+    fused = bool(rng.integers(0, 2)); blank = int(rng.choice([0, V - 1, rng.integers(0, V)]))
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn(B, T, V, generator=g) * sharp
+    if not fused: x = torch.log_softmax(x.double(), -1).float()
+    labs = [v for v in range(V) if v != blank]
+    tg = torch.tensor(rng.choice(labs, size=(B, max(Smax, 1))), dtype=torch.long)
+    xl = torch.tensor(rng.integers(1, T + 1, size=B)); xl[0] = T
+    tl = torch.tensor(rng.integers(Smax // 2 if dense else 0, Smax + 1, size=B)); tl[0] = Smax
+    le, ge = U.c_abi_loss(x, tg[:, :max(Smax, 1)], xl, tl, blank, not fused, _lib.ALGO_EXACT)
+    lf, gf = U.c_abi_loss(x, tg[:, :max(Smax, 1)], xl, tl, blank, not fused, _lib.ALGO_FAST)
+    for b in range(B):
+        total += 1
+        if np.isfinite(le[b]): feas[(sharp, "S/T>=.6" if float(tl[b]) / float(xl[b]) >= 0.6 else "S/T<.6")] += 1
+        if np.isnan(lf[b]):
+            flagged += 1
+            key = (sharp, "S/T>=.6" if float(tl[b]) / float(xl[b]) >= 0.6 else "S/T<.6")
+            if np.isfinite(le[b]): tally[key] += 1
+            if np.isfinite(le[b]) and verbose: print("case %d utt %d: flagged but feasible (B=%d T=%d V=%d S=%d sharp=%g xl=%d tl=%d)" % (case, b, B, T, V, Smax, sharp, xl[b], tl[b]))
+            continue
+        dl = abs(float(lf[b]) - float(le[b])) / max(1.0, abs(float(le[b])))
+        dg = float(np.abs(gf[b].astype(np.float64) - ge[b].astype(np.float64)).max())
+        if dg > 2e-5:
+            err = np.abs(gf[b].astype(np.float64) - ge[b].astype(np.float64)).max(-1)      # per frame
+            bad = np.nonzero(err > 2e-5)[0]
+            print("   frames with error: %d of %d, first %d last %d; by segment: %s" % (len(bad), int(xl[b]), bad[0], bad[-1], sorted(set((bad // 16).tolist()))[:12]))
+        if dl > 1e-4 or dg > 2e-5: print("case %d utt %d: loss rel %.2e grad abs %.2e (B=%d T=%d V=%d S=%d sharp=%g fused=%d blank=%d xl=%d tl=%d)" % (case, b, dl, dg, B, T, V, Smax, sharp, fused, blank, xl[b], tl[b]))
+        worst_l, worst_g = max(worst_l, dl), max(worst_g, dg)
+print("%d utterances in %d cases: %d flagged by the fast path; worst loss rel %.2e, worst grad abs %.2e" % (total, n_cases, flagged, worst_l, worst_g))
+for k in sorted(feas): print("  sharp %-4g %-8s feasible %4d, flagged by the fast path %4d" % (k[0], k[1], feas[k], tally[k]))
