@@ -1,0 +1,49 @@
+"""Randomised parity sweep of the GPU prefix beam search against the oracle (CPU restatement of the reference): random
+shapes, beam widths, blank / space positions, word-insertion penalties, tie-heavy (rounded) and -inf-holed emissions,
+ragged lengths, with and without the tiny 3-gram LM.  Every utterance must decode to exactly the oracle's label sequence."""
+import sys, os
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np, torch
+import gpu_util as U, oracle_lib as O
+from end2end_amd.engines import LanguageModel
+ARPA = os.path.join(root, "tests", "golden", "tiny_3gram.arpa")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for case in range(n_cases):
+    with_lm = bool(rng.integers(0, 4) == 0)
+    B = int(rng.integers(1, 5)); T = int(rng.integers(1, 70))
+    if with_lm:
+        labels = ["_", "a", "b", " "]; V = 4; blank = 0
+        cs = bool(rng.integers(0, 2))
+        lm = LanguageModel(ARPA, labels, cs); olm = O.OracleLM(ARPA)
+        kw = dict(lmwt=float(rng.choice([0.5, 1.0, 2.0])), wip=float(rng.choice([0.0, 1.0])), oov_penalty=float(rng.choice([-1000.0, -3.0])), case_sensitive=cs)
+    else:
+        V = int(rng.integers(2, 14)); blank = int(rng.choice([0, V - 1, rng.integers(0, V)]))
+        alphabet = list("abcdefghijklm")
+        labels = [alphabet[i] for i in range(V)]
+        labels[blank] = "_"
+        if V > 2 and rng.integers(0, 2): labels[int(rng.choice([i for i in range(V) if i != blank]))] = " "
+        lm = olm = None
+        kw = dict(wip=float(rng.choice([0.0, 1.0, 2.5])))
+    W = int(rng.choice([1, 2, 3, 5, 16, 40, 64, 65, 100, 128, 200]))
+    if W * V + W + 8 > 8192: W = 100
+    sharp = float(rng.choice([0.3, 1.0, 3.0]))
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn(B, T, V, generator=g, dtype=torch.float64) * sharp
+    style = int(rng.integers(0, 4))
+    if style == 1: x = x.round()                       # many exact ties
+    if style == 2: x = torch.zeros_like(x)             # everything ties
+    lp = torch.log_softmax(x, -1)
+    if style == 3 and V > 2: lp[:, ::3, int(rng.integers(0, V))] = float("-inf")
+    xl = rng.integers(1, T + 1, size=B).tolist(); xl[0] = T
+    gpu_kw = {k: v for k, v in kw.items() if k != "case_sensitive"}
+    if rng.integers(0, 2): lp_in = lp.float(); lp_ref = lp_in.double()
+    else: lp_in = lp; lp_ref = lp
+    ids, lens = U.c_abi_beam(lp_in, xl, blank, W, labels, lm, **gpu_kw)
+    o_ids, o_lens, _ = O.ctc_beam(lp_ref.numpy(), xl, blank, W, labels, olm, **kw)
+    if lens.tolist() != o_lens.tolist() or ids.tolist() != o_ids.tolist():
+        bad += 1
+        print("MISMATCH case %d: B=%d T=%d V=%d W=%d blank=%d style=%d lm=%d kw=%s xl=%s" % (case, B, T, V, W, blank, style, with_lm, kw, xl))
+print("%d cases, %d mismatches" % (n_cases, bad))

@@ -9,14 +9,21 @@ import gpu_util as U
 from end2end_amd import _lib
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-dense = len(sys.argv) > 3 and sys.argv[3] == 'dense'
-verbose = os.environ.get('FUZZ_VERBOSE') == '1'       # target lengths close to the input lengths
+mode = sys.argv[3] if len(sys.argv) > 3 else ''
+dense = mode == 'dense'        # target lengths close to the input lengths
+edges = mode == 'edges'        # short inputs, target lengths around the lane-packing boundaries
+wide = mode == 'wide'          # alphabets beyond the lattice kernels' 96 columns (compaction path)
+verbose = os.environ.get('FUZZ_VERBOSE') == '1'
 worst_l, worst_g, flagged, total = 0.0, 0.0, 0, 0
 import collections
 tally = collections.Counter(); feas = collections.Counter()
 for case in range(n_cases):
     B = int(rng.integers(1, 9)); T = int(rng.integers(1, 700)); V = int(rng.integers(2, 97))
+    if wide: V = int(rng.choice([97, 128, 500, 1000, 3001])); T = int(rng.integers(1, 200))
+    if edges and rng.integers(0, 2): T = int(rng.integers(1, 48))
     Smax = int(rng.integers(0, min(255, T) + 1))
+    if wide: Smax = min(Smax, 90)             # (more distinct labels than 95 + blank do not fit the lattice kernels)
+    if edges and T >= 70: Smax = int(min(T, rng.choice([62, 63, 64, 65, 126, 127, 128, 129, 254, 255])))
     if dense and T > 4: Smax = int(min(255, max(1, T * rng.uniform(0.45, 0.98))))
     sharp = float(rng.choice([0.1, 1.0, 3.0] if dense else [0.1, 1.0, 3.0, 8.0, 20.0]))
     fused = bool(rng.integers(0, 2)); blank = int(rng.choice([0, V - 1, rng.integers(0, V)]))
