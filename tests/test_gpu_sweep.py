@@ -1,0 +1,53 @@
+"""-m gpu: small randomised sweeps (fixed seeds) of the fast path against the exact kernel, which the other tests pin to
+the oracle.  The long versions live in tools/diag/fuzz_*.py; a sweep like this found the dense-target bug of round 1."""
+import numpy as np
+import pytest
+import torch
+
+import gpu_util as U
+from end2end_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _sweep(seed, n_cases, mode):
+    rng = np.random.default_rng(seed)
+    compared = 0
+    for _ in range(n_cases):
+        B = int(rng.integers(1, 7)); T = int(rng.integers(1, 500)); V = int(rng.integers(2, 97))
+        if mode == "wide":
+            V = int(rng.choice([97, 200, 1500])); T = int(rng.integers(1, 120))
+        Smax = int(rng.integers(0, min(255, T) + 1))
+        if mode == "dense" and T > 4:
+            Smax = int(min(255, max(1, T * rng.uniform(0.45, 0.98))))
+        if mode == "edges":
+            T = int(rng.integers(1, 48)) if rng.integers(0, 2) else int(rng.integers(130, 400))
+            Smax = int(min(T, rng.choice([0, 1, 62, 63, 64, 65, 126, 127, 128, 129, 254, 255])))
+        if mode == "wide":
+            Smax = min(Smax, 90)
+        sharp = float(rng.choice([0.1, 1.0, 3.0]))
+        fused = bool(rng.integers(0, 2)); blank = int(rng.choice([0, V - 1, rng.integers(0, V)]))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(B, T, V, generator=g) * sharp
+        if not fused:
+            x = torch.log_softmax(x.double(), -1).float()
+        labs = [v for v in range(V) if v != blank]
+        tg = torch.tensor(rng.choice(labs, size=(B, max(Smax, 1))), dtype=torch.long)
+        xl = torch.tensor(rng.integers(1, T + 1, size=B)); xl[0] = T
+        tl = torch.tensor(rng.integers(Smax // 2 if mode == "dense" else 0, Smax + 1, size=B)); tl[0] = Smax
+        le, ge = U.c_abi_loss(x, tg, xl, tl, blank, not fused, _lib.ALGO_EXACT)
+        lf, gf = U.c_abi_loss(x, tg, xl, tl, blank, not fused, _lib.ALGO_FAST)
+        for b in range(B):
+            if np.isnan(lf[b]):
+                continue                                     # the fast path gave up: AUTO would take the exact result
+            compared += 1
+            what = "mode %s B=%d T=%d V=%d S=%d fused=%d blank=%d utt %d (xl=%d tl=%d)" % (
+                mode, B, T, V, Smax, fused, blank, b, int(xl[b]), int(tl[b]))
+            assert abs(float(lf[b]) - float(le[b])) <= 1e-4 * max(1.0, abs(float(le[b]))), what
+            np.testing.assert_allclose(gf[b], ge[b], rtol=1e-4, atol=2e-6, err_msg=what)
+    return compared
+
+
+@pytest.mark.parametrize("mode,seed,n", [("general", 101, 40), ("dense", 102, 40), ("edges", 103, 60), ("wide", 104, 25)])
+def test_fast_path_agrees_with_exact_kernel(mode, seed, n):
+    assert _sweep(seed, n, mode) > n // 2
