@@ -914,6 +914,17 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
           pl = ol;
         }
       }
+      if ((tt & 7) == 6) {
+        // health of the recomputed row at its smallest (just before F1's rescale is replayed): the lane that holds
+        // the row's largest cell must hold it as a comfortably normal f32 -- with emissions that contradict the
+        // targets a row can lose 2^-20 per step and drown within the 8 steps between two rescales
+        float lm = a[0];
+#pragma unroll
+        for (int k = 1; k < NC; k++) lm = fmaxf(lm, a[k]);
+        const int key = eA + (lm > 0.f ? (int)((__float_as_uint(lm) >> 23) & 0xffu) - 127 : -300);
+        const int top = wave_max(key);
+        if (__any(key == top && lm < 0x1p-90f)) smin = 0.f;
+      }
       if ((tt & 7) == 7) {             // t0 is a multiple of 16: t & 7 == tt & 7
         const int e = tt == 7 ? eA7 : eA15;
         if (e != 0) {
@@ -937,9 +948,24 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
 #pragma unroll
     for (int k = 0; k < NC; k++) q[k] = in.q[k];
     const int ownB = in.ownB;
-    const int E = eA + ownB;
-    const int emax = wave_max(E);
-    const int sh = max(E - emax, -200);
+    // The common unit of alpha*beta is taken where the two rows actually meet: the alpha row at the segment's LAST
+    // step (it is in registers) against the beta checkpoint of the same time.  (eA alone describes alpha at the
+    // segment's first step; with sharply peaked rows that move two cells per step the mass sits up to four lanes
+    // further on by the end, and a unit derived from the start row would be off by the full dynamic range --
+    // sum alpha*beta then left f32 and the utterance was handed to the exact kernel for nothing.)
+    float a_end = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; k++) a_end = fmaxf(a_end, A[kSeg - 1][k]);          // (this branch: n == 16)
+    // (a lane whose alpha cells have sunk to the denormal range carries no precision: it must not define the unit)
+    const int e_end = a_end >= 0x1p-120f ? (int)((__float_as_uint(a_end) >> 23) & 0xffu) - 127 : -200;
+    const int emax = wave_max(eA + ownB + e_end);
+    const int want = eA + ownB - emax;
+    const int sh = min(max(want, -200), 120);
+    // (a lane whose beta cells would need more than 2^120 in this unit while it still holds beta mass: out of range)
+    float q_any = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; k++) q_any = fmaxf(q_any, q[k]);
+    if (__any(want > 120 && q_any > 0.f)) smax = __builtin_huge_valf();
 #pragma unroll
     for (int k = 0; k < NC; k++) q[k] = ldexpf(q[k], sh);
   } else {
@@ -1096,9 +1122,16 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
   if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, in, lds, lane, smin, smax);
   else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, in, lds, lane, smin, smax);
+#ifdef E2E_FAST_PROFILE
+  if (lane == 0) s_prof_acc[7] = ((unsigned long long)__float_as_uint(smin) << 32) | __float_as_uint(smax);
+#endif
   F2_FLUSH
   // range check: everything that carries posterior mass was representable (see the header comment)
   const bool finite_ok = smax < __builtin_huge_valf();
+  // (2^-90 is not the edge of f32 but a margin: a row sum that small means its terms are products of factors that
+  // are themselves close to the denormal range.  A randomised sweep with 2^-110 let gradients through that were
+  // off by 2e-3.  Rows between F1's rescales legitimately sit 2^-40 .. 2^-80 below the unit: alpha is rescaled at
+  // t%8 == 7 and beta at t%8 == 0, so every row in between carries nine steps of decay.)
   if (!(smin >= 0x1p-90f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
   if (seg == 0 && lane == 0) {
     const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];

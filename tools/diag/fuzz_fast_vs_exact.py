@@ -7,6 +7,7 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np, torch
 import gpu_util as U
 from end2end_amd import _lib
+if os.environ.get('E2E_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['E2E_LIB'])
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 mode = sys.argv[3] if len(sys.argv) > 3 else ''
