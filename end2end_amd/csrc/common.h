@@ -29,6 +29,23 @@ struct LossArgs {
   hipStream_t stream;
 };
 
+// Exponential tilt of the fast path's scaled lattice (rows hold alpha[j] r^j and beta[j] r^(L-1-j)); shared by the
+// kernels that produce and that consume its checkpoints.  See LaneCells in ctc_loss_fast.hip.
+__host__ __device__ inline float fast_tilt(int S, int T) {
+  float rho = (float)S / (float)T;
+  rho = fminf(fmaxf(rho, 1.f / 33.f), 0.8f);
+  return S > 0 ? 2.f * rho / (1.f - rho) : 1.f;
+}
+constexpr int kFastSeg = 16;       // steps between two checkpoints of the fast path
+
+// What the flagged-utterance launch needs to redo only the SECOND kernel of the fast path in f64 (an utterance whose
+// f32 segment kernel ran out of range keeps its f64 chains' results: checkpoints, probabilities, loss).
+struct FastRetry {
+  const float* ytab; const float* ckA; const float* ckQ; const short* ckE; const short* escA; const short* escB;
+  const double* logz;              // [B][2] the chains' log Z (alpha side, beta side)
+  int NS, NB, CELLS, PPL;
+};
+
 size_t exact_workspace_bytes(int B, int T, int V, int Smax);            // every utterance (algo EXACT)
 size_t exact_fallback_workspace_bytes(int B, int T, int V, int Smax);   // flagged-utterance fallback of the fast path
 int launch_exact(const LossArgs& a);

@@ -11,6 +11,8 @@
 // sweep and one coalesced row read in the beta sweep.  LDS holds the extended
 // label row, the previous lattice row (double-buffered), the per-label
 // posterior accumulator post[V] and the label-sorted cell order.
+#include <string.h>
+
 #include "common.h"
 
 namespace e2e {
@@ -28,6 +30,7 @@ struct ExactParams {
   double* ws_lse;     // [B][T] row log-sum-exp (logits mode)
   const int* flags;   // per-utterance "redo me" words written by the fast path (mode != 0)
   int mode;           // 0: every utterance; 1: only flagged ones; 2: poison flagged ones, compute nothing
+  int has_retry; FastRetry retry;   // mode 1: the fast path's checkpoints, for the f64 redo of its second kernel
 };
 
 __device__ __forceinline__ double neg_inf() { return -__builtin_huge_val(); }
@@ -47,6 +50,200 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// f64 redo of the fast path's segment kernel for one utterance (flag bits 8 / 16: the f32 recompute left its range).
+// The chains' work stands -- loss, probabilities, alpha / beta checkpoints every 16 steps, all from f64 state -- so
+// only the 16-step segments are done again, in doubles: each of the 8 waves takes every 8th segment, recomputes its
+// alpha rows from the checkpoint into this workgroup's alpha slab, walks beta back through it, adds alpha*beta per
+// label with LDS f64 atomics and writes the gradient rows.  ~0.3 ms per utterance instead of the ~7 ms of the full
+// log-domain recomputation.  Returns false (-> exact path) if a row sum is still not a positive finite number.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_shift_up(double v) {      // lane n <- lane n-1, lane 0 <- 0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_shift_down(double v) {    // lane n <- lane n+1, lane 63 <- 0
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <typename IO, int PPL>
+__device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, int b, int slot) {
+  constexpr int NC = 2 * PPL, kSeg = kFastSeg;
+  const FastRetry& rt = p.retry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int V = p.V, blank = p.blank, Lmax = p.Lmax, Tmax = p.T;
+  const int T = (int)p.x_len[b], S = (int)p.t_len[b], L = 2 * S + 1;
+  const bool cond = (T > 1 || L == 1);
+  const double rr = (double)fast_tilt(S, T);
+  double* wa = p.ws_alpha + (size_t)slot * (size_t)Tmax * (size_t)Lmax;
+  IO* grads = reinterpret_cast<IO*>(p.grads) + (size_t)b * (size_t)Tmax * (size_t)V;
+  // per-wave LDS: post[16][V] per-label sums, then 16 row sums, 16 blank sums
+  double* post = reinterpret_cast<double*>(smem) + (size_t)wid * (kSeg * (V + 2));
+  double* rowsum = post + kSeg * V;
+  double* blanksum = rowsum + kSeg;
+  __shared__ int s_bad;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+
+  // this lane's pairs i = PPL*lane + r: label, skip permissions (ctc_loss.cpp:53-57, 91-96) -- as LaneCells::load
+  int lab[PPL]; double skp[PPL], skn[PPL];
+  const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
+#pragma unroll
+  for (int r = 0; r < PPL; r++) {
+    const int i = PPL * lane + r;
+    const int li = i < S ? (int)tg[i] : -1;
+    const int lp_ = (i >= 1 && i - 1 < S) ? (int)tg[i - 1] : -1;
+    const int ln = (i + 1 < S) ? (int)tg[i + 1] : -1;
+    lab[r] = i < S ? li : -1;
+    skp[r] = (i < S && i >= 1 && li != blank && lp_ != li) ? rr * rr : 0.0;
+    skn[r] = (i + 1 < S && li != blank && ln != li) ? rr * rr : 0.0;
+  }
+  const float* ytab = rt.ytab + (size_t)b * Tmax * V;
+  auto y = [&](int t, int v) -> double { return v >= 0 ? (double)ytab[(size_t)t * V + v] : 0.0; };
+  const short* escA = rt.escA + (size_t)b * rt.NB;
+  const short* escB = rt.escB + (size_t)b * rt.NB;
+  bool bad = false;
+  // Every row must reproduce the chains' log Z: sum_j alpha_t[j] beta_t[j] = Z r^(L-1) 2^-(EA(t) + EB(t)), with EA / EB
+  // the exponents the chains had removed by then.  It does not if the f32 checkpoints could not hold what mattered (their
+  // cells share one exponent per lane: a cell 2^-149 below its lane's largest is stored as zero) -- then the exact kernel.
+  const double logz = rt.logz[2 * b];
+  const double lz_tilt = (double)(L - 1) * log(rr);
+  const int nbk = (T + 7) / 8;
+
+  for (int seg = wid; seg * kSeg < T; seg += kThreads / 64) {
+    const int t0 = seg * kSeg, n = min(kSeg, T - t0);
+    for (int i = lane; i < kSeg * (V + 2); i += 64) post[i] = 0.0;
+    // ---- alpha rows of the segment into the slab (tilted cells, F1's units and rescales) ----
+    double a[NC];
+    if (seg == 0) {
+#pragma unroll
+      for (int k = 0; k < NC; k++) a[k] = 0.0;
+    } else {
+      const float* src = rt.ckA + ((size_t)b * rt.NS + seg) * rt.CELLS + lane * NC;
+      const int own = rt.ckE[(((size_t)b * rt.NS + seg) * 2 + 0) * 64 + lane];
+#pragma unroll
+      for (int k = 0; k < NC; k++) a[k] = own > -30000 ? ldexp((double)src[k], own) : 0.0;
+    }
+    for (int tt = 0; tt < n; tt++) {
+      const int t = t0 + tt;
+      const double yb = y(t, blank);
+      if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) a[k] = 0.0;
+        if (lane == 0) { a[0] = cond ? yb : 0.0; a[1] = rr * y(0, lab[0]); }
+      } else {
+        double pl = lane_shift_up(a[NC - 1]);
+#pragma unroll
+        for (int r = 0; r < PPL; r++) {
+          const double ob = a[2 * r], ol = a[2 * r + 1];
+          a[2 * r] = (ob + rr * pl) * yb;
+          a[2 * r + 1] = (ol + rr * ob + skp[r] * pl) * y(t, lab[r]);
+          pl = ol;
+        }
+      }
+      if ((t & 7) == 7) {
+        const int e = escA[t >> 3];
+        if (e != 0) {
+#pragma unroll
+          for (int k = 0; k < NC; k++) a[k] = ldexp(a[k], -e);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NC; k++) { const int j = NC * lane + k; if (j < Lmax) wa[(size_t)t * Lmax + j] = a[k]; }
+    }
+    // ---- beta back through the segment ----
+    double q[NC];
+    const bool last_seg = (t0 + n == T);
+    if (!last_seg) {
+      const float* src = rt.ckQ + ((size_t)b * rt.NS + seg + 1) * rt.CELLS + lane * NC;
+      const int own = rt.ckE[(((size_t)b * rt.NS + seg + 1) * 2 + 1) * 64 + lane];
+#pragma unroll
+      for (int k = 0; k < NC; k++) q[k] = own > -30000 ? ldexp((double)src[k], own) : 0.0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < NC; k++) q[k] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this wave's alpha rows (and the zeroed sums) first
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int tt = n - 1; tt >= 0; tt--) {
+      const int t = t0 + tt;
+      double bs[NC];
+      if (t == T - 1) {
+#pragma unroll
+        for (int r = 0; r < PPL; r++) {
+          const int i = PPL * lane + r;
+          bs[2 * r] = (2 * i == L - 1 && cond) ? 1.0 : 0.0;
+          bs[2 * r + 1] = (2 * i + 1 == L - 2) ? rr : 0.0;
+        }
+      } else {
+        double nb = lane_shift_down(q[0]), nl = lane_shift_down(q[1]);
+#pragma unroll
+        for (int r = PPL - 1; r >= 0; r--) {
+          bs[2 * r + 1] = q[2 * r + 1] + rr * nb + skn[r] * nl;
+          bs[2 * r] = q[2 * r] + rr * q[2 * r + 1];
+          nb = q[2 * r]; nl = q[2 * r + 1];
+        }
+      }
+      double mine = 0.0, myblank = 0.0;
+#pragma unroll
+      for (int r = 0; r < PPL; r++) {
+        const int j0 = NC * lane + 2 * r;
+        const double pa = j0 < Lmax ? wa[(size_t)t * Lmax + j0] * bs[2 * r] : 0.0;
+        const double pb = j0 + 1 < Lmax ? wa[(size_t)t * Lmax + j0 + 1] * bs[2 * r + 1] : 0.0;
+        myblank += pa; mine += pa + pb;
+        if (lab[r] >= 0 && lab[r] < V && pb != 0.0) atomicAdd(&post[tt * V + lab[r]], pb);
+      }
+      mine = wave_sum(mine); myblank = wave_sum(myblank);
+      if (lane == 0) { rowsum[tt] = mine; blanksum[tt] = myblank; }
+      const double yb = y(t, blank);
+#pragma unroll
+      for (int r = 0; r < PPL; r++) {
+        q[2 * r] = bs[2 * r] * yb;
+        q[2 * r + 1] = bs[2 * r + 1] * y(t, lab[r]);
+      }
+      if ((t & 7) == 0) {
+        const int e = escB[t >> 3];
+        if (e != 0) {
+#pragma unroll
+          for (int k = 0; k < NC; k++) q[k] = ldexp(q[k], -e);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    // ---- gradient rows: y - posterior ----
+    for (int tt = 0; tt < n; tt++) {
+      const double st = rowsum[tt];
+      if (!(st > 0.0) || !(st < __builtin_huge_val())) bad = true;
+      {
+        const int t = t0 + tt;
+        int EA = 0, EB = 0;
+        for (int m = lane; m < nbk; m += 64) {
+          if (8 * m + 7 <= t) EA += escA[m];
+          if (8 * m >= t + 1) EB += escB[m];
+        }
+        for (int o = 32; o > 0; o >>= 1) { EA += __shfl_xor(EA, o, 64); EB += __shfl_xor(EB, o, 64); }
+        const double lz_row = log(st) + (double)(EA + EB) * 0.693147180559945309417 - lz_tilt;
+        if (!(fabs(lz_row - logz) <= 1e-7 * fabs(logz) + 1e-5)) bad = true;
+      }
+      const double inv = 1.0 / st;
+      for (int v = lane; v < V; v += 64) {
+        double pv = post[tt * V + v];
+        if (v == blank) pv += blanksum[tt];
+        grads[(size_t)(t0 + tt) * V + v] = (IO)(y(t0 + tt, v) - pv * inv);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  if (__any(bad)) { if (lane == 0) atomicOr(&s_bad, 1); }
+  __syncthreads();
+  return s_bad == 0;
 }
 
 // One utterance b, with the alpha slab `slot` of the workspace.
@@ -72,6 +269,16 @@ __device__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, 
   double* wl = p.ws_lse + (size_t)slot * (size_t)Tmax;
 
   if (p.mode != 0 && p.flags[b] == 0) return;
+  if (p.mode == 1 && p.has_retry && (p.flags[b] & ~(8 | 16)) == 0) {
+    // only the f32 segment kernel's range gave out: redo that part in f64; the full recomputation below only if even
+    // that fails
+    bool ok = false;
+    if (p.retry.PPL == 1) ok = retry_segments_f64<IO, 1>(p, smem, b, slot);
+    else if (p.retry.PPL == 2) ok = retry_segments_f64<IO, 2>(p, smem, b, slot);
+    else if (p.retry.PPL == 4) ok = retry_segments_f64<IO, 4>(p, smem, b, slot);
+    __syncthreads();
+    if (ok) return;
+  }
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   if (p.mode == 2 || Tq < 1 || Tq > Tmax || Sq < 0 || Sq > Smax) {   // invalid lengths: poison, do not crash
     const double qnan = __builtin_nan("");
@@ -245,6 +452,7 @@ size_t exact_lds_bytes(int V, int Smax) {
   const size_t Lmax = 2 * (size_t)Smax + 1, S1 = Smax > 0 ? Smax : 1;
   return sizeof(double) * (2 * Lmax + S1 + (size_t)V + 16) + sizeof(int) * (Lmax + 2 * S1);
 }
+size_t retry_lds_bytes(int V) { return sizeof(double) * (kThreads / 64) * kFastSeg * ((size_t)V + 2); }
 
 }  // namespace
 
@@ -265,12 +473,13 @@ size_t exact_fallback_workspace_bytes(int B, int T, int V, int Smax) {
   return exact_bytes_for(B < kFallbackSlabs ? B : kFallbackSlabs, T, Smax);
 }
 
-int launch_exact_flagged(const LossArgs& a, const int* flags, int mode);
+int launch_exact_flagged(const LossArgs& a, const int* flags, int mode, const FastRetry* retry);
 
-int launch_exact(const LossArgs& a) { return launch_exact_flagged(a, nullptr, 0); }
+int launch_exact(const LossArgs& a) { return launch_exact_flagged(a, nullptr, 0, nullptr); }
 
-int launch_exact_flagged(const LossArgs& a, const int* flags, int mode) {
-  const size_t lds = exact_lds_bytes(a.V, a.Smax);
+int launch_exact_flagged(const LossArgs& a, const int* flags, int mode, const FastRetry* retry) {
+  size_t lds = exact_lds_bytes(a.V, a.Smax);
+  if (mode == 1 && retry && retry_lds_bytes(a.V) > lds) lds = retry_lds_bytes(a.V);
   if (lds > 160 * 1024) {
     set_error("exact CTC kernel: V=%d, Smax=%d need %zu B of LDS (> 160 KiB)", a.V, a.Smax, lds);
     return E2E_ERR_UNSUPPORTED;
@@ -286,6 +495,8 @@ int launch_exact_flagged(const LossArgs& a, const int* flags, int mode) {
   p.targets = a.targets; p.tgt_stride = a.tgt_stride; p.x_len = a.x_len; p.t_len = a.t_len;
   p.B = a.B; p.T = a.T; p.V = a.V; p.Smax = a.Smax; p.Lmax = 2 * a.Smax + 1; p.blank = a.blank;
   p.losses = a.losses; p.grads = a.grads; p.flags = flags; p.mode = mode;
+  p.has_retry = (mode == 1 && retry && a.dtype == E2E_F32) ? 1 : 0;
+  if (p.has_retry) p.retry = *retry; else memset(&p.retry, 0, sizeof(p.retry));
   p.ws_alpha = reinterpret_cast<double*>(a.ws);
   p.ws_lse = reinterpret_cast<double*>(reinterpret_cast<char*>(a.ws) +
                                        align_up((size_t)slabs * a.T * p.Lmax * sizeof(double), 256));

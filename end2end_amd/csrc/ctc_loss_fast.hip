@@ -32,7 +32,7 @@
 namespace e2e {
 namespace {
 
-constexpr int kSeg = 16;        // steps per F2 segment == checkpoint spacing
+constexpr int kSeg = kFastSeg;  // steps per F2 segment == checkpoint spacing (16)
 constexpr int kBlk = 8;         // prep -> chain hand-off block and rescale period
 constexpr int kRingBlks = 8;    // ring depth (blocks)
 constexpr int kRow = 10;        // doubles per label row of a ring block: 8 steps + pad (80 B spreads the 16-byte gathers over the banks)
@@ -241,9 +241,7 @@ struct LaneCells {
   __device__ void set_tilt(int S, int T) {
     // the number of alignments of t frames to i labels grows by ~((t-i)/(2i))^2 per extra label, so the
     // untilted maximum sits at i = t/3; r = 2*rho/(1-rho) moves it to i = rho*t
-    float rho = (float)S / (float)T;
-    rho = fminf(fmaxf(rho, 1.f / 33.f), 0.8f);
-    r = S > 0 ? 2.f * rho / (1.f - rho) : 1.f;
+    r = fast_tilt(S, T);
   }
   // the packed form F1 leaves in the workspace for F2 (one word per label pair; `slot` = label-sorted position)
   __device__ static unsigned pack(int lab, int slot, float skp, float skn) {
@@ -358,6 +356,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     }
   };
   float xv[NP][NV];
+  float lpmin = 0.f;                // smallest FINITE log-probability this wave has seen (alpha-side producers)
   load_block(first, xv);
   for (int n = first; n < nblk; n += stride) {       // this wave fills every `stride`-th block
     float xn[NP][NV];
@@ -373,7 +372,10 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
       float y[NV];
       if (p.logprobs) {
 #pragma unroll
-        for (int k = 0; k < NV; k++) y[k] = exp_le0(xv[pass][k]);
+        for (int k = 0; k < NV; k++) {
+          y[k] = exp_le0(xv[pass][k]);
+          if (row_live && xv[pass][k] > ninf) lpmin = fminf(lpmin, xv[pass][k]);      // (-inf: an impossible symbol, exact)
+        }
       } else {
         float m = xv[pass][0];
 #pragma unroll
@@ -381,7 +383,10 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
         m = row16_max(m);
         float ssum = 0.f;
 #pragma unroll
-        for (int k = 0; k < NV; k++) { y[k] = exp_le0(xv[pass][k] - m); ssum += y[k]; }
+        for (int k = 0; k < NV; k++) {
+          y[k] = exp_le0(xv[pass][k] - m); ssum += y[k];
+          if (row_live && xv[pass][k] > ninf) lpmin = fminf(lpmin, xv[pass][k] - m);  // (>= the log-probability)
+        }
         ssum = row16_sum(ssum);
         float inv = __builtin_amdgcn_rcpf(ssum);
         inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);        // one Newton step: ~0.5 ulp
@@ -403,6 +408,10 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 #pragma unroll
       for (int k = 0; k < NV; k++) xv[pass][k] = xn[pass][k];
   }
+  // Probabilities are f32: below ~2^-126 they are flushed, and a chain that ran through such frames carries a loss that
+  // is off by the flushed amount (a symbol with log-probability -inf is exactly impossible and does not count).  Reason bit 64 ("emissions near the end of f32"): such an utterance is recomputed
+  // entirely by the exact kernel, never by the f64 redo of the segments alone, which would keep the chains' loss.
+  if (dir == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], 64); }       // e^-69 = 2^-100
 #ifdef E2E_FAST_PROFILE
   if (lane == 0 && b < 256 && first == 0) { g_prof[(b * 4 + 2 + dir) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + 2 + dir) * 4 + 1] = prof_spin; }
 #endif
@@ -1197,7 +1206,7 @@ size_t fast_workspace_bytes(int B, int T, int V, int Smax) {
   return fast_layout(B, T, V, Smax).total;
 }
 
-int launch_exact_flagged(const LossArgs& a, const int* flags, int mode);
+int launch_exact_flagged(const LossArgs& a, const int* flags, int mode, const FastRetry* retry);
 
 int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   const FastLayout l = fast_layout(a.B, a.T, a.V, a.Smax);
@@ -1229,7 +1238,10 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   LossArgs e = a;
   e.ws = ws + l.total; e.ws_bytes = a.ws_bytes - l.total;
   // mode 1: redo flagged utterances exactly; mode 2: no fallback requested -> poison them
-  return launch_exact_flagged(e, p.flags, fallback_to_exact ? 1 : 2);
+  FastRetry rt;
+  rt.ytab = p.ytab; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.escA = p.escA; rt.escB = p.escB;
+  rt.NS = p.NS; rt.NB = p.NB; rt.CELLS = p.CELLS; rt.PPL = ppl_for(a.Smax); rt.logz = p.logz;
+  return launch_exact_flagged(e, p.flags, fallback_to_exact ? 1 : 2, &rt);
 }
 
 }  // namespace e2e

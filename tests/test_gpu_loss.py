@@ -203,6 +203,27 @@ def test_fast_path_dense_targets(shape):
     U.assert_same(grads[feasible], g_o[feasible], F32_RTOL, F32_ATOL, "grads")
 
 
+def test_range_flags_are_redone_in_f64_not_by_the_exact_kernel():
+    """Informative frames bunched into the first part of an otherwise uninformative utterance, at scale 8: the f32 segment
+    kernel leaves its range for some utterances (flag bit 8).  ALGO_AUTO then redoes only the segments in f64 from the chains'
+    checkpoints (the full log-domain recomputation only if a row fails to reproduce the chains' log Z) -- the result must be
+    the exact kernel's."""
+    rng = np.random.default_rng(0)
+    B, T, V, S = 24, 700, 29, 150
+    x = rng.standard_normal((B, T, V)).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, S)); tl = rng.integers(S // 2, S + 1, size=B); xl = np.full(B, T); xl[1:] -= rng.integers(0, 60, size=B - 1)
+    for b in range(B):
+        slots = np.sort(rng.choice(np.arange(0, int(xl[b] * 0.6)), size=int(tl[b]), replace=False))
+        x[b, slots, tg[b, :int(tl[b])]] += 8.0
+    args = (torch.from_numpy(x), torch.from_numpy(tg), torch.from_numpy(xl), torch.from_numpy(tl), 0, False)
+    lf, _ = U.c_abi_loss(*args, _lib.ALGO_FAST)
+    la, ga = U.c_abi_loss(*args, _lib.ALGO_AUTO)
+    le, ge = U.c_abi_loss(*args, _lib.ALGO_EXACT)
+    assert np.isnan(lf).sum() >= 2, "this input no longer drives the f32 segment kernel out of range: pick a harder one"
+    U.assert_same(la, le, F32_RTOL, 2e-5, "losses")
+    U.assert_same(ga, ge, F32_RTOL, F32_ATOL, "grads")
+
+
 def test_fast_path_takes_peaky_consistent_emissions():
     """What a trained model emits: logits that favour a valid alignment of the utterance's own targets by 2 .. 20 over unit
     noise.  The fast path must handle these itself (no flag, no exact fallback) and accurately."""

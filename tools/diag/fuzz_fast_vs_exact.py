@@ -15,6 +15,8 @@ dense = mode == 'dense'        # target lengths close to the input lengths
 edges = mode == 'edges'        # short inputs, target lengths around the lane-packing boundaries
 wide = mode == 'wide'          # alphabets beyond the lattice kernels' 96 columns (compaction path)
 verbose = os.environ.get('FUZZ_VERBOSE') == '1'
+check_auto = os.environ.get('FUZZ_AUTO', '1') == '1'
+auto_bad = 0
 worst_l, worst_g, flagged, total = 0.0, 0.0, 0, 0
 import collections
 tally = collections.Counter(); feas = collections.Counter()
@@ -37,6 +39,18 @@ for case in range(n_cases):
     tl = torch.tensor(rng.integers(Smax // 2 if dense else 0, Smax + 1, size=B)); tl[0] = Smax
     le, ge = U.c_abi_loss(x, tg[:, :max(Smax, 1)], xl, tl, blank, not fused, _lib.ALGO_EXACT)
     lf, gf = U.c_abi_loss(x, tg[:, :max(Smax, 1)], xl, tl, blank, not fused, _lib.ALGO_FAST)
+    if check_auto:
+        # what the caller gets by default: flagged utterances redone (f64 segments, or the exact kernel) -- every one must agree
+        la, ga = U.c_abi_loss(x, tg[:, :max(Smax, 1)], xl, tl, blank, not fused, _lib.ALGO_AUTO)
+        for b in range(B):
+            if not np.isfinite(le[b]):
+                assert not np.isfinite(la[b]) or np.isnan(la[b]) or la[b] == le[b], (case, b)
+                continue
+            viol = (np.abs(ga[b].astype(np.float64) - ge[b].astype(np.float64)) - (2e-6 + 1e-4 * np.abs(ge[b].astype(np.float64)))).max()
+            if viol > 0 or abs(float(la[b]) - float(le[b])) > 1e-4 * max(1.0, abs(float(le[b]))):
+                auto_bad += 1
+                print("AUTO case %d utt %d: beyond tolerance by %.2e, loss %.6g vs %.6g (fast path flagged: %s; B=%d T=%d V=%d S=%d sharp=%g fused=%d blank=%d xl=%d tl=%d)" % (
+                    case, b, viol, la[b], le[b], bool(np.isnan(lf[b])), B, T, V, Smax, sharp, fused, blank, xl[b], tl[b]))
     for b in range(B):
         total += 1
         if np.isfinite(le[b]): feas[(sharp, "S/T>=.6" if float(tl[b]) / float(xl[b]) >= 0.6 else "S/T<.6")] += 1
@@ -54,5 +68,5 @@ for case in range(n_cases):
             print("   frames with error: %d of %d, first %d last %d; by segment: %s" % (len(bad), int(xl[b]), bad[0], bad[-1], sorted(set((bad // 16).tolist()))[:12]))
         if dl > 1e-4 or dg > 2e-5: print("case %d utt %d: loss rel %.2e grad abs %.2e (B=%d T=%d V=%d S=%d sharp=%g fused=%d blank=%d xl=%d tl=%d)" % (case, b, dl, dg, B, T, V, Smax, sharp, fused, blank, xl[b], tl[b]))
         worst_l, worst_g = max(worst_l, dl), max(worst_g, dg)
-print("%d utterances in %d cases: %d flagged by the fast path; worst loss rel %.2e, worst grad abs %.2e" % (total, n_cases, flagged, worst_l, worst_g))
+print("%d utterances in %d cases: %d flagged by the fast path; worst loss rel %.2e, worst grad abs %.2e; AUTO beyond tolerance: %d" % (total, n_cases, flagged, worst_l, worst_g, auto_bad))
 for k in sorted(feas): print("  sharp %-4g %-8s feasible %4d, flagged by the fast path %4d" % (k[0], k[1], feas[k], tally[k]))
