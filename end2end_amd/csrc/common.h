@@ -41,7 +41,7 @@ constexpr int kFastSeg = 16;       // steps between two checkpoints of the fast 
 // What the flagged-utterance launch needs to redo only the SECOND kernel of the fast path in f64 (an utterance whose
 // f32 segment kernel ran out of range keeps its f64 chains' results: checkpoints, probabilities, loss).
 struct FastRetry {
-  const float* ytab; const float* ckA; const float* ckQ; const short* ckE; const short* escA; const short* escB;
+  const float* ytab; const float* ckA; const float* ckQ; const short* ckE; const int* cumA; const int* cumB;
   const double* logz;              // [B][2] the chains' log Z (alpha side, beta side)
   int NS, NB, CELLS, PPL;
 };

@@ -105,15 +105,14 @@ __device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, in
   }
   const float* ytab = rt.ytab + (size_t)b * Tmax * V;
   auto y = [&](int t, int v) -> double { return v >= 0 ? (double)ytab[(size_t)t * V + v] : 0.0; };
-  const short* escA = rt.escA + (size_t)b * rt.NB;
-  const short* escB = rt.escB + (size_t)b * rt.NB;
+  const int* cumA = rt.cumA + (size_t)b * rt.NB;       // see FastParams in ctc_loss_fast.hip
+  const int* cumB = rt.cumB + (size_t)b * rt.NB;
   bool bad = false;
   // Every row must reproduce the chains' log Z: sum_j alpha_t[j] beta_t[j] = Z r^(L-1) 2^-(EA(t) + EB(t)), with EA / EB
   // the exponents the chains had removed by then.  It does not if the f32 checkpoints could not hold what mattered (their
   // cells share one exponent per lane: a cell 2^-149 below its lane's largest is stored as zero) -- then the exact kernel.
   const double logz = rt.logz[2 * b];
   const double lz_tilt = (double)(L - 1) * log(rr);
-  const int nbk = (T + 7) / 8;
 
   for (int seg = wid; seg * kSeg < T; seg += kThreads / 64) {
     const int t0 = seg * kSeg, n = min(kSeg, T - t0);
@@ -147,7 +146,7 @@ __device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, in
         }
       }
       if ((t & 7) == 7) {
-        const int e = escA[t >> 3];
+        const int e = cumA[(t >> 3) + 1] - cumA[t >> 3];
         if (e != 0) {
 #pragma unroll
           for (int k = 0; k < NC; k++) a[k] = ldexp(a[k], -e);
@@ -207,7 +206,7 @@ __device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, in
         q[2 * r + 1] = bs[2 * r + 1] * y(t, lab[r]);
       }
       if ((t & 7) == 0) {
-        const int e = escB[t >> 3];
+        const int e = cumB[t >> 3] - cumB[(t >> 3) + 1];
         if (e != 0) {
 #pragma unroll
           for (int k = 0; k < NC; k++) q[k] = ldexp(q[k], -e);
@@ -222,12 +221,7 @@ __device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, in
       if (!(st > 0.0) || !(st < __builtin_huge_val())) bad = true;
       {
         const int t = t0 + tt;
-        int EA = 0, EB = 0;
-        for (int m = lane; m < nbk; m += 64) {
-          if (8 * m + 7 <= t) EA += escA[m];
-          if (8 * m >= t + 1) EB += escB[m];
-        }
-        for (int o = 32; o > 0; o >>= 1) { EA += __shfl_xor(EA, o, 64); EB += __shfl_xor(EB, o, 64); }
+        const int EA = cumA[(t + 1) >> 3], EB = cumB[(t + 8) >> 3];
         const double lz_row = log(st) + (double)(EA + EB) * 0.693147180559945309417 - lz_tilt;
         // (absolute: a row sum off by more than 2e-6 relative means cells that mattered were stored with too few bits)
         if (!(fabs(lz_row - logz) <= 2e-6 + 1e-12 * fabs(logz))) bad = true;

@@ -12,14 +12,16 @@
 //                                             per-block sequence words in LDS, no barriers
 //     Every 8 steps a chain rescales its row by a power of two (exponent of the row maximum),
 //     every 16 steps it stores the row as an f32 checkpoint.  Outputs: loss, checkpoints,
-//     per-8-step exponents, the probability rows (for F2), alpha-side and beta-side log Z.
+//     cumulative removed exponents per 8-step block, the probability rows (for F2), alpha-side
+//     and beta-side log Z, log2 of the tilted partition sum (what every row of F2 must reproduce).
 //  kernel F2  (one wave per (utterance, 16-step segment): thousands of independent waves)
 //     recomputes the 16 alpha rows of its segment from the checkpoint into registers, walks
 //     beta backwards through the segment, forms the posteriors alpha*beta/sum, accumulates them
 //     per label in LDS and writes the gradient rows (prob - posterior), coalesced.
+//     Every row checks sum_j alpha*beta against the chains' partition sum (finish_rows).
 //  exact kernel (ctc_loss_exact.hip) re-does the utterances F1/F2 flag: infeasible alignments,
-//     range underflow (sum alpha*beta below 2^-90 of the row scales), alpha/beta log Z mismatch,
-//     targets that contain the blank id.
+//     rows that fail the self-check or leave f32's range (segments redone in f64 from the
+//     checkpoints first), alpha/beta log Z mismatch, targets that contain the blank id.
 //
 // Reference semantics restated: src/losses/ctc_loss.cpp:33-117 (recurrences, loss, gradient).
 #include <type_traits>
@@ -48,8 +50,10 @@ struct FastParams {
   float* ckA;      // [B][NS][CELLS]  row k: alpha row at t = 16k-1 (k >= 1)
   float* ckQ;      // [B][NS][CELLS]  row k: beta-with-emission row at t = 16k (k >= 1)
   short* ckE;      // [B][NS][2][64]  per-lane exponent of checkpoint row k (0: alpha, 1: beta); -30000 = all zero
-  short* escA;     // [B][NB]   exponent removed from the alpha row at step 8n+7
-  short* escB;     // [B][NB]   exponent removed from the beta row at step 8n
+  int* cumA;       // [B][NB]   cumA[m]: sum of the exponents the alpha chain removed at steps 8i+7, i < m (cumA[0] = 0)
+  int* cumB;       // [B][NB]   cumB[m]: sum of the exponents the beta chain removed at steps 8i, i >= m (0 past the end)
+  double* zt2;     // [B]       log2 of the TILTED partition sum in the alpha chain's final units + what it removed:
+                   //           what sum_j alpha_t[j]*beta_t[j] * 2^(cumA + cumB) must equal at every t
   double* logz;    // [B][2]    alpha-side / beta-side log Z
   int* flags;      // [B]       != 0: redo with the exact kernel
   unsigned* cinfo; // [B][CELLS/2]  per label pair: label | sorted slot << 8 | alpha skip << 16 | beta skip << 17
@@ -192,6 +196,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 #ifdef E2E_FAST_PROFILE
 } __device__ unsigned long long g_prof[256 * 4 * 4]; namespace {   // [wg][wave][total, spin, nspin, -]
 } __device__ unsigned long long g_prof2[16384 * 8]; namespace {      // F2 phase cycles per workgroup (first 16384)
+} __device__ float g_zdev[16384]; namespace {                         // F2 self-check: log2 deviation per workgroup
 __shared__ unsigned long long s_prof_prev;
 __shared__ unsigned long long s_prof_acc[8];
 #define F2_STAMP(i) { unsigned long long _t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
@@ -457,7 +462,11 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
   int e_pending = 0;                               // exponent measured one step earlier
   int e_total = 0;                                 // sum of removed exponents
   float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
-  short* esc = (DIR == 0 ? p.escA : p.escB) + (size_t)b * p.NB;
+  int* cum = (DIR == 0 ? p.cumA : p.cumB) + (size_t)b * p.NB;
+  if (lane == 0) {
+    if (DIR == 0) cum[0] = 0;
+    else { cum[((T - 1) >> 3) + 1] = 0; cum[((T - 1) >> 3) + 2] = 0; }
+  }
 
   // the probabilities of a block: per label cell (and for the blank) four wide reads of 2 steps each
   typedef double d2 __attribute__((ext_vector_type(2)));
@@ -548,8 +557,8 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
 #pragma unroll
             for (int k = 0; k < NC; k++) c[k] = ldexp(c[k], -e_pending);
           }
-          if (lane == 0) esc[t >> 3] = (short)e_pending;
           e_total += e_pending;
+          if (lane == 0) cum[(t >> 3) + (DIR == 0 ? 1 : 0)] = e_total;
           e_pending = 0;
           const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
           if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
@@ -613,6 +622,7 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
   if (lane == 0) {
     const double lz = log(z) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log(rr);
     p.logz[2 * b + DIR] = lz;
+    if (DIR == 0) p.zt2[b] = log2(z) + (double)e_total;
     if (DIR == 0) {
       p.losses[b] = (float)(-lz);
       if (!(z > 0.0) || !(z < __builtin_huge_val())) atomicOr(&p.flags[b], 4);     // infeasible or out of range
@@ -708,6 +718,13 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
 // F2: one wave per (utterance, 16-step segment)
 // ============================================================================================
 constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before they are summed and written out
+#ifndef E2E_SMIN                    // (both overridable for tools/diag experiments)
+#define E2E_SMIN 0x1p-120f         // smallest row sum sum_j alpha*beta the gradient rows are trusted with
+#endif
+#ifndef E2E_ZTOL
+#define E2E_ZTOL 4e-6f
+#endif
+constexpr float kZTol = E2E_ZTOL;   // |log2| tolerance of the rows' self-check (2.8e-6 relative; rounding alone stays below 1e-6)
 constexpr int kYs = kSeg + 4;      // row stride (floats) of the transposed probability tile: 80 B spreads the
                                    // 16-byte gathers of different labels over the LDS bank row
 
@@ -732,7 +749,8 @@ struct F2Lds {
 // rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows.  FULL: all 8 rows are live.
 template <int PPL, bool FULL>
 __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, int n, int h, const F2Lds<PPL>& lds,
-                                            const float (&pb)[kHalf], int lane, float& smin, float& smax) {
+                                            const float (&pb)[kHalf], int lane, float& smin, float& smax,
+                                            int u_lo, int u_hi, float zfrac) {
   constexpr int PROW = F2Lds<PPL>::PROW;
   const int V = p.V, blank = p.blank;
   const int rows = FULL ? kHalf : min(kHalf, n - h * kHalf);      // live rows of this half (>= 1)
@@ -755,6 +773,19 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
     st = lab_total + bl_total;
     smin = fminf(smin, st); smax = fmaxf(smax, st);
   };
+  // Self-check of a row: sum_j alpha_t[j] beta_t[j] is the same number at every t -- the tilted partition sum the
+  // chains ended with (zt2).  st is that sum in this segment's unit, u the exponent of the unit (minus zt2's integer
+  // part): log2(st) + u must equal zt2's fraction.  Cells that mattered but were flushed -- too few bits in the f32
+  // checkpoints, a recomputed row sinking below the lane's unit -- only ever LOWER the sum, so the deviation bounds
+  // the posterior mass the row lost.  (Rounding alone: < 1e-6, measured over the fuzz sweeps.)
+  auto row_ok = [&](float st, int u) {
+    const float dev = __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(st)) - zfrac + (float)(__builtin_amdgcn_frexp_expf(st) + u);
+#ifdef E2E_FAST_PROFILE
+    { const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+      if (wg < 16384 && (FULL ? lane < kHalf : lane == 0)) atomicMax(reinterpret_cast<int*>(&g_zdev[wg]), __float_as_int(fminf(fabsf(dev), 1e30f))); }
+#endif
+    return fabsf(dev) <= kZTol;
+  };
   if (FULL) {
     // straight-line code for the 8 rows (their dependent scan chains interleave); the per-row results are
     // written by lane k afterwards instead of by lane 0 inside eight conditional blocks
@@ -767,6 +798,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
       my_bt = lane == k ? bt : my_bt;
     }
     if (lane < kHalf) { lds.invs[lane] = __builtin_amdgcn_rcpf(my_st); lds.btot[lane] = my_bt; }
+    if (__any(lane < kHalf && !row_ok(my_st, lane == kHalf - 1 ? u_hi : u_lo))) smin = 0.f;
   } else {
 #pragma unroll
     for (int k = 0; k < kHalf; k++) {
@@ -774,6 +806,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
         float st, bt;
         scan_row(k, st, bt);
         if (lane == 0) { lds.invs[k] = __builtin_amdgcn_rcpf(st); lds.btot[k] = bt; }
+        if (!row_ok(st, k == kHalf - 1 ? u_hi : u_lo)) smin = 0.f;
       }
     }
   }
@@ -810,12 +843,17 @@ struct SegIn {
   float q[2 * PPL];                 // beta-with-emission checkpoint row at the segment's end (not the last segment)
   int ownB;
   int eA7, eA15, eB0, eB8;          // rescale exponents inside the segment
+  int EA0, EB16;                    // what the chains had removed in total: alpha before step t0, beta down to step t0+16
+  float zfrac; int zint;            // the chains' log2 of the tilted partition sum (zt2), split: zint + zfrac
   __device__ void load(const FastParams& p, int b, int seg, int lane) {
     const int t0 = seg * kSeg;
-    const short* escA = p.escA + (size_t)b * p.NB;
-    const short* escB = p.escB + (size_t)b * p.NB;
-    eA7 = escA[(t0 >> 3)]; eA15 = escA[(t0 >> 3) + 1];
-    eB0 = escB[(t0 >> 3)]; eB8 = escB[(t0 >> 3) + 1];
+    const int* cA = p.cumA + (size_t)b * p.NB + (t0 >> 3);
+    const int* cB = p.cumB + (size_t)b * p.NB + (t0 >> 3);
+    const int a0 = cA[0], a1 = cA[1], a2 = cA[2], b0 = cB[0], b1 = cB[1], b2 = cB[2];
+    eA7 = a1 - a0; eA15 = a2 - a1; eB0 = b0 - b1; eB8 = b1 - b2;
+    EA0 = a0; EB16 = b2;
+    { const double z = p.zt2[b]; const double zi = floor(z); zfrac = (float)(z - zi);
+      zint = (int)fmax(fmin(zi, 1e9), -1e9); if (!(z == z)) zfrac = z; }      // (infeasible: -inf; never passes the check)
     ownA = 0;
 #pragma unroll
     for (int k = 0; k < 2 * PPL; k++) a[k] = 0.f;
@@ -923,17 +961,6 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
           pl = ol;
         }
       }
-      if ((tt & 7) == 6) {
-        // health of the recomputed row at its smallest (just before F1's rescale is replayed): the lane that holds
-        // the row's largest cell must hold it as a comfortably normal f32 -- with emissions that contradict the
-        // targets a row can lose 2^-20 per step and drown within the 8 steps between two rescales
-        float lm = a[0];
-#pragma unroll
-        for (int k = 1; k < NC; k++) lm = fmaxf(lm, a[k]);
-        const int key = eA + (lm > 0.f ? (int)((__float_as_uint(lm) >> 23) & 0xffu) - 127 : -300);
-        const int top = wave_max(key);
-        if (__any(key == top && lm < 0x1p-90f)) smin = 0.f;
-      }
       if ((tt & 7) == 7) {             // t0 is a multiple of 16: t & 7 == tt & 7
         const int e = tt == 7 ? eA7 : eA15;
         if (e != 0) {
@@ -953,6 +980,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
   float q[NC];
   const bool last_seg = (t0 + n == T);
   float end_unit = 1.f;
+  int unit_exp = 0;                 // alpha*beta products of this segment are in units of 2^unit_exp (chains' units)
   if (FULL || !last_seg) {
 #pragma unroll
     for (int k = 0; k < NC; k++) q[k] = in.q[k];
@@ -968,6 +996,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
     // (a lane whose alpha cells have sunk to the denormal range carries no precision: it must not define the unit)
     const int e_end = a_end >= 0x1p-120f ? (int)((__float_as_uint(a_end) >> 23) & 0xffu) - 127 : -200;
     const int emax = wave_max(eA + ownB + e_end);
+    unit_exp = emax;
     const int want = eA + ownB - emax;
     const int sh = min(max(want, -200), 120);
     // (a lane whose beta cells would need more than 2^120 in this unit while it still holds beta mass: out of range)
@@ -982,6 +1011,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
     for (int k = 0; k < NC; k++) q[k] = 0.f;
     const int eA_ref = __shfl(eA, (L - 1) / NC, 64);          // lane holding cell L-1
     end_unit = ldexpf(1.f, max(min(eA - eA_ref, 126), -126));
+    unit_exp = eA_ref;
   }
   F2_STAMP(3)
 #pragma unroll
@@ -1042,7 +1072,11 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
       }
     }
     F2_STAMP(4)
-    finish_rows<PPL, FULL>(p, b, t0, n, h, lds, pb, lane, smin, smax);
+    // exponent of the rows' unit in the chains' terms: what alpha had removed by the row (rescales at tt = 7, 15) plus
+    // what beta had removed down to it (at tt = 8, 0 -- after the row's product), minus the integer part of zt2
+    const int ea_lo = in.EA0 + (h ? eA7 : 0), eb = in.EB16 + (h ? 0 : eB8);
+    const int u_lo = unit_exp + ea_lo + eb - in.zint, u_hi = u_lo + (h ? eA15 : eA7);
+    finish_rows<PPL, FULL>(p, b, t0, n, h, lds, pb, lane, smin, smax, u_lo, u_hi, in.zfrac);
     F2_STAMP(6)
   }
 }
@@ -1137,11 +1171,13 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   F2_FLUSH
   // range check: everything that carries posterior mass was representable (see the header comment)
   const bool finite_ok = smax < __builtin_huge_valf();
-  // (2^-90 is not the edge of f32 but a margin: a row sum that small means its terms are products of factors that
-  // are themselves close to the denormal range.  A randomised sweep with 2^-110 let gradients through that were
-  // off by 2e-3.  Rows between F1's rescales legitimately sit 2^-40 .. 2^-80 below the unit: alpha is rescaled at
-  // t%8 == 7 and beta at t%8 == 0, so every row in between carries nine steps of decay.)
-  if (!(smin >= 0x1p-90f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
+  // (smin: a row sum that can still be inverted and whose terms of relative weight 2^-6 are normal f32.  What decides
+  // whether the rows kept everything that mattered is the self-check in finish_rows, which also zeroes smin: with a
+  // margin alone -- 2^-90 -- two utterances in three with emissions that contradict their targets were sent to the f64
+  // redo for nothing, and with 2^-110 and no self-check a randomised sweep let gradients through that were off by 2e-3.
+  // Rows between F1's rescales legitimately sit 2^-40 .. 2^-80 below the unit: alpha is rescaled at t%8 == 7 and beta
+  // at t%8 == 0, so every row in between carries nine steps of decay.)
+  if (!(smin >= E2E_SMIN) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
   if (seg == 0 && lane == 0) {
     const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
     if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
@@ -1170,7 +1206,7 @@ int ppl_for(int Smax) {
 }
 
 struct FastLayout {
-  size_t ytab, ckA, ckQ, ckE, escA, escB, logz, flags, cinfo, lstart, total;
+  size_t ytab, ckA, ckQ, ckE, cumA, cumB, logz, zt2, flags, cinfo, lstart, total;
   int NS, NB, CELLS;
 };
 
@@ -1179,14 +1215,15 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
   const int ppl = ppl_for(Smax);
   l.CELLS = 128 * (ppl > 0 ? ppl : 1);
   l.NS = (T + kSeg - 1) / kSeg;
-  l.NB = (T + kBlk - 1) / kBlk + 1;
+  l.NB = (T + kBlk - 1) / kBlk + 4;       // (cumA / cumB are read up to two blocks past an utterance's last)
   size_t o = 0;
   l.ytab = o; o += align_up((size_t)B * T * V * sizeof(float), 256);
   l.ckA = o; o += align_up((size_t)B * l.NS * l.CELLS * sizeof(float), 256);
   l.ckQ = o; o += align_up((size_t)B * l.NS * l.CELLS * sizeof(float), 256);
   l.ckE = o; o += align_up((size_t)B * l.NS * 2 * 64 * sizeof(short), 256);
-  l.escA = o; o += align_up((size_t)B * l.NB * sizeof(short), 256);
-  l.escB = o; o += align_up((size_t)B * l.NB * sizeof(short), 256);
+  l.cumA = o; o += align_up((size_t)B * l.NB * sizeof(int), 256);
+  l.cumB = o; o += align_up((size_t)B * l.NB * sizeof(int), 256);
+  l.zt2 = o; o += align_up((size_t)B * sizeof(double), 256);
   l.logz = o; o += align_up((size_t)B * 2 * sizeof(double), 256);
   l.flags = o; o += align_up((size_t)B * sizeof(int), 256);
   l.cinfo = o; o += align_up((size_t)B * (l.CELLS / 2) * sizeof(unsigned), 256);
@@ -1223,7 +1260,8 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.ytab = reinterpret_cast<float*>(ws + l.ytab);
   p.ckA = reinterpret_cast<float*>(ws + l.ckA); p.ckQ = reinterpret_cast<float*>(ws + l.ckQ);
   p.ckE = reinterpret_cast<short*>(ws + l.ckE);
-  p.escA = reinterpret_cast<short*>(ws + l.escA); p.escB = reinterpret_cast<short*>(ws + l.escB);
+  p.cumA = reinterpret_cast<int*>(ws + l.cumA); p.cumB = reinterpret_cast<int*>(ws + l.cumB);
+  p.zt2 = reinterpret_cast<double*>(ws + l.zt2);
   p.logz = reinterpret_cast<double*>(ws + l.logz); p.flags = reinterpret_cast<int*>(ws + l.flags);
   p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart);
   p.NS = l.NS; p.NB = l.NB; p.CELLS = l.CELLS;
@@ -1239,7 +1277,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   e.ws = ws + l.total; e.ws_bytes = a.ws_bytes - l.total;
   // mode 1: redo flagged utterances exactly; mode 2: no fallback requested -> poison them
   FastRetry rt;
-  rt.ytab = p.ytab; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.escA = p.escA; rt.escB = p.escB;
+  rt.ytab = p.ytab; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.cumA = p.cumA; rt.cumB = p.cumB;
   rt.NS = p.NS; rt.NB = p.NB; rt.CELLS = p.CELLS; rt.PPL = ppl_for(a.Smax); rt.logz = p.logz;
   return launch_exact_flagged(e, p.flags, fallback_to_exact ? 1 : 2, &rt);
 }
@@ -1247,6 +1285,12 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
 }  // namespace e2e
 
 #ifdef E2E_FAST_PROFILE
+extern "C" int e2e_debug_fast_zdev(float* host, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
+  if (reset) { void* ptr; if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(e2e::g_zdev)) != hipSuccess) return E2E_ERR_HIP;
+    return hipMemset(ptr, 0, sizeof(float) * 16384) == hipSuccess ? 0 : E2E_ERR_HIP; }
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(e2e::g_zdev), sizeof(float) * 16384) == hipSuccess ? 0 : E2E_ERR_HIP;
+}
 extern "C" int e2e_debug_fast_profile2(unsigned long long* host, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
   if (reset) { void* ptr; if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(e2e::g_prof2)) != hipSuccess) return E2E_ERR_HIP;

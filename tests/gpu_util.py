@@ -9,7 +9,7 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_AUTO):
+def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_AUTO, keep=None):
     """x: torch tensor (B,T,V) on any device with any strides (moved to the GPU keeping its layout)."""
     L = _lib.load()
     d = dev()
@@ -36,6 +36,8 @@ def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_
                                       B, T, V, Smax, blank, losses.data_ptr(), grads.data_ptr(),
                                       ws.data_ptr(), ws.numel(), algo, _lib.stream_ptr(d)))
     torch.cuda.synchronize()
+    if keep is not None:
+        keep["workspace"] = ws              # (diagnostics read the fast path's flag words out of it)
     return losses.cpu().numpy(), grads.cpu().numpy()
 
 

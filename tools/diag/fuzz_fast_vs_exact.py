@@ -17,9 +17,11 @@ wide = mode == 'wide'          # alphabets beyond the lattice kernels' 96 column
 verbose = os.environ.get('FUZZ_VERBOSE') == '1'
 check_auto = os.environ.get('FUZZ_AUTO', '1') == '1'
 auto_bad = 0
+import ctypes
+zdev_good, zdev_bad = [], []       # instrumented library only: the segment self-check's deviation, by outcome
 worst_l, worst_g, flagged, total = 0.0, 0.0, 0, 0
 import collections
-tally = collections.Counter(); feas = collections.Counter()
+tally = collections.Counter(); feas = collections.Counter(); flagwords = collections.Counter()
 for case in range(n_cases):
     B = int(rng.integers(1, 9)); T = int(rng.integers(1, 700)); V = int(rng.integers(2, 97))
     if wide: V = int(rng.choice([97, 128, 500, 1000, 3001])); T = int(rng.integers(1, 200))
@@ -38,7 +40,21 @@ for case in range(n_cases):
     xl = torch.tensor(rng.integers(1, T + 1, size=B)); xl[0] = T
     tl = torch.tensor(rng.integers(Smax // 2 if dense else 0, Smax + 1, size=B)); tl[0] = Smax
     le, ge = U.c_abi_loss(x, tg[:, :max(Smax, 1)], xl, tl, blank, not fused, _lib.ALGO_EXACT)
-    lf, gf = U.c_abi_loss(x, tg[:, :max(Smax, 1)], xl, tl, blank, not fused, _lib.ALGO_FAST)
+    has_zdev = bool(os.environ.get('E2E_LIB')) and hasattr(_lib.load(), 'e2e_debug_fast_zdev')
+    if has_zdev: _lib.load().e2e_debug_fast_zdev(None, 1)
+    kept = {}
+    lf, gf = U.c_abi_loss(x, tg[:, :max(Smax, 1)], xl, tl, blank, not fused, _lib.ALGO_FAST, keep=kept)
+    if V <= 96:
+        fw = (ctypes.c_int * B)(); lzw = (ctypes.c_double * (2 * B))()
+        _lib.load().e2e_debug_fast_state.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
+        if _lib.load().e2e_debug_fast_state(kept["workspace"].data_ptr(), B, T, V, max(Smax, 1), fw, lzw) == 0:
+            for b in range(B):
+                if np.isfinite(le[b]): flagwords[(sharp, fw[b])] += 1
+    zd = None
+    if has_zdev and V <= 96 and B * ((T + 15) // 16) <= 16384:
+        buf = np.zeros(16384, np.float32)
+        _lib.load().e2e_debug_fast_zdev(buf.ctypes.data_as(ctypes.c_void_p), 0)
+        zd = buf[:B * ((T + 15) // 16)].reshape(B, -1)
     if check_auto:
         # what the caller gets by default: flagged utterances redone (f64 segments, or the exact kernel) -- every one must agree
         la, ga = U.c_abi_loss(x, tg[:, :max(Smax, 1)], xl, tl, blank, not fused, _lib.ALGO_AUTO)
@@ -62,6 +78,10 @@ for case in range(n_cases):
             continue
         dl = abs(float(lf[b]) - float(le[b])) / max(1.0, abs(float(le[b])))
         dg = float(np.abs(gf[b].astype(np.float64) - ge[b].astype(np.float64)).max())
+        if zd is not None:
+            dev = float(np.abs(zd[b, :(int(xl[b]) + 15) // 16]).max())       # worst row of the utterance's segments
+            viol_f = float((np.abs(gf[b].astype(np.float64) - ge[b].astype(np.float64)) - (2e-6 + 1e-4 * np.abs(ge[b].astype(np.float64)))).max())
+            (zdev_bad if viol_f > 0 else zdev_good).append((dev, viol_f, case, b))
         if dg > 2e-5:
             err = np.abs(gf[b].astype(np.float64) - ge[b].astype(np.float64)).max(-1)      # per frame
             bad = np.nonzero(err > 2e-5)[0]
@@ -70,3 +90,9 @@ for case in range(n_cases):
         worst_l, worst_g = max(worst_l, dl), max(worst_g, dg)
 print("%d utterances in %d cases: %d flagged by the fast path; worst loss rel %.2e, worst grad abs %.2e; AUTO beyond tolerance: %d" % (total, n_cases, flagged, worst_l, worst_g, auto_bad))
 for k in sorted(feas): print("  sharp %-4g %-8s feasible %4d, flagged by the fast path %4d" % (k[0], k[1], feas[k], tally[k]))
+if zdev_good or zdev_bad:
+    gd = np.array([d[0] for d in zdev_good]) if zdev_good else np.zeros(1)
+    print("self-check |log2 dev| of utterances within tolerance: median %.2e, 99%% %.2e, max %.2e (%d)" % (np.median(gd), np.quantile(gd, 0.99), gd.max(), len(gd)))
+    for d in sorted(zdev_bad): print("   beyond tolerance by %.2e: |log2 dev| %.2e (case %d utt %d)" % (d[1], d[0], d[2], d[3]))
+print("flag words of feasible utterances (1 lengths, 2 blank label, 4 infeasible/inf, 8 range, 16 non-finite, 32 log Z mismatch, 64 tiny emissions):")
+for k in sorted(flagwords): print("  sharp %-4g flags %3d: %d" % (k[0], k[1], flagwords[k]))
