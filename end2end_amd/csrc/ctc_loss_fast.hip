@@ -122,6 +122,37 @@ __device__ __forceinline__ float wave_scan(float v) {
   E2E_ROW_BCAST_STEPS("v_add_f32_dpp", v);
   return v;
 }
+// eight inclusive prefix sums at once, step by step across the eight: a DPP instruction needs two wait states after
+// the VALU write of its source, which the other seven values' instructions fill (scanning them one after the other
+// costs an s_nop per step -- a fifth of the instructions of the F2 scan phase)
+__device__ __forceinline__ void wave_scan8(float (&v)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), 0x111, 0xf, 0xf, true));
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), 0x112, 0xf, 0xf, true));
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), 0x114, 0xf, 0xf, true));
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), 0x118, 0xf, 0xf, true));
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %6, %6, %6 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %7, %7, %7 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %4, %4, %4 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %5, %5, %5 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
 __device__ __forceinline__ int wave_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
@@ -730,108 +761,119 @@ constexpr int kYs = kSeg + 4;      // row stride (floats) of the transposed prob
 
 template <int PPL>
 struct F2Lds {
-  static constexpr int PROW = 64 * PPL;        // label cells in label order
-  float* Ps;        // [kHalf][PROW]
+  // label cells in label order; every row is preceded by 4 pad floats whose last one stays 0: the prefix sum "before
+  // slot 0", so that a label's posterior is pre[hi-1] - pre[lo-1] without a case distinction
+  static constexpr int PROW = 64 * PPL + 4;
+  float* Ps;        // [kHalf][PROW], Ps[k*PROW - 1] == 0
   float* ys;        // [V+1][kYs]   probabilities of the segment, TRANSPOSED (label-major, 16 steps + pad), row V = 0
-  float* invs;      // [kHalf]
-  float* btot;      // [kHalf]
   int* starts;      // [130] first sorted slot of every label (V+1 entries used)
   __device__ F2Lds(unsigned char* smem, int V) {
-    Ps = reinterpret_cast<float*>(smem);
+    Ps = reinterpret_cast<float*>(smem) + 4;
     ys = Ps + kHalf * PROW;
-    invs = ys + kYs * (V + 1);
-    btot = invs + kHalf;
-    starts = reinterpret_cast<int*>(btot + kHalf);
+    starts = reinterpret_cast<int*>(ys + kYs * (V + 1));
   }
-  static size_t bytes(int V) { return sizeof(float) * (kHalf * PROW + kYs * (V + 1) + 2 * kHalf) + sizeof(int) * 130; }
+  static size_t bytes(int V) { return sizeof(float) * (4 + kHalf * PROW + kYs * (V + 1)) + sizeof(int) * 130; }
+};
+
+// The gradient rows are written one lane per label (two labels per lane beyond 64 columns): what a lane needs about
+// its labels is the same for all 16 rows of the segment and is looked up once.
+struct GradLanes {
+  int hi[2], lo[2];     // float index into a Ps row of the label's last sorted slot / of the slot before its first
+  int y[2];             // float index of the label's row in the transposed probability tile
+  float isblank[2];     // 1 for the blank column (it takes the pre-summed blank cells), else 0
+  template <int PPL>
+  __device__ void init(const F2Lds<PPL>& lds, int V, int blank, int lane) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int v = min(lane + 64 * s, V - 1);
+      hi[s] = lds.starts[v + 1] - 1; lo[s] = lds.starts[v] - 1;
+      y[s] = v * kYs; isblank[s] = v == blank ? 1.f : 0.f;
+    }
+  }
 };
 
 // rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows.  FULL: all 8 rows are live.
 template <int PPL, bool FULL>
 __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, int n, int h, const F2Lds<PPL>& lds,
-                                            const float (&pb)[kHalf], int lane, float& smin, float& smax,
+                                            const GradLanes& gl, const float (&pb)[kHalf], int lane, float& smin, float& smax,
                                             int u_lo, int u_hi, float zfrac) {
   constexpr int PROW = F2Lds<PPL>::PROW;
-  const int V = p.V, blank = p.blank;
+  const int V = p.V;
   const int rows = FULL ? kHalf : min(kHalf, n - h * kHalf);      // live rows of this half (>= 1)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // prefix sums over the label-sorted cells, totals, s_t = sum_j alpha_t[j]*beta_t[j]
   float btot8[kHalf];                     // blank cells: the lanes' partial sums never went through the LDS
   wave_sum8(pb, btot8, lane);
-  auto scan_row = [&](int k, float& st, float& bl_total) {
-    float c[PPL];
+  float st8[kHalf];                       // (wave-uniform)
+  {
+    float c[kHalf][PPL], inc[kHalf];
 #pragma unroll
-    for (int r = 0; r < PPL; r++) c[r] = lds.Ps[k * PROW + PPL * lane + r];
+    for (int k = 0; k < kHalf; k++) {
 #pragma unroll
-    for (int r = 1; r < PPL; r++) c[r] += c[r - 1];
-    const float incl = wave_scan(c[PPL - 1]);
-    const float excl = incl - c[PPL - 1];
+      for (int r = 0; r < PPL; r++) c[k][r] = lds.Ps[k * PROW + PPL * lane + r];
+    }
 #pragma unroll
-    for (int r = 0; r < PPL; r++) lds.Ps[k * PROW + PPL * lane + r] = c[r] + excl;
-    const float lab_total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
-    bl_total = btot8[k];
-    st = lab_total + bl_total;
-    smin = fminf(smin, st); smax = fmaxf(smax, st);
-  };
+    for (int r = 1; r < PPL; r++) {
+#pragma unroll
+      for (int k = 0; k < kHalf; k++) c[k][r] += c[k][r - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < kHalf; k++) inc[k] = c[k][PPL - 1];
+    wave_scan8(inc);
+#pragma unroll
+    for (int k = 0; k < kHalf; k++) {
+      const float excl = inc[k] - c[k][PPL - 1];
+#pragma unroll
+      for (int r = 0; r < PPL; r++) lds.Ps[k * PROW + PPL * lane + r] = c[k][r] + excl;
+      st8[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc[k]), 63)) + btot8[k];
+    }
+  }
   // Self-check of a row: sum_j alpha_t[j] beta_t[j] is the same number at every t -- the tilted partition sum the
   // chains ended with (zt2).  st is that sum in this segment's unit, u the exponent of the unit (minus zt2's integer
   // part): log2(st) + u must equal zt2's fraction.  Cells that mattered but were flushed -- too few bits in the f32
   // checkpoints, a recomputed row sinking below the lane's unit -- only ever LOWER the sum, so the deviation bounds
-  // the posterior mass the row lost.  (Rounding alone: < 1e-6, measured over the fuzz sweeps.)
-  auto row_ok = [&](float st, int u) {
-    const float dev = __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(st)) - zfrac + (float)(__builtin_amdgcn_frexp_expf(st) + u);
+  // the posterior mass the row lost.  (Rounding alone: < 1e-6, measured over the fuzz sweeps.)  Lane k checks row k.
+  {
+    float my_st = 1.f;
+#pragma unroll
+    for (int k = 0; k < kHalf; k++) my_st = lane == k ? st8[k] : my_st;
+    const int u = lane == kHalf - 1 ? u_hi : u_lo;
+    const float dev = __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(my_st)) - zfrac + (float)(__builtin_amdgcn_frexp_expf(my_st) + u);
+    const bool live = lane < rows;
 #ifdef E2E_FAST_PROFILE
     { const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
-      if (wg < 16384 && (FULL ? lane < kHalf : lane == 0)) atomicMax(reinterpret_cast<int*>(&g_zdev[wg]), __float_as_int(fminf(fabsf(dev), 1e30f))); }
+      if (wg < 16384 && live) atomicMax(reinterpret_cast<int*>(&g_zdev[wg]), __float_as_int(fminf(fabsf(dev), 1e30f))); }
 #endif
-    return fabsf(dev) <= kZTol;
-  };
-  if (FULL) {
-    // straight-line code for the 8 rows (their dependent scan chains interleave); the per-row results are
-    // written by lane k afterwards instead of by lane 0 inside eight conditional blocks
-    float my_st = 1.f, my_bt = 0.f;
-#pragma unroll
-    for (int k = 0; k < kHalf; k++) {
-      float st, bt;
-      scan_row(k, st, bt);
-      my_st = lane == k ? st : my_st;
-      my_bt = lane == k ? bt : my_bt;
-    }
-    if (lane < kHalf) { lds.invs[lane] = __builtin_amdgcn_rcpf(my_st); lds.btot[lane] = my_bt; }
-    if (__any(lane < kHalf && !row_ok(my_st, lane == kHalf - 1 ? u_hi : u_lo))) smin = 0.f;
-  } else {
-#pragma unroll
-    for (int k = 0; k < kHalf; k++) {
-      if (k < rows) {
-        float st, bt;
-        scan_row(k, st, bt);
-        if (lane == 0) { lds.invs[k] = __builtin_amdgcn_rcpf(st); lds.btot[k] = bt; }
-        if (!row_ok(st, k == kHalf - 1 ? u_hi : u_lo)) smin = 0.f;
-      }
-    }
+    // (smin / smax: see the range check at the end of the kernel)
+    const bool bad = live && !(fabsf(dev) <= kZTol && my_st >= E2E_SMIN);
+    if (__any(bad)) smin = 0.f;
+    if (__any(live && !(my_st < __builtin_huge_valf()))) smax = __builtin_huge_valf();
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   F2_STAMP(5)
-  // gradient rows: y - posterior (d loss/d logits in fused mode; exp(lp) - posterior otherwise).  The live rows of
-  // this half are rows*V consecutive floats of the output: one lane per element, fully coalesced stores.
+  // gradient rows: y - posterior (d loss/d logits in fused mode; exp(lp) - posterior otherwise).  Lane v writes column
+  // v of every row: its label's slots, its row of the probability tile and whether it is the blank are the same for
+  // all rows (GradLanes); per row that leaves three LDS reads at constant offsets, three VALU operations and a store.
   float* grads = p.grads + ((size_t)b * p.T + t0 + h * kHalf) * V;
-  const unsigned magic = (1u << 20) / (unsigned)V + 1u;                    // o / V for o < 2^20 / V
-  const int count = rows * V;
-  // branch-free: every lane reads from clamped addresses and only the store is predicated, so that the LDS reads of
-  // a pass (and of neighbouring passes) are in flight together instead of one round trip per conditional read
-#pragma unroll 4
-  for (int ob = 0; ob < count; ob += 64) {
-    const int o = min(ob + lane, count - 1);
-    const int k = (int)(((unsigned)o * magic) >> 20), v = o - k * V;
-    const int lo = lds.starts[v], hi = lds.starts[v + 1];       // label v owns the sorted slots [lo, hi)
-    const float* pre = lds.Ps + k * PROW;
-    const float a1 = pre[max(hi - 1, 0)], a0 = pre[max(lo - 1, 0)];
-    const float bt = lds.btot[k], iv = lds.invs[k], yv = lds.ys[v * kYs + h * kHalf + k];
-    float pv = hi > lo ? a1 - (lo > 0 ? a0 : 0.f) : 0.f;
-    pv += v == blank ? bt : 0.f;
-    if (ob + lane < count) grads[ob + lane] = yv - pv * iv;
+  const int nsets = V > 64 ? 2 : 1;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    if (s < nsets) {
+      const int v = lane + 64 * s;
+      const float* pre_hi = lds.Ps + gl.hi[s];
+      const float* pre_lo = lds.Ps + gl.lo[s];
+      const float* yrow = lds.ys + gl.y[s] + h * kHalf;
+#pragma unroll
+      for (int k = 0; k < kHalf; k++) {
+        if (FULL || k < rows) {
+          const float pv = (pre_hi[k * PROW] - pre_lo[k * PROW]) + gl.isblank[s] * btot8[k];
+          const float g = yrow[k] - pv * __builtin_amdgcn_rcpf(st8[k]);
+          if (v < V) grads[(size_t)k * V + v] = g;
+        }
+      }
+    }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ps / invs are rewritten by the next half
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ps is rewritten by the next half
 }
 
 // what a segment needs from F1's workspace besides the probabilities; requested before the tile is staged so that
@@ -880,7 +922,7 @@ template <int PPL, bool FULL>
 __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg, int T, int S, int n,
                                              const LaneCells<PPL>& lc, const int (&rank)[PPL],
                                              const SegIn<PPL>& in,
-                                             const F2Lds<PPL>& lds, int lane, float& smin, float& smax) {
+                                             const F2Lds<PPL>& lds, const GradLanes& gl, int lane, float& smin, float& smax) {
   constexpr int NC = 2 * PPL;
   constexpr int kSlope = 3 * NC;    // exponent drop allowed per lane (see the alpha load below)
   constexpr int PROW = F2Lds<PPL>::PROW;
@@ -1076,7 +1118,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
     // what beta had removed down to it (at tt = 8, 0 -- after the row's product), minus the integer part of zt2
     const int ea_lo = in.EA0 + (h ? eA7 : 0), eb = in.EB16 + (h ? 0 : eB8);
     const int u_lo = unit_exp + ea_lo + eb - in.zint, u_hi = u_lo + (h ? eA15 : eA7);
-    finish_rows<PPL, FULL>(p, b, t0, n, h, lds, pb, lane, smin, smax, u_lo, u_hi, in.zfrac);
+    finish_rows<PPL, FULL>(p, b, t0, n, h, lds, gl, pb, lane, smin, smax, u_lo, u_hi, in.zfrac);
     F2_STAMP(6)
   }
 }
@@ -1159,12 +1201,15 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
       }
     }
   }
+  if (lane < kHalf) lds.Ps[lane * F2Lds<PPL>::PROW - 1] = 0.f;           // the rows' zero guards
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
+  GradLanes gl;
+  gl.init(lds, V, p.blank, lane);
   F2_STAMP(0)
   float smin = __builtin_huge_valf(), smax = 0.f;
   const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
-  if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, in, lds, lane, smin, smax);
-  else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, in, lds, lane, smin, smax);
+  if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, in, lds, gl, lane, smin, smax);
+  else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, in, lds, gl, lane, smin, smax);
 #ifdef E2E_FAST_PROFILE
   if (lane == 0) s_prof_acc[7] = ((unsigned long long)__float_as_uint(smin) << 32) | __float_as_uint(smax);
 #endif
@@ -1177,7 +1222,7 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   // redo for nothing, and with 2^-110 and no self-check a randomised sweep let gradients through that were off by 2e-3.
   // Rows between F1's rescales legitimately sit 2^-40 .. 2^-80 below the unit: alpha is rescaled at t%8 == 7 and beta
   // at t%8 == 0, so every row in between carries nine steps of decay.)
-  if (!(smin >= E2E_SMIN) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
+  if (!(smin > 0.f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
   if (seg == 0 && lane == 0) {
     const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
     if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
