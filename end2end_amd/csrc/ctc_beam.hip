@@ -2,13 +2,20 @@
 // Restates src/decoders/ctc_decoder.cpp:153-201 (driver), :353-441 (decode_sentence), :247-312
 // (get_next_prefix), :314-318 (score), :232-245 (get_sentence).
 //
-// One 256-thread workgroup per utterance; time is serial, the W*V (prefix, character) pairs of a step are
-// spread over the threads.  The prefix tree lives in a per-utterance node pool in HBM (L2 resident); the
-// reference's shared_ptr / weak_ptr ownership is restated as explicit reference counts:
-//   * a node is owned by its membership in the beam and by each live child (`parent` pointer);
-//   * the weak `next_data` map of a prefix is a V-entry child table that exists only while the prefix is in the
-//     beam (only beam members are ever asked for a child); a dying child clears its entry -- so a pruned child that
-//     is kept alive by a descendant is still found, receives probability, and is NOT re-added (quirk Q7).
+// One 1024-thread workgroup per utterance; time is serial, the W*V (prefix, character) pairs of a step are
+// spread over the threads.  The prefix tree lives in a per-utterance node pool in HBM (parent, character: written once,
+// read only for the final sentence).  The reference's shared_ptr / weak_ptr ownership -- a prefix lives while it is in
+// the beam or has a living child; the weak `next_data` entry of its parent expires when it dies -- is restated without
+// reference counts:
+//   * only beam members are ever asked for a child, so what has to be known is, for every member P and character c,
+//     whether the child (P, c) is alive, i.e. is a member or an ancestor of one (a pruned child that is kept alive by
+//     a descendant is still found, receives probability that nobody reads, and is NOT re-added: quirk Q7);
+//   * every member j carries its GUARD: the first prefix on its way to the root (itself included) whose parent is a
+//     member, as (owner = that parent's position in the beam, character, node id).  Every alive child of a member is
+//     the guard of some member (of itself, if it is one), so the members' child tables are REBUILT each step from the
+//     guards: cleared, then one LDS write per member.  When a guard's owner leaves the beam, the guard is inherited
+//     from the owner's own guard (the next alive prefix up the path whose parent is still a member).
+//   No global atomics, no reads of the node pool inside the step loop.
 // All scores are IEEE doubles with the reference's two-argument log-sum-exp.  The beam (probabilities, LM state, child
 // tables) lives in LDS; prefixes are created LAZILY: a step scores all W*V would-be prefixes, selects the W survivors
 // (8-pass radix select on an order-preserving 64-bit key, ties by position, then a one-wavefront bitonic sort of the
@@ -302,7 +309,7 @@ struct LmFields {
 // occupied".  Nodes are never reused: at most W prefixes are created per step, so W*(T+3) nodes cover an utterance
 // and allocation is a counter (no free list to initialise, read or write).
 struct BeamNode {
-  int parent, last_char, refs, pad;
+  int parent, last_char;
 };
 
 struct BeamParams {
@@ -311,7 +318,7 @@ struct BeamParams {
   int has_lm; LmView lm; double lmwt, wip, oov;
   int64_t* out; int64_t max_out; int64_t* out_len;
   BeamNode* nodes; int* status;                       // per-utterance workspace
-  int NCAP, TCAP, CMAX, WP2, HS;
+  int NCAP, CMAX, WP2, HS;
 };
 
 __device__ __forceinline__ double ninf() { return -__builtin_huge_val(); }
@@ -408,8 +415,9 @@ struct Members {
   double* npb; double* npnb;   // this step's prob_blank / prob_not_blank (become prev at next_step)
   double* inc;                 // contribution to prob_not_blank arriving from the parent (if it is in the beam)
   double* full;                // log_sum_exp(prev_pnb, prev_pb), once per member and step
-  int* node; int* last; int* tab; int* kept;
-  int* par;                    // node id of the parent prefix (-1: the root)
+  int* node; int* last; int* kept;
+  int* newpos;                 // position in the beam this step selects (valid where kept)
+  int* gown; int* gchar; int* gnode;   // the member's guard (see the file header): owner's position (-1: none), character, node
   LmFields* lm;
   __device__ unsigned char* carve(unsigned char* q, int W) {
     ppb = (double*)q; q += sizeof(double) * W; ppnb = (double*)q; q += sizeof(double) * W;
@@ -417,18 +425,19 @@ struct Members {
     inc = (double*)q; q += sizeof(double) * W; full = (double*)q; q += sizeof(double) * W;
     lm = (LmFields*)q; q += sizeof(LmFields) * W;
     node = (int*)q; q += sizeof(int) * W; last = (int*)q; q += sizeof(int) * W;
-    tab = (int*)q; q += sizeof(int) * W; kept = (int*)q; q += sizeof(int) * W;
-    par = (int*)q; q += sizeof(int) * W;
+    kept = (int*)q; q += sizeof(int) * W; newpos = (int*)q; q += sizeof(int) * W;
+    gown = (int*)q; q += sizeof(int) * W; gchar = (int*)q; q += sizeof(int) * W;
+    gnode = (int*)q; q += sizeof(int) * W;
     q += sizeof(int) * W;        // (pad: the next member set starts 8-byte aligned for any W)
     return q;
   }
-  __host__ __device__ static size_t bytes(int W) { return (size_t)W * (6 * sizeof(double) + sizeof(LmFields) + 6 * sizeof(int)); }
+  __host__ __device__ static size_t bytes(int W) { return (size_t)W * (6 * sizeof(double) + sizeof(LmFields) + 8 * sizeof(int)); }
 };
 
 struct BeamLds {
-  static size_t bytes(int W, int V, int CMAX, int TCAP, int WP2, int HS) {
+  static size_t bytes(int W, int V, int CMAX, int WP2, int HS) {
     return sizeof(double) * ((size_t)CMAX + 2 * V + WP2) +
-           sizeof(int) * ((size_t)CMAX + WP2 + (size_t)TCAP * V + TCAP + 2 * kSelBins + 64 + 4 * (size_t)HS) +
+           sizeof(int) * ((size_t)CMAX + WP2 + 2 * (size_t)W * V + 2 * kSelBins + 64 + 4 * (size_t)HS) +
            2 * Members::bytes(W) + 64;
   }
 };
@@ -483,13 +492,12 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   Members M0; M0.carve(mem0, W);
   int* newq = (int*)q8; q8 += sizeof(int) * p.CMAX;                  // pair index q = c*n + i of new candidate j
   int* sidx = (int*)q8; q8 += sizeof(int) * p.WP2;
-  int* ctab = (int*)q8; q8 += sizeof(int) * (size_t)p.TCAP * V;      // child tables of the beam members (weak next_data)
-  int* free_tabs = (int*)q8; q8 += sizeof(int) * p.TCAP;
+  int* const ctab0 = (int*)q8; q8 += sizeof(int) * 2 * (size_t)W * V; // [set][member][V] child tables (weak next_data)
   int* hist = (int*)q8; q8 += sizeof(int) * 2 * kSelBins;
   int* s_part = (int*)q8; q8 += sizeof(int) * 64;
   int* const sm0 = (int*)q8; q8 += sizeof(int) * 4 * p.HS;            // [set][key | val][HS]
   auto slot_map = [&](int set) { SlotMap m; m.key = sm0 + set * 2 * p.HS; m.val = m.key + p.HS; m.mask = p.HS - 1; return m; };
-  __shared__ int s_next_node, s_free_tabs, s_err, s_krem, s_done, s_bin;
+  __shared__ int s_next_node, s_err, s_krem, s_done, s_bin;
   __shared__ unsigned s_hi, s_lo;
   __shared__ unsigned long long s_prefix;
 
@@ -499,19 +507,18 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   const int T = Tq < 0 ? 0 : (Tq > p.T ? p.T : (int)Tq);
 
   // ---- pools, root prefix (get_initial_prefix, :222-230) ----
-  for (int i = tid; i < p.TCAP; i += kThreads) free_tabs[i] = p.TCAP - 1 - i;
-  for (int c = tid; c < V; c += kThreads) ctab[c] = -1;                              // table 0 = the root's
+  for (int c = tid; c < V; c += kThreads) ctab0[c] = -1;                             // set 0, member 0 = the root
   for (int h = tid; h < p.HS; h += kThreads) { sm0[h] = -1; sm0[2 * p.HS + h] = -1; }
   if (T > 0) for (int c = tid; c < V; c += kThreads) srow2[c] = (double)lp[(int64_t)c * p.sV];
   if (tid == 0) {
-    s_next_node = 1; s_free_tabs = p.TCAP - 1; s_err = 0;                           // node 0 / table 0 are taken
+    s_next_node = 1; s_err = 0;                                                     // node 0 is taken
     BeamNode& r = nodes[0];
-    r.parent = -1; r.last_char = -1; r.refs = 1; r.pad = 0;
+    r.parent = -1; r.last_char = -1;
     LmFields l;
     l.lm_score = 0.0; l.lm_before = 0.0; l.num_words = 0; l.num_oov = 0; l.num_oov_before = 0; l.word_len = 0;
     l.word_hash = kFnvInit; l.st_n = 0; l.stb_n = 0;
     if (p.has_lm) { l.st[0] = p.lm.bos; l.st_n = 1; l.stb[0] = p.lm.bos; l.stb_n = 1; }
-    M0.ppb[0] = 0.0; M0.ppnb[0] = ninf(); M0.node[0] = 0; M0.last[0] = -1; M0.tab[0] = 0; M0.par[0] = -1;
+    M0.ppb[0] = 0.0; M0.ppnb[0] = ninf(); M0.node[0] = 0; M0.last[0] = -1; M0.gown[0] = -1; M0.gchar[0] = 0; M0.gnode[0] = 0;
     M0.lm[0] = l;
   }
   __syncthreads();
@@ -529,6 +536,8 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     Bm.carve(mem0 + (size_t)(cur ^ 1) * mbytes, W);
     const SlotMap mapA = slot_map(cur);              // node -> position among the current members
     const SlotMap mapB = slot_map(cur ^ 1);          // ... among the members this step selects (filled in the rebuild)
+    const int* const ctab = ctab0 + (size_t)cur * W * V;          // child tables of the current members: [member][V]
+    int* const ctabB = ctab0 + (size_t)(cur ^ 1) * W * V;         // ... of the members this step selects
     double* const srow = srow2 + (t & 1) * V;
     // the next step's row is requested now and parked in LDS at the end of the step: no global round trip at a
     // step's start
@@ -536,6 +545,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     if (tid < V && t + 1 < T) next_lp = (double)lp[(int64_t)(t + 1) * p.sT + (int64_t)tid * p.sV];
     for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; A.full[i] = lse2(A.ppnb[i], A.ppb[i]); }
     for (int h = tid; h < p.HS; h += kThreads) mapB.key[h] = -1;
+    for (int e = tid; e < W * V; e += kThreads) ctabB[e] = -1;
     lds_barrier();
     // pairs in the reference's order: character outer, prefix inner (:370-395): q = c*n + i
     const int npairs = n * V;
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     int my_new = 0;
     for (int q = q0; q < q1; q++) {
       const int c = q / n, i = q - c * n;
-      if (c != blank && ctab[A.tab[i] * V + c] < 0) my_new++;
+      if (c != blank && ctab[i * V + c] < 0) my_new++;
     }
     const int incl = wave_scan_i(my_new);
     if (lane == 63) s_part[wid] = incl;
@@ -561,7 +571,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       const double full = A.full[i];
       if (c == blank) { A.npb[i] = curp + full; continue; }                    // :374-376 (prob_blank was -inf)
       const double val = curp + (c == A.last[i] ? A.ppb[i] : full);            // :383-385 / :389-391
-      const int k = ctab[A.tab[i] * V + c];
+      const int k = ctab[i * V + c];
       if (k >= 0) {
         const int j = mapA.find(k);
         if (j >= 0) A.inc[j] = val;            // the child is a beam member: its share from this parent
@@ -743,9 +753,10 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       const int d = sel[j];
       if (d < n) {
         const int i = d;
-        A.kept[i] = 1;
+        A.kept[i] = 1; A.newpos[i] = j;
         Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i];
-        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; Bm.tab[j] = A.tab[i]; Bm.par[j] = A.par[i]; Bm.lm[j] = A.lm[i];
+        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; Bm.lm[j] = A.lm[i];
+        Bm.gown[j] = A.gown[i]; Bm.gchar[j] = A.gchar[i]; Bm.gnode[j] = A.gnode[i];     // (owner: position in A, for now)
         mapB.insert(A.node[i], j);
       } else {
         const int q = newq[d - n];
@@ -757,53 +768,35 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         if (k >= p.NCAP) { s_err = 1; k = 0; }
         else {
           BeamNode nn;
-          nn.parent = A.node[i]; nn.last_char = c; nn.refs = 1; nn.pad = 0;
-          nodes[k] = nn;
-          atomicAdd(&nodes[A.node[i]].refs, 1);
-          ctab[A.tab[i] * V + c] = k;
+          nn.parent = A.node[i]; nn.last_char = c;
+          nodes[k] = nn;                                                          // (fire and forget)
           mapB.insert(k, j);
         }
-        Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.node[j] = k; Bm.last[j] = c; Bm.tab[j] = -1; Bm.par[j] = A.node[i];
+        Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.node[j] = k; Bm.last[j] = c;
+        Bm.gown[j] = i; Bm.gchar[j] = c; Bm.gnode[j] = k;                         // its own guard, if its parent stays
         Bm.lm[j] = nl;
       }
     }
-    __threadfence_block();
-    __syncthreads();
+    lds_barrier();
     BPROF(4);
-    // ---- members that left the beam: give the table back, drop the beam's reference, cascade (shared_ptr release) ----
-    // A prefix that dies expires in its parent's child table (weak_ptr); the parent holds a table only while it is
-    // a member of the beam this step started with, which the LDS map answers.  The first level needs no global read
-    // at all (the parent's id is cached with the member), only the reference-count atomics.
-    for (int i = tid; i < n; i += kThreads) {
-      if (A.kept[i]) continue;
-      free_tabs[atomicAdd(&s_free_tabs, 1)] = A.tab[i];
-      int k = A.node[i], par = A.par[i], lc = A.last[i];
-      bool known = true;                             // (par, lc) of k are at hand
-      while (k >= 0) {
-        int2 pl = make_int2(par, lc);
-        if (!known) pl = *reinterpret_cast<const int2*>(&nodes[k]);         // requested together with the atomic
-        if (atomicSub(&nodes[k].refs, 1) != 1) break;
-        par = pl.x; lc = pl.y;
-        if (par >= 0) { const int pi = mapA.find(par); if (pi >= 0) ctab[A.tab[pi] * V + lc] = -1; }   // weak_ptr expires
-        k = par; known = false;
+    // ---- guards and child tables of the new beam ----
+    // A guard whose owner left the beam is inherited from the owner's guard (the next alive prefix up the path whose
+    // parent was a member), until an owner that stays is found or the path runs out.  Every alive child of a member is
+    // some member's guard: writing the guards into the cleared tables reproduces exactly the entries whose weak_ptr has
+    // not expired upstream.
+    for (int j = tid; j < nsel; j += kThreads) {
+      int go = Bm.gown[j], gc = Bm.gchar[j], gn = Bm.gnode[j];
+      while (go >= 0 && !A.kept[go]) { const int o = go; go = A.gown[o]; gc = A.gchar[o]; gn = A.gnode[o]; }
+      if (go >= 0) {
+        const int o = A.newpos[go];
+        Bm.gown[j] = o; Bm.gchar[j] = gc; Bm.gnode[j] = gn;
+        ctabB[o * V + gc] = gn;
+      } else {
+        Bm.gown[j] = -1;
       }
     }
-    __threadfence_block();
     lds_barrier();
     BPROF(5);
-    // ---- new members get a child table ----
-    for (int j = tid; j < nsel; j += kThreads) {
-      if (Bm.tab[j] < 0) {
-        const int ti = atomicSub(&s_free_tabs, 1) - 1;
-        int tb = 0;
-        if (ti < 0) s_err = 2; else tb = free_tabs[ti];
-        Bm.tab[j] = tb;
-        for (int c = 0; c < V; c++) ctab[tb * V + c] = -1;
-      }
-    }
-    __threadfence_block();
-    __syncthreads();
-    BPROF(6);
     if (tid < V) srow2[((t + 1) & 1) * V + tid] = next_lp;          // (read after the first barrier of the next step)
     n = nsel; cur ^= 1;
     if (s_err) break;
@@ -838,17 +831,16 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   }
 }
 
-struct BeamLayout { size_t nodes, status, total, lds; int NCAP, TCAP, CMAX, WP2, HS; };
+struct BeamLayout { size_t nodes, status, total, lds; int NCAP, CMAX, WP2, HS; };
 
 BeamLayout beam_layout(int B, int T, int V, int W) {
   BeamLayout l;
   l.CMAX = W * V + W + 8;
   // live nodes: the beam and its ancestors (at most one root path of length <= T per member); at most W are created per step
   l.NCAP = W * (T + 3) + 8;
-  l.TCAP = 2 * W + 8;
   l.WP2 = 64; while (l.WP2 < W) l.WP2 <<= 1;
   l.HS = 256; while (l.HS < 4 * W) l.HS <<= 1;
-  l.lds = BeamLds::bytes(W, V, l.CMAX, l.TCAP, l.WP2, l.HS);
+  l.lds = BeamLds::bytes(W, V, l.CMAX, l.WP2, l.HS);
   size_t o = 0;
   l.nodes = o; o += align_up((size_t)B * l.NCAP * sizeof(BeamNode), 256);
   l.status = o; o += align_up((size_t)B * sizeof(int), 256);
@@ -896,7 +888,7 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   p.out = out; p.max_out = max_out; p.out_len = out_len;
   p.nodes = reinterpret_cast<BeamNode*>(ws + l.nodes);
   p.status = reinterpret_cast<int*>(ws + l.status);
-  p.NCAP = l.NCAP; p.TCAP = l.TCAP; p.CMAX = l.CMAX; p.WP2 = l.WP2; p.HS = l.HS;
+  p.NCAP = l.NCAP; p.CMAX = l.CMAX; p.WP2 = l.WP2; p.HS = l.HS;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == E2E_F32) {
     E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_beam_kernel<float>),
@@ -919,7 +911,7 @@ extern "C" int e2e_ctc_beam_status(const void* workspace, int B, int T, int V, i
   std::vector<int> st((size_t)B);
   if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
   if (B && hipMemcpy(st.data(), ws + l.status, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost) != hipSuccess) return E2E_ERR_HIP;
-  for (int v : st) if (v) { set_error("beam search: utterance status %d (1 node pool, 2 table pool, 3 output truncated)", v); return E2E_ERR_UNSUPPORTED; }
+  for (int v : st) if (v) { set_error("beam search: utterance status %d (1 node pool, 3 output truncated)", v); return E2E_ERR_UNSUPPORTED; }
   return E2E_OK;
 }
 
