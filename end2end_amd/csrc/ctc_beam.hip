@@ -359,6 +359,11 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // atomics before the release) and at the end of the step.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Candidate d >= n of a step is the pair q = d - n (q = c*n + i, the reference's order); a pair that creates no prefix
+// holds this marker instead of a score: a negative NaN, which the order-preserving key maps BELOW -inf (scores can
+// be -inf), and which every pass over the keys skips.
+constexpr unsigned long long kNoCandBits = 0xFFF8000000000000ULL;
+constexpr unsigned long long kNoCandKey = ~kNoCandBits;
 // order-preserving map double -> uint64 (larger double <=> larger key)
 __device__ __forceinline__ unsigned long long okey(double d) {
   unsigned long long u = (unsigned long long)__double_as_longlong(d);
@@ -436,8 +441,8 @@ struct Members {
 
 struct BeamLds {
   static size_t bytes(int W, int V, int CMAX, int WP2, int HS) {
-    return sizeof(double) * ((size_t)CMAX + 2 * V + WP2) +
-           sizeof(int) * ((size_t)CMAX + WP2 + 2 * (size_t)W * V + 2 * kSelBins + 64 + 4 * (size_t)HS) +
+    return sizeof(double) * ((size_t)CMAX + 2 * V + WP2 + kSelSmall) +
+           sizeof(int) * ((size_t)WP2 + kSelSmall + 2 * (size_t)W * V + 2 * kSelBins + 64 + 4 * (size_t)HS) +
            2 * Members::bytes(W) + 64;
   }
 };
@@ -480,9 +485,9 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   const int V = p.V, W = p.W, blank = p.blank;
   // ---- LDS carve-up ----
   unsigned char* q8 = smem;
-  double* key = (double*)q8; q8 += sizeof(double) * p.CMAX;          // score of candidate d (dense: old members, then new)
+  double* key = (double*)q8; q8 += sizeof(double) * p.CMAX;          // score of candidate d: old members, then the n*V pairs
   double* srow2 = (double*)q8; q8 += sizeof(double) * 2 * V;         // this step's and the next step's log-probabilities
-  double* skey = (double*)q8; q8 += sizeof(double) * p.WP2;          // the selected W, for the final ordering
+  double* skey = (double*)q8; q8 += sizeof(double) * (p.WP2 + kSelSmall);   // the gathered candidates, for the final ordering
   // (the two member sets and the two slot maps are addressed as "base + set * size", never through an array of
   // pointer structs: a pointer that went through memory loses its LDS address space and every access through it
   // becomes a FLAT instruction -- slower, and not ordered by an LDS-only barrier)
@@ -490,14 +495,13 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   const size_t mbytes = Members::bytes(W);
   q8 += 2 * mbytes;
   Members M0; M0.carve(mem0, W);
-  int* newq = (int*)q8; q8 += sizeof(int) * p.CMAX;                  // pair index q = c*n + i of new candidate j
-  int* sidx = (int*)q8; q8 += sizeof(int) * p.WP2;
+  int* sidx = (int*)q8; q8 += sizeof(int) * (p.WP2 + kSelSmall);
   int* const ctab0 = (int*)q8; q8 += sizeof(int) * 2 * (size_t)W * V; // [set][member][V] child tables (weak next_data)
   int* hist = (int*)q8; q8 += sizeof(int) * 2 * kSelBins;
   int* s_part = (int*)q8; q8 += sizeof(int) * 64;
   int* const sm0 = (int*)q8; q8 += sizeof(int) * 4 * p.HS;            // [set][key | val][HS]
   auto slot_map = [&](int set) { SlotMap m; m.key = sm0 + set * 2 * p.HS; m.val = m.key + p.HS; m.mask = p.HS - 1; return m; };
-  __shared__ int s_next_node, s_err, s_krem, s_done, s_bin;
+  __shared__ int s_next_node, s_err, s_krem, s_done, s_bin, s_total_new;
   __shared__ unsigned s_hi, s_lo;
   __shared__ unsigned long long s_prefix;
 
@@ -546,44 +550,48 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; A.full[i] = lse2(A.ppnb[i], A.ppb[i]); }
     for (int h = tid; h < p.HS; h += kThreads) mapB.key[h] = -1;
     for (int e = tid; e < W * V; e += kThreads) ctabB[e] = -1;
+    for (int h = tid; h < 2 * kSelBins; h += kThreads) hist[h] = 0;        // (the second half held the previous step's sel)
+    if (tid == 0) { s_hi = 0u; s_lo = 0xffffffffu; s_total_new = 0; }
     lds_barrier();
     // pairs in the reference's order: character outer, prefix inner (:370-395): q = c*n + i
     const int npairs = n * V;
     const int chunk = (npairs + kThreads - 1) / kThreads;
     const int q0 = min(tid * chunk, npairs), q1 = min(q0 + chunk, npairs);
-    // pass 1: which pairs would create a prefix?  (weak child lookup, :250-252)
+    const int c_first = q0 / n, i_first = q0 - c_first * n;                      // (the only division: the chunk walks on from here)
     int my_new = 0;
-    for (int q = q0; q < q1; q++) {
-      const int c = q / n, i = q - c * n;
-      if (c != blank && ctab[i * V + c] < 0) my_new++;
-    }
-    const int incl = wave_scan_i(my_new);
-    if (lane == 63) s_part[wid] = incl;
-    lds_barrier();
-    BPROF(0);
-    int base = 0, total_new = 0;
-    for (int w = 0; w < kThreads / 64; w++) { if (w < wid) base += s_part[w]; total_new += s_part[w]; }
-    int pos = base + incl - my_new;
-    // pass 2: blank shares, child shares, scores of the would-be prefixes
-    for (int q = q0; q < q1; q++) {
-      const int c = q / n, i = q - c * n;
-      const double curp = srow[c];
-      const double full = A.full[i];
-      if (c == blank) { A.npb[i] = curp + full; continue; }                    // :374-376 (prob_blank was -inf)
-      const double val = curp + (c == A.last[i] ? A.ppb[i] : full);            // :383-385 / :389-391
-      const int k = ctab[i * V + c];
+    // the pairs: blank shares, child shares, scores of the would-be prefixes (weak child lookup, :250-252)
+    // (the high words of the largest key of all and of the smallest key of the old members bracket the selection
+    // threshold; they are collected while the keys are produced)
+    unsigned key_hi = 0u, key_lo = 0xffffffffu;
+    for (int q = q0, c = c_first, i = i_first; q < q1; q++) {
+      const int ci = c, ii = i;
+      if (++i == n) { i = 0; c++; }
+      const double curp = srow[ci];
+      const double full = A.full[ii];
+      double* const slot = key + n + q;
+      *reinterpret_cast<unsigned long long*>(slot) = kNoCandBits;
+      if (ci == blank) { A.npb[ii] = curp + full; continue; }                  // :374-376 (prob_blank was -inf)
+      const double val = curp + (ci == A.last[ii] ? A.ppb[ii] : full);         // :383-385 / :389-391
+      const int k = ctab[ii * V + ci];
       if (k >= 0) {
         const int j = mapA.find(k);
         if (j >= 0) A.inc[j] = val;            // the child is a beam member: its share from this parent
         // else: alive but pruned (Q7) -- the probability is lost and the slot stays taken
       } else {
         LmFields nl;
-        child_lm(p, A.lm[i], A.last[i], c, nl);
-        newq[pos] = q;
-        key[n + pos] = beam_score(p, val, ninf(), nl);                        // after next_step: prev_pnb = val, prev_pb = -inf
-        pos++;
+        child_lm(p, A.lm[ii], A.last[ii], ci, nl);
+        const double sc = beam_score(p, val, ninf(), nl);                       // after next_step: prev_pnb = val, prev_pb = -inf
+        *slot = sc;
+        key_hi = max(key_hi, (unsigned)(okey(sc) >> 32));
+        my_new++;
       }
     }
+    {
+      const int incl = wave_scan_i(my_new);
+      if (lane == 63 && incl) atomicAdd(&s_total_new, incl);
+    }
+    key_hi = (unsigned)wave_max_i((int)(key_hi ^ 0x80000000u)) ^ 0x80000000u;     // (signed max on biased values)
+    if (lane == 0) atomicMax(&s_hi, key_hi);
     lds_barrier();
     BPROF(1);
     // members: repeated-character share (:386-387), next_step (:337-342), score
@@ -592,44 +600,38 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       double pnb = A.inc[i];
       if (lc >= 0 && lc != blank) pnb = lse2(pnb, srow[lc] + A.ppnb[i]);
       A.npnb[i] = pnb;
-      key[i] = beam_score(p, pnb, A.npb[i], A.lm[i]);
+      const double sc = beam_score(p, pnb, A.npb[i], A.lm[i]);
+      key[i] = sc;
+      const unsigned h32 = (unsigned)(okey(sc) >> 32);
+      key_hi = max(key_hi, h32); key_lo = min(key_lo, h32);
+    }
+    if (wid < (n + 63) / 64) {
+      key_hi = (unsigned)wave_max_i((int)(key_hi ^ 0x80000000u)) ^ 0x80000000u;
+      key_lo = ~((unsigned)wave_max_i((int)((~key_lo) ^ 0x80000000u)) ^ 0x80000000u);
+      if (lane == 0) { atomicMax(&s_hi, key_hi); atomicMin(&s_lo, key_lo); }
     }
     lds_barrier();
     BPROF(2);
-    const int ntot = n + total_new;
-    const int nsel = ntot > W ? W : ntot;
+    const int total_new = s_total_new;
+    const int nreal = n + total_new;                // candidates that exist
+    const int ntot = n + npairs;                    // entries of key[]
+    const int nsel = nreal > W ? W : nreal;
     int* const sel = hist + kSelBins;               // the selected candidates in beam order (valid after the block below)
-    if (ntot > W) {                                                              // :405-415
+    if (nreal > W) {                                                             // :405-415
       // ---- radix select of the W-th largest score on the order-preserving 64-bit key, 11 bits per pass ----
-      // Scores differ in their mantissas, so the first digit (sign + exponent) hardly splits them and the second
-      // normally isolates the threshold: as soon as the bin of the chosen digit holds exactly the remaining k
-      // (taken whole) or at most 64 candidates (finished exactly by one wave) the passes stop -- two passes in
-      // practice, six at most.  Two histograms alternate (the idle one is cleared while the other is scanned).
-      for (int h = tid; h < 2 * kSelBins; h += kThreads) hist[h] = 0;
-      if (tid == 0) { s_krem = W; s_done = 0; s_bin = 0; s_hi = 0u; s_lo = 0xffffffffu; }
-      lds_barrier();
       // Where to start: the threshold lies between the smallest score of a full beam's old members (W candidates are
-      // at least that good) and the largest score of all, so it shares their common leading bits -- found on the keys'
-      // high words with two cheap reductions.  Starting below them, the first digit already spreads the candidates
-      // that matter over the bins (a pass over the sign/exponent bits would put all of them into one).
-      {
-        unsigned hi = 0u, lo = 0xffffffffu;
-        for (int d = tid; d < ntot; d += kThreads) {
-          const unsigned h32 = (unsigned)(okey(key[d]) >> 32);
-          hi = max(hi, h32);
-          if (d < n) lo = min(lo, h32);
-        }
-        hi = (unsigned)wave_max_i((int)(hi ^ 0x80000000u)) ^ 0x80000000u;      // (signed max on biased values)
-        lo = ~((unsigned)wave_max_i((int)((~lo) ^ 0x80000000u)) ^ 0x80000000u);
-        if (lane == 0) { atomicMax(&s_hi, hi); atomicMin(&s_lo, lo); }
-      }
-      lds_barrier();
+      // at least that good) and the largest score of all, so it shares their common leading bits (s_hi / s_lo).
+      // Starting below them, the first digit already spreads the candidates that matter over the bins (a pass over
+      // the sign/exponent bits would put all of them into one): 1.01 passes per step measured.  A pass stops the
+      // search as soon as the bin of the chosen digit holds exactly the remaining k (taken whole) or at most 64
+      // candidates (ranked exactly below).  Two histograms alternate; both start the step cleared.
       const unsigned H32 = s_hi, L32 = n == W ? s_lo : 0u;
       const unsigned xdiff = H32 ^ L32;
       const int hb = xdiff ? 63 - __builtin_clz(xdiff) : 31;                    // highest bit that may differ
       unsigned long long mask = hb == 63 ? 0ULL : ~0ULL << (hb + 1);
-      if (tid == 0) s_prefix = ((unsigned long long)H32 << 32) & mask;
-      lds_barrier();
+      unsigned long long prefix = ((unsigned long long)H32 << 32) & mask;       // (decided bits: the same in every thread)
+      int krem = W, bin = 0;
+      bool done = false;
       int shift = hb + 1 - kSelBits;                                            // >= 21
       for (int pass = 0;; pass++) {
         int* hcur = hist + (pass & 1) * kSelBins;
@@ -637,114 +639,116 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         const int nbits = 64 - __builtin_popcountll(mask) - shift;                    // (the last digit may be short)
         const int width = nbits < kSelBits ? nbits : kSelBits;
         const unsigned long long dmask = (1ULL << width) - 1ULL;
-        const unsigned long long prefix = s_prefix;
         for (int d = tid; d < ntot; d += kThreads) {
           const unsigned long long u = okey(key[d]);
-          if ((u & mask) == prefix) atomicAdd(&hcur[(int)((u >> shift) & dmask)], 1);
+          if ((u & mask) == prefix && u != kNoCandKey) atomicAdd(&hcur[(int)((u >> shift) & dmask)], 1);
         }
         lds_barrier();
+        // the digit where the running count (from the top) reaches krem: every thread owns kPer adjacent bins
+        // (one wave walking 32 bins per lane paid a 64-way bank conflict on every read)
+        constexpr int kPer = kSelBins / kThreads;
+        static_assert(kPer * kThreads == kSelBins && kPer >= 1, "bins per thread");
+        const int top = kSelBins - 1 - kPer * tid;
+        int cnt[kPer], mine = 0;
+#pragma unroll
+        for (int jj = 0; jj < kPer; jj++) { cnt[jj] = hcur[top - jj]; mine += cnt[jj]; }
+        const int inc = wave_scan_i(mine);
+        if (lane == 63) s_part[wid] = inc;
+        if (pass > 0) {
+#pragma unroll
+          for (int jj = 0; jj < kPer; jj++) hnext[top - jj] = 0;
+        }
+        lds_barrier();
+        int above = inc - mine;                       // candidates with a larger digit than this thread's first
+        for (int w = 0; w < wid; w++) above += s_part[w];
         const unsigned long long digit_mask = dmask << shift;
-        if (wid == 0) {
-          // lane l owns the 32 digits 2047-32l .. 2016-32l (descending); find the digit where the running count reaches k
-          constexpr int kPer = kSelBins / 64;
-          const int top = kSelBins - 1 - kPer * lane;
-          int s32 = 0;
-          for (int j = 0; j < kPer; j++) s32 += hcur[top - j];
-          const int inc = wave_scan_i(s32);
-          int above = inc - s32;                      // elements with a larger digit than this lane's first
-          const int k = s_krem;
-          if (above < k && inc >= k) {                // the threshold digit is one of this lane's
-            for (int j = 0; j < kPer; j++) {
-              const int cj = hcur[top - j];
-              if (above + cj >= k) {
-                s_krem = k - above;
-                s_prefix = (prefix & ~digit_mask) | ((unsigned long long)(top - j) << shift);
-                s_bin = cj;
-                if (cj == k - above) s_done = 1;      // the whole bin survives: no finer threshold needed
-                break;
-              }
-              above += cj;
+        if (above < krem && above + mine >= krem) {   // the threshold digit is one of this thread's
+#pragma unroll
+          for (int jj = 0; jj < kPer; jj++) {
+            if (above + cnt[jj] >= krem) {
+              s_krem = krem - above;
+              s_prefix = (prefix & ~digit_mask) | ((unsigned long long)(top - jj) << shift);
+              s_bin = cnt[jj];
+              s_done = cnt[jj] == krem - above ? 1 : 0;     // the whole bin survives: no finer threshold needed
+              break;
             }
+            above += cnt[jj];
           }
-        } else {
-          for (int h = tid - 64; h < kSelBins; h += kThreads - 64) hnext[h] = 0;
         }
         mask |= digit_mask;
         lds_barrier();
-        if (s_done || shift == 0 || s_bin <= kSelSmall) break;
+        krem = s_krem; prefix = s_prefix; bin = s_bin; done = s_done != 0;
+#ifdef E2E_BEAM_PROFILE
+        if (b == 0 && tid == 0) g_beam_prof[10] += 1;
+#endif
+        if (done || shift == 0 || bin <= kSelSmall) break;
         shift = shift - kSelBits > 0 ? shift - kSelBits : 0;
+        lds_barrier();                                // (s_* are rewritten by the next pass)
       }
       BPROF(7);
-      // survivors: keys whose decided bits are above the threshold prefix, plus s_krem of those equal to it --
-      // all of them (taken whole), the first by position (every bit decided: exact ties), or the best s_krem by
-      // (score, position) of a small bin, which one wave works out below.
-      const unsigned long long Tk = s_prefix;
-      const int krem = s_krem;
-      const bool small_bin = !s_done && shift != 0;           // (then s_bin <= kSelSmall and s_bin > krem)
-      int* const glist = hist;                                 // candidates of the small bin, by position
+      // Gathered for the final ranking: keys whose decided bits are above the threshold prefix, plus those equal to
+      // it -- all of them if they are at most 64 (the ranking below keeps the best krem of them), else exactly krem:
+      // the whole bin, or (every bit decided: exact ties) the first by position.
+      const unsigned long long Tk = prefix;
+      const bool small_bin = !done && shift != 0;           // (then bin <= kSelSmall and bin > krem)
 #define OKEY_CMP(u) ((u) & mask)
       // ---- compaction: larger keys first, then the equal ones ----
       const int per = (ntot + kThreads - 1) / kThreads;
       const int d0 = min(tid * per, ntot), d1 = min(d0 + per, ntot);
       int ngt = 0, neq = 0;
-      for (int d = d0; d < d1; d++) { const unsigned long long u = OKEY_CMP(okey(key[d])); ngt += u > Tk; neq += u == Tk; }
+      for (int d = d0; d < d1; d++) {
+        const unsigned long long uf = okey(key[d]), u = OKEY_CMP(uf);
+        ngt += u > Tk; neq += u == Tk && uf != kNoCandKey;
+      }
       const int ig = wave_scan_i(ngt), ie = wave_scan_i(neq);
       if (lane == 63) { s_part[wid] = ig; s_part[16 + wid] = ie; }
       lds_barrier();
       int bg = 0, be = 0, tg = 0;
       for (int w = 0; w < kThreads / 64; w++) { if (w < wid) { bg += s_part[w]; be += s_part[16 + w]; } tg += s_part[w]; }
       int og = bg + ig - ngt, oe = be + ie - neq;
+      const int take = small_bin ? bin : krem;
       for (int d = d0; d < d1; d++) {
-        const unsigned long long u = OKEY_CMP(okey(key[d]));
+        const unsigned long long uf = okey(key[d]), u = OKEY_CMP(uf);
         if (u > Tk) { skey[og] = key[d]; sidx[og] = d; og++; }
-        else if (u == Tk) {
-          if (small_bin) glist[oe] = d;
-          else if (oe < krem) { skey[tg + oe] = key[d]; sidx[tg + oe] = d; }
+        else if (u == Tk && uf != kNoCandKey) {
+          if (oe < take) { skey[tg + oe] = key[d]; sidx[tg + oe] = d; }
           oe++;
         }
       }
 #undef OKEY_CMP
-      if (small_bin) {
-        lds_barrier();
-        if (wid == 0) {
-          // the best krem of the bin's g <= 64 candidates: one per lane, rank by counting
-          const int g = s_bin;
-          const int myd = lane < g ? glist[lane] : 0x7fffffff;
-          const double myk = lane < g ? key[lane < g ? myd : 0] : ninf();
-          int rank = 0;
-          for (int j = 0; j < g; j++) {
-            const int dj = glist[j];
-            const double kj = key[dj];
-            rank += (kj > myk || (kj == myk && dj < myd)) ? 1 : 0;
-          }
-          if (lane < g && rank < krem) { skey[tg + rank] = myk; sidx[tg + rank] = myd; }
-        }
-      }
+      const int M = tg + take;                      // W <= M <= W - 1 + kSelSmall gathered candidates
       lds_barrier();
       BPROF(8);
-      // ---- order the survivors: (score desc, position asc), rank by counting with every thread ----
-      {
-        for (int e = tid; e < W; e += kThreads) hist[e] = 0;            // (glist is dead; W <= kSelBins, checked by the host)
-        lds_barrier();
-        const int P = kThreads / W > 0 ? kThreads / W : 1;              // threads per survivor
-        for (int e = tid / P; e < W; e += kThreads / P) {
-          const int part = tid % P;
+      // ---- rank the gathered candidates by (score desc, position asc): eight lanes count for one candidate; rank < W
+      //      is the candidate's place in the new beam (the surplus of a small threshold bin falls off the end) ----
+      for (int e0 = 0; e0 < M; e0 += kThreads / 8) {
+        const int e = e0 + (tid >> 3), part = tid & 7;
+        int cnt = 0, de = 0;
+        if (e < M) {
           const double ke = skey[e];
-          const int de = sidx[e];
-          int cnt = 0;
-          for (int j = part; j < W; j += P) {
-            const double kj = skey[j];
-            const int dj = sidx[j];
+          de = sidx[e];
+          for (int jj = part; jj < M; jj += 8) {
+            const double kj = skey[jj];
+            const int dj = sidx[jj];
             cnt += (kj > ke || (kj == ke && dj < de)) ? 1 : 0;
           }
-          if (cnt) atomicAdd(&hist[e], cnt);
         }
-        lds_barrier();
-        for (int e = tid; e < W; e += kThreads) sel[hist[e]] = sidx[e];
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror: the other quad of the 8
+        if (e < M && part == 0 && cnt < W) sel[cnt] = de;
       }
       lds_barrier();
     } else {
-      for (int j = tid; j < ntot; j += kThreads) sel[j] = j;                      // unchanged order: old members, then new
+      // nothing is pruned (the first steps of an utterance): old members, then the pairs that exist, in order
+      for (int j = tid; j < n; j += kThreads) sel[j] = j;
+      const int incl = wave_scan_i(my_new);
+      if (lane == 63) s_part[wid] = incl;
+      lds_barrier();
+      int pos = n + incl - my_new;
+      for (int w = 0; w < wid; w++) pos += s_part[w];
+      for (int q = q0; q < q1; q++)
+        if (okey(key[n + q]) != kNoCandKey) sel[pos++] = n + q;
       lds_barrier();
     }
     BPROF(3);
@@ -759,7 +763,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         Bm.gown[j] = A.gown[i]; Bm.gchar[j] = A.gchar[i]; Bm.gnode[j] = A.gnode[i];     // (owner: position in A, for now)
         mapB.insert(A.node[i], j);
       } else {
-        const int q = newq[d - n];
+        const int q = d - n;
         const int c = q / n, i = q - c * n;
         const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : A.full[i]);
         LmFields nl;

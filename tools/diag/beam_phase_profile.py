@@ -16,7 +16,7 @@ eng.decode(x, xl); eng.decode(x, xl)
 buf = (C.c_ulonglong * 16)()
 L = _lib.load(); L.e2e_debug_beam_profile.argtypes = [C.c_void_p]
 assert L.e2e_debug_beam_profile(buf) == 0
-names = ["pass1+scan", "pass2 pairs", "members", "select: order", "rebuild", "guards+tables", "(unused)", "select: radix", "select: compact"]
-tot = sum(buf[:9])
+names = ["pass1+scan", "pass2 pairs", "members", "select: order", "rebuild", "guards+tables", "(unused)", "select: radix passes", "select: compact", "select: range of the keys"]
+tot = sum(buf[:10])
 for k, nm in enumerate(names): print("%-16s %8.0f cycles/step (%4.1f%%)" % (nm, buf[k] / T, 100.0 * buf[k] / tot))
-print("total %.0f cycles/step" % (tot / T))
+print("total %.0f cycles/step; radix passes per step %.2f" % (tot / T, buf[10] / T))
