@@ -371,12 +371,17 @@ __device__ __forceinline__ unsigned long long okey(double d) {
 }
 
 // the LM part of get_next_prefix (:258-308) for the child (parent pr, char c)
+// (LM = false: the kernel instantiated for decoding without a language model touches num_words only -- the word
+// insertion penalty needs it -- and none of the LM state, which otherwise costs the pair loop a third of its
+// instructions and the kernel its scratch memory)
+template <bool LM>
 __device__ __forceinline__ void child_lm(const BeamParams& p, const LmFields& pr, int parent_last, int c, LmFields& nn) {
   const bool new_word = c != p.space_id && (pr.num_words == 0 || parent_last == p.space_id);     // :258-259
   nn.num_words = pr.num_words + (new_word ? 1 : 0);
-  nn.lm_score = 0.0; nn.lm_before = 0.0; nn.num_oov = 0; nn.num_oov_before = 0;
+  nn.lm_score = 0.0; nn.num_oov = 0;
+  if (!LM) return;
+  nn.lm_before = 0.0; nn.num_oov_before = 0;
   nn.word_len = 0; nn.word_hash = kFnvInit; nn.st_n = 0; nn.stb_n = 0;
-  if (!p.has_lm) return;
   const double kLogE10 = 2.302585092994045684;
   if (c != p.space_id) {
     unsigned long long h = new_word ? kFnvInit : pr.word_hash;
@@ -410,8 +415,17 @@ __device__ __forceinline__ void child_lm(const BeamParams& p, const LmFields& pr
 }
 
 // get_prev_full_prob_with_lmwt, :314-318, from the already "next_step"-ed probabilities
+template <bool LM>
 __device__ __forceinline__ double beam_score(const BeamParams& p, double ppnb, double ppb, const LmFields& lm) {
-  return lse2(ppnb, ppb) + lm.lm_score * p.lmwt - lm.num_words * p.wip + lm.num_oov * p.oov;
+  // (without a language model lm_score and num_oov are zero for every prefix; the expression keeps its shape so that
+  // the result has the reference's bits for any lmwt / oov the caller passes)
+  const double lm_score = LM ? lm.lm_score : 0.0;
+  const int num_oov = LM ? lm.num_oov : 0;
+  return lse2(ppnb, ppb) + lm_score * p.lmwt - lm.num_words * p.wip + num_oov * p.oov;
+}
+template <bool LM>
+__device__ __forceinline__ void copy_lm(LmFields& dst, const LmFields& src) {
+  if (LM) dst = src; else dst.num_words = src.num_words;
 }
 
 // members of the beam, structure of arrays in LDS (two copies: the beam is rebuilt into the other one every step)
@@ -478,7 +492,7 @@ namespace e2e { namespace {
 #define BPROF(slot) do {} while (0)
 #endif
 
-template <typename IO>
+template <typename IO, bool LM>
 __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -579,8 +593,8 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         // else: alive but pruned (Q7) -- the probability is lost and the slot stays taken
       } else {
         LmFields nl;
-        child_lm(p, A.lm[ii], A.last[ii], ci, nl);
-        const double sc = beam_score(p, val, ninf(), nl);                       // after next_step: prev_pnb = val, prev_pb = -inf
+        child_lm<LM>(p, A.lm[ii], A.last[ii], ci, nl);
+        const double sc = beam_score<LM>(p, val, ninf(), nl);                       // after next_step: prev_pnb = val, prev_pb = -inf
         *slot = sc;
         key_hi = max(key_hi, (unsigned)(okey(sc) >> 32));
         my_new++;
@@ -600,7 +614,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       double pnb = A.inc[i];
       if (lc >= 0 && lc != blank) pnb = lse2(pnb, srow[lc] + A.ppnb[i]);
       A.npnb[i] = pnb;
-      const double sc = beam_score(p, pnb, A.npb[i], A.lm[i]);
+      const double sc = beam_score<LM>(p, pnb, A.npb[i], A.lm[i]);
       key[i] = sc;
       const unsigned h32 = (unsigned)(okey(sc) >> 32);
       key_hi = max(key_hi, h32); key_lo = min(key_lo, h32);
@@ -641,6 +655,9 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         const unsigned long long dmask = (1ULL << width) - 1ULL;
         for (int d = tid; d < ntot; d += kThreads) {
           const unsigned long long u = okey(key[d]);
+#ifdef E2E_BEAM_PROFILE
+          if (b == 0 && pass == 0 && u != kNoCandKey && (unsigned)(u >> 32) >= L32) atomicAdd((unsigned long long*)&g_beam_prof[11], 1ULL);
+#endif
           if ((u & mask) == prefix && u != kNoCandKey) atomicAdd(&hcur[(int)((u >> shift) & dmask)], 1);
         }
         lds_barrier();
@@ -759,7 +776,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         const int i = d;
         A.kept[i] = 1; A.newpos[i] = j;
         Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i];
-        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; Bm.lm[j] = A.lm[i];
+        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; copy_lm<LM>(Bm.lm[j], A.lm[i]);
         Bm.gown[j] = A.gown[i]; Bm.gchar[j] = A.gchar[i]; Bm.gnode[j] = A.gnode[i];     // (owner: position in A, for now)
         mapB.insert(A.node[i], j);
       } else {
@@ -767,7 +784,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         const int c = q / n, i = q - c * n;
         const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : A.full[i]);
         LmFields nl;
-        child_lm(p, A.lm[i], A.last[i], c, nl);
+        child_lm<LM>(p, A.lm[i], A.last[i], c, nl);
         int k = atomicAdd(&s_next_node, 1);                                       // make_shared<Prefix>, :254
         if (k >= p.NCAP) { s_err = 1; k = 0; }
         else {
@@ -778,7 +795,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         }
         Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.node[j] = k; Bm.last[j] = c;
         Bm.gown[j] = i; Bm.gchar[j] = c; Bm.gnode[j] = k;                         // its own guard, if its parent stays
-        Bm.lm[j] = nl;
+        copy_lm<LM>(Bm.lm[j], nl);
       }
     }
     lds_barrier();
@@ -810,7 +827,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   {
     Members A;
     A.carve(mem0 + (size_t)cur * mbytes, W);
-    for (int i = tid; i < n; i += kThreads) key[i] = beam_score(p, A.ppnb[i], A.ppb[i], A.lm[i]);
+    for (int i = tid; i < n; i += kThreads) key[i] = beam_score<LM>(p, A.ppnb[i], A.ppb[i], A.lm[i]);
     __syncthreads();
   }
   int64_t* out = p.out + (int64_t)b * p.max_out;
@@ -894,15 +911,11 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   p.status = reinterpret_cast<int*>(ws + l.status);
   p.NCAP = l.NCAP; p.CMAX = l.CMAX; p.WP2 = l.WP2; p.HS = l.HS;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == E2E_F32) {
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_beam_kernel<float>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_beam_kernel<float>, dim3(B), dim3(kThreads), l.lds, s, p);
-  } else {
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_beam_kernel<double>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_beam_kernel<double>, dim3(B), dim3(kThreads), l.lds, s, p);
-  }
+  const void* fn = dtype == E2E_F32 ? (lm ? (const void*)&ctc_beam_kernel<float, true> : (const void*)&ctc_beam_kernel<float, false>)
+                                    : (lm ? (const void*)&ctc_beam_kernel<double, true> : (const void*)&ctc_beam_kernel<double, false>);
+  E2E_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds), "hipFuncSetAttribute");
+  void* args[] = { &p };
+  E2E_HIP_CHECK(hipLaunchKernel(fn, dim3(B), dim3(kThreads), args, l.lds, s), "ctc_beam_kernel launch");
   E2E_HIP_CHECK(hipGetLastError(), "ctc_beam_kernel launch");
   return E2E_OK;
 }

@@ -19,4 +19,4 @@ assert L.e2e_debug_beam_profile(buf) == 0
 names = ["pass1+scan", "pass2 pairs", "members", "select: order", "rebuild", "guards+tables", "(unused)", "select: radix passes", "select: compact", "select: range of the keys"]
 tot = sum(buf[:10])
 for k, nm in enumerate(names): print("%-16s %8.0f cycles/step (%4.1f%%)" % (nm, buf[k] / T, 100.0 * buf[k] / tot))
-print("total %.0f cycles/step; radix passes per step %.2f" % (tot / T, buf[10] / T))
+print("total %.0f cycles/step; radix passes per step %.2f; candidates at or above the old members' minimum: %.0f per step" % (tot / T, buf[10] / T, buf[11] / T))
