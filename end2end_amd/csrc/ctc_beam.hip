@@ -713,9 +713,13 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       const int per = (ntot + kThreads - 1) / kThreads;
       const int d0 = min(tid * per, ntot), d1 = min(d0 + per, ntot);
       int ngt = 0, neq = 0;
-      for (int d = d0; d < d1; d++) {
+      unsigned cls = 0;                              // two bits per candidate of this thread: 1 above, 2 in the threshold bin
+      static_assert(kMaxCand <= 16 * kThreads, "classification bits per thread");
+      for (int d = d0, sh2 = 0; d < d1; d++, sh2 += 2) {
         const unsigned long long uf = okey(key[d]), u = OKEY_CMP(uf);
-        ngt += u > Tk; neq += u == Tk && uf != kNoCandKey;
+        const bool gt = u > Tk, eq = u == Tk && uf != kNoCandKey;
+        ngt += gt; neq += eq;
+        cls |= (gt ? 1u : eq ? 2u : 0u) << sh2;
       }
       const int ig = wave_scan_i(ngt), ie = wave_scan_i(neq);
       if (lane == 63) { s_part[wid] = ig; s_part[16 + wid] = ie; }
@@ -724,10 +728,9 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       for (int w = 0; w < kThreads / 64; w++) { if (w < wid) { bg += s_part[w]; be += s_part[16 + w]; } tg += s_part[w]; }
       int og = bg + ig - ngt, oe = be + ie - neq;
       const int take = small_bin ? bin : krem;
-      for (int d = d0; d < d1; d++) {
-        const unsigned long long uf = okey(key[d]), u = OKEY_CMP(uf);
-        if (u > Tk) { skey[og] = key[d]; sidx[og] = d; og++; }
-        else if (u == Tk && uf != kNoCandKey) {
+      for (int d = d0; d < d1 && cls; d++, cls >>= 2) {
+        if (cls & 1u) { skey[og] = key[d]; sidx[og] = d; og++; }
+        else if (cls & 2u) {
           if (oe < take) { skey[tg + oe] = key[d]; sidx[tg + oe] = d; }
           oe++;
         }
@@ -740,20 +743,21 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       //      is the candidate's place in the new beam (the surplus of a small threshold bin falls off the end) ----
       for (int e0 = 0; e0 < M; e0 += kThreads / 8) {
         const int e = e0 + (tid >> 3), part = tid & 7;
-        int cnt = 0, de = 0;
+        int cnt = 0;
         if (e < M) {
+          // (the gathered list is in position order within its two parts, and the keys of the first part are all
+          // larger than those of the second: among equal keys the earlier list index is the earlier position)
           const double ke = skey[e];
-          de = sidx[e];
+#pragma unroll 4
           for (int jj = part; jj < M; jj += 8) {
             const double kj = skey[jj];
-            const int dj = sidx[jj];
-            cnt += (kj > ke || (kj == ke && dj < de)) ? 1 : 0;
+            cnt += (kj > ke || (kj == ke && jj < e)) ? 1 : 0;
           }
         }
         cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
         cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
         cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror: the other quad of the 8
-        if (e < M && part == 0 && cnt < W) sel[cnt] = de;
+        if (e < M && part == 0 && cnt < W) sel[cnt] = sidx[e];
       }
       lds_barrier();
     } else {
