@@ -44,6 +44,11 @@ constexpr int kLmMaxOrder = 6;     // KENLM_MAX_ORDER=6, CMakeLists.txt:36
 constexpr int kCtx = kLmMaxOrder - 1;
 
 struct NgSlot { uint32_t ids[kLmMaxOrder]; int32_t n; float prob; float backoff; };
+// The same tables in the form the kernel probes: one 16-byte load per probe, matched by the n-gram's 64-bit hash
+// (the loader checks that no two n-grams of the model share one; a queried n-gram that is NOT in the model would have
+// to collide in all 64 bits with the entry at its probe position to be mistaken for it).
+struct NgSig { uint64_t sig; float prob; float backoff; };       // sig 0: empty
+struct VEntry { uint64_t key; uint32_t val; uint32_t pad; };     // key 0: empty
 
 struct LmView {                    // what the kernel sees (device pointers) / what the host scorer sees
   int order;
@@ -52,16 +57,20 @@ struct LmView {                    // what the kernel sees (device pointers) / w
   uint32_t bos;
   const unsigned char* label_bytes; const int* label_off;   // label c spells bytes [off[c], off[c+1])
   int fold_case;
+  const NgSig* ngs; const VEntry* vt;                        // device only (null: n-gram hashes collide, use ng / vkeys)
+  float unk_prob;                                            // p(<unk>) (KenLM's -100 if the model has none)
 };
 
 __host__ __device__ inline uint64_t fnv_step(uint64_t h, unsigned char b) { return (h ^ b) * 1099511628211ULL; }
 constexpr uint64_t kFnvInit = 1469598103934665603ULL;
 
+// hash of an n-gram of word ids (table placement and signature; internal to this file): one multiply per id
+__host__ __device__ inline uint64_t ng_mix(uint64_t h, uint32_t id) { h = (h ^ id) * 0x9E3779B97F4A7C15ULL; return h ^ (h >> 32); }
+__host__ __device__ inline uint64_t ng_finish(uint64_t h, int n) { h = ng_mix(h, 0x51ED2700u + (uint32_t)n); return h == 0 ? 1 : h; }
 __host__ __device__ inline uint64_t ngram_hash(const uint32_t* ids, int n) {
-  uint64_t h = kFnvInit ^ (uint64_t)n;
-  for (int i = 0; i < n; i++)
-    for (int b = 0; b < 4; b++) h = fnv_step(h, (unsigned char)(ids[i] >> (8 * b)));
-  return h;
+  uint64_t h = kFnvInit;
+  for (int i = 0; i < n; i++) h = ng_mix(h, ids[i]);
+  return ng_finish(h, n);
 }
 
 __host__ __device__ inline uint32_t lm_word_lookup(const LmView& lm, uint64_t h) {
@@ -126,13 +135,15 @@ struct e2e_lm {
   // device copies
   uint64_t* d_vkeys = nullptr; uint32_t* d_vvals = nullptr; e2e::NgSlot* d_ng = nullptr;
   unsigned char* d_label_bytes = nullptr; int* d_label_off = nullptr;
+  e2e::NgSig* d_ngs = nullptr; e2e::VEntry* d_vt = nullptr;     // (d_ngs stays null if two n-grams share a hash)
+  float unk_prob = -100.f;
   e2e::LmView host_view() const {
     return {order, vkeys.data(), vvals.data(), (uint32_t)vkeys.size() - 1, ng.data(), (uint32_t)ng.size() - 1, bos,
-            label_bytes.data(), label_off.data(), fold_case};
+            label_bytes.data(), label_off.data(), fold_case, nullptr, nullptr, unk_prob};
   }
   e2e::LmView dev_view() const {
     return {order, d_vkeys, d_vvals, (uint32_t)vkeys.size() - 1, d_ng, (uint32_t)ng.size() - 1, bos,
-            d_label_bytes, d_label_off, fold_case};
+            d_label_bytes, d_label_off, fold_case, d_ngs, d_ngs ? d_vt : nullptr, unk_prob};
   }
 };
 
@@ -245,7 +256,27 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
     if (hipMalloc(d, bytes) != hipSuccess) return false;
     return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
   };
-  bool ok = up((void**)&lm->d_vkeys, lm->vkeys.data(), lm->vkeys.size() * sizeof(uint64_t)) &&
+  // the kernel's 16-byte forms of the two tables (same slots)
+  std::vector<NgSig> ngs(lm->ng.size(), NgSig{0, 0.f, 0.f});
+  bool sig_ok = true;
+  {
+    std::vector<uint64_t> seen;
+    seen.reserve(entries.size());
+    for (size_t i = 0; i < lm->ng.size(); i++) {
+      const NgSlot& sl = lm->ng[i];
+      if (sl.n == 0) continue;
+      ngs[i].sig = ngram_hash(sl.ids, sl.n); ngs[i].prob = sl.prob; ngs[i].backoff = sl.backoff;
+      seen.push_back(ngs[i].sig);
+      if (sl.n == 1 && sl.ids[0] == 0) lm->unk_prob = sl.prob;
+    }
+    std::sort(seen.begin(), seen.end());
+    sig_ok = std::adjacent_find(seen.begin(), seen.end()) == seen.end();
+  }
+  std::vector<VEntry> vt(lm->vkeys.size());
+  for (size_t i = 0; i < vt.size(); i++) vt[i] = VEntry{lm->vkeys[i], lm->vvals[i], 0u};
+  bool ok = (!sig_ok || up((void**)&lm->d_ngs, ngs.data(), ngs.size() * sizeof(NgSig))) &&
+            up((void**)&lm->d_vt, vt.data(), vt.size() * sizeof(VEntry)) &&
+            up((void**)&lm->d_vkeys, lm->vkeys.data(), lm->vkeys.size() * sizeof(uint64_t)) &&
             up((void**)&lm->d_vvals, lm->vvals.data(), lm->vvals.size() * sizeof(uint32_t)) &&
             up((void**)&lm->d_ng, lm->ng.data(), lm->ng.size() * sizeof(NgSlot)) &&
             up((void**)&lm->d_label_bytes, lm->label_bytes.data(), lm->label_bytes.size()) &&
@@ -254,8 +285,9 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
     // no usable GPU: keep the host tables (e2e_lm_word_index / e2e_lm_score still work); e2e_ctc_beam refuses it
     (void)hipGetLastError();
     (void)hipFree(lm->d_vkeys); (void)hipFree(lm->d_vvals); (void)hipFree(lm->d_ng);
-    (void)hipFree(lm->d_label_bytes); (void)hipFree(lm->d_label_off);
+    (void)hipFree(lm->d_label_bytes); (void)hipFree(lm->d_label_off); (void)hipFree(lm->d_ngs); (void)hipFree(lm->d_vt);
     lm->d_vkeys = nullptr; lm->d_vvals = nullptr; lm->d_ng = nullptr; lm->d_label_bytes = nullptr; lm->d_label_off = nullptr;
+    lm->d_ngs = nullptr; lm->d_vt = nullptr;
   }
   *out = lm;
   return E2E_OK;
@@ -264,7 +296,7 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
 extern "C" void e2e_lm_free(e2e_lm* lm) {
   if (!lm) return;
   (void)hipFree(lm->d_vkeys); (void)hipFree(lm->d_vvals); (void)hipFree(lm->d_ng);
-  (void)hipFree(lm->d_label_bytes); (void)hipFree(lm->d_label_off);
+  (void)hipFree(lm->d_label_bytes); (void)hipFree(lm->d_label_off); (void)hipFree(lm->d_ngs); (void)hipFree(lm->d_vt);
   delete lm;
 }
 
@@ -371,11 +403,93 @@ __device__ __forceinline__ unsigned long long okey(double d) {
 }
 
 // the LM part of get_next_prefix (:258-308) for the child (parent pr, char c)
+// What a (prefix, character != space) pair asks of the language model: the id of the word spelled so far and its
+// score in the prefix's context.  The answer depends on the prefix's LM state and the character only -- not on the time
+// step -- so a beam member's V answers are looked up ONCE, when it enters the beam, by V different threads, and kept
+// in LDS while it stays (`lmc`): the pair loop and the rebuild then read them instead of walking the n-gram tables
+// (global memory, several dependent probes) for every pair of every step.
+struct LmAnswer { float sc; uint32_t wi; };
+__device__ __forceinline__ unsigned long long spell(const BeamParams& p, unsigned long long h, int c) {
+  for (int bi = p.lm.label_off[c]; bi < p.lm.label_off[c + 1]; bi++) {
+    unsigned char ch = p.lm.label_bytes[bi];
+    if (p.lm.fold_case && ch >= 'A' && ch <= 'Z') ch += 32;
+    h = fnv_step(h, ch);
+  }
+  return h;
+}
+// one n-gram of the signature table: the first probe's entry is already loaded
+__device__ __forceinline__ bool ngs_resolve(const LmView& lm, uint64_t h, NgSig e, float& prob, float& backoff) {
+  for (uint32_t i = (uint32_t)h & lm.ngmask;;) {
+    if (e.sig == h) { prob = e.prob; backoff = e.backoff; return true; }
+    if (e.sig == 0) return false;
+    i = (i + 1) & lm.ngmask;
+    e = lm.ngs[i];
+  }
+}
+// lm_base_score for contexts of up to kParCtx words with every table probe of the back-off chain in flight at once:
+// the (k+1)-grams (ctx[k-1..0], word) and the context k-grams whose back-off weights the chain may need are hashed
+// first, their entries requested together, and only then combined in the chain's order (same float additions).
+constexpr int kParCtx = 3;
+__device__ __forceinline__ float lm_score_parallel(const LmView& lm, const uint32_t (&ctx)[kCtx], int n, uint32_t word) {
+  uint64_t hf[kParCtx + 1], hb[kParCtx + 1];
+  NgSig ef[kParCtx + 1], eb[kParCtx + 1];
+#pragma unroll
+  for (int k = 0; k <= kParCtx; k++) {
+    uint64_t h = kFnvInit;
+#pragma unroll
+    for (int i = 0; i < k; i++) h = ng_mix(h, ctx[k - 1 - i]);
+    hb[k] = ng_finish(h, k);
+    hf[k] = ng_finish(ng_mix(h, word), k + 1);
+  }
+#pragma unroll
+  for (int k = 0; k <= kParCtx; k++) {
+    if (k <= n) ef[k] = lm.ngs[(uint32_t)hf[k] & lm.ngmask];
+    if (k >= 1 && k <= n) eb[k] = lm.ngs[(uint32_t)hb[k] & lm.ngmask];
+  }
+  float acc = 0.f, result = 0.f;
+  bool found = false;
+#pragma unroll
+  for (int k = kParCtx; k >= 0; k--) {
+    if (k <= n && !found) {
+      float pr = 0.f, bo = 0.f;
+      if (ngs_resolve(lm, hf[k], ef[k], pr, bo)) { result = acc + pr; found = true; }
+      else if (k > 0 && ngs_resolve(lm, hb[k], eb[k], pr, bo)) acc += bo;
+    }
+  }
+  if (!found) result = acc + lm.unk_prob;
+  return result;
+}
+__device__ __forceinline__ LmAnswer lm_query(const BeamParams& p, const LmFields& pr, int parent_last, int c) {
+  const bool new_word = pr.num_words == 0 || parent_last == p.space_id;                           // :258-259 (c != space)
+  LmAnswer a;
+  uint64_t h = spell(p, new_word ? kFnvInit : pr.word_hash, c);
+  uint32_t ctx[kCtx];
+  int cn = new_word ? pr.st_n : pr.stb_n;
+#pragma unroll
+  for (int s2 = 0; s2 < kCtx; s2++) ctx[s2] = new_word ? pr.st[s2] : pr.stb[s2];
+  if (p.lm.ngs) {
+    if (h == 0) h = 1;
+    a.wi = 0;
+    for (uint32_t i = (uint32_t)h & p.lm.vmask;; i = (i + 1) & p.lm.vmask) {
+      const VEntry e = p.lm.vt[i];
+      if (e.key == h) { a.wi = e.val; break; }
+      if (e.key == 0) break;                      // NotFound() == <unk> == 0
+    }
+    if (cn > p.lm.order - 1) cn = p.lm.order - 1;
+    if (cn <= kParCtx) { a.sc = lm_score_parallel(p.lm, ctx, cn, a.wi); return a; }
+  } else {
+    a.wi = lm_word_lookup(p.lm, h);
+  }
+  a.sc = lm_base_score(p.lm, ctx, cn, a.wi, nullptr, nullptr);
+  return a;
+}
+
+// the LM part of get_next_prefix (:258-308) for the child (parent pr, char c), given the LM's answer for the pair
 // (LM = false: the kernel instantiated for decoding without a language model touches num_words only -- the word
 // insertion penalty needs it -- and none of the LM state, which otherwise costs the pair loop a third of its
 // instructions and the kernel its scratch memory)
 template <bool LM>
-__device__ __forceinline__ void child_lm(const BeamParams& p, const LmFields& pr, int parent_last, int c, LmFields& nn) {
+__device__ __forceinline__ void child_lm(const BeamParams& p, const LmFields& pr, int parent_last, int c, LmAnswer ans, LmFields& nn) {
   const bool new_word = c != p.space_id && (pr.num_words == 0 || parent_last == p.space_id);     // :258-259
   nn.num_words = pr.num_words + (new_word ? 1 : 0);
   nn.lm_score = 0.0; nn.num_oov = 0;
@@ -384,14 +498,8 @@ __device__ __forceinline__ void child_lm(const BeamParams& p, const LmFields& pr
   nn.word_len = 0; nn.word_hash = kFnvInit; nn.st_n = 0; nn.stb_n = 0;
   const double kLogE10 = 2.302585092994045684;
   if (c != p.space_id) {
-    unsigned long long h = new_word ? kFnvInit : pr.word_hash;
-    for (int bi = p.lm.label_off[c]; bi < p.lm.label_off[c + 1]; bi++) {
-      unsigned char ch = p.lm.label_bytes[bi];
-      if (p.lm.fold_case && ch >= 'A' && ch <= 'Z') ch += 32;
-      h = fnv_step(h, ch);
-    }
-    nn.word_hash = h; nn.word_len = (new_word ? 0 : pr.word_len) + 1;
-    const uint32_t wi = lm_word_lookup(p.lm, h);
+    nn.word_hash = spell(p, new_word ? kFnvInit : pr.word_hash, c);
+    nn.word_len = (new_word ? 0 : pr.word_len) + 1;
     if (new_word) {                                                       // :265-281
       for (int s = 0; s < pr.st_n; s++) nn.stb[s] = pr.st[s];
       nn.stb_n = pr.st_n; nn.lm_before = pr.lm_score; nn.num_oov_before = pr.num_oov;
@@ -399,11 +507,14 @@ __device__ __forceinline__ void child_lm(const BeamParams& p, const LmFields& pr
       for (int s = 0; s < pr.stb_n; s++) nn.stb[s] = pr.stb[s];
       nn.stb_n = pr.stb_n; nn.lm_before = pr.lm_before; nn.num_oov_before = pr.num_oov_before;
     }
-    int on = 0;
-    const float sc = lm_base_score(p.lm, nn.stb, nn.stb_n, wi, nn.st, &on);
-    nn.st_n = on;
-    nn.lm_score = nn.lm_before + (double)sc / kLogE10;                     // quirk Q8: divides by ln 10
-    nn.num_oov = nn.num_oov_before + (wi == 0 ? 1 : 0);
+    // the state after the word: the word, then the context it was scored in (lm_base_score's out_ctx)
+    int m = nn.stb_n; if (m > p.lm.order - 1) m = p.lm.order - 1;
+    m = m + 1; if (m > p.lm.order - 1) m = p.lm.order - 1;
+    if (m > 0) nn.st[0] = ans.wi;
+    for (int s = 1; s < m; s++) nn.st[s] = nn.stb[s - 1];
+    nn.st_n = m;
+    nn.lm_score = nn.lm_before + (double)ans.sc / kLogE10;                 // quirk Q8: divides by ln 10
+    nn.num_oov = nn.num_oov_before + (ans.wi == 0 ? 1 : 0);
   } else {                                                                // :299-307 copy
     nn.word_hash = pr.word_hash; nn.word_len = pr.word_len;
     nn.lm_score = pr.lm_score; nn.lm_before = pr.lm_before;
@@ -411,6 +522,23 @@ __device__ __forceinline__ void child_lm(const BeamParams& p, const LmFields& pr
     for (int s = 0; s < pr.st_n; s++) nn.st[s] = pr.st[s];
     for (int s = 0; s < pr.stb_n; s++) nn.stb[s] = pr.stb[s];
     nn.st_n = pr.st_n; nn.stb_n = pr.stb_n;
+  }
+}
+// ... and only what the score of the would-be prefix needs (the pair loop)
+template <bool LM>
+__device__ __forceinline__ void child_score_fields(const BeamParams& p, const LmFields& pr, int parent_last, int c, LmAnswer ans, LmFields& nn) {
+  const bool new_word = c != p.space_id && (pr.num_words == 0 || parent_last == p.space_id);
+  nn.num_words = pr.num_words + (new_word ? 1 : 0);
+  nn.lm_score = 0.0; nn.num_oov = 0;
+  if (!LM) return;
+  const double kLogE10 = 2.302585092994045684;
+  if (c != p.space_id) {
+    const double before = new_word ? pr.lm_score : pr.lm_before;
+    const int oov_before = new_word ? pr.num_oov : pr.num_oov_before;
+    nn.lm_score = before + (double)ans.sc / kLogE10;
+    nn.num_oov = oov_before + (ans.wi == 0 ? 1 : 0);
+  } else {
+    nn.lm_score = pr.lm_score; nn.num_oov = pr.num_oov;
   }
 }
 
@@ -437,6 +565,7 @@ struct Members {
   int* node; int* last; int* kept;
   int* newpos;                 // position in the beam this step selects (valid where kept)
   int* gown; int* gchar; int* gnode;   // the member's guard (see the file header): owner's position (-1: none), character, node
+  int* from;                   // position in the previous beam (-1: the member is new)
   LmFields* lm;
   __device__ unsigned char* carve(unsigned char* q, int W) {
     ppb = (double*)q; q += sizeof(double) * W; ppnb = (double*)q; q += sizeof(double) * W;
@@ -447,17 +576,17 @@ struct Members {
     kept = (int*)q; q += sizeof(int) * W; newpos = (int*)q; q += sizeof(int) * W;
     gown = (int*)q; q += sizeof(int) * W; gchar = (int*)q; q += sizeof(int) * W;
     gnode = (int*)q; q += sizeof(int) * W;
-    q += sizeof(int) * W;        // (pad: the next member set starts 8-byte aligned for any W)
+    from = (int*)q; q += sizeof(int) * W;        // (an even number of int arrays: the next set starts 8-byte aligned)
     return q;
   }
   __host__ __device__ static size_t bytes(int W) { return (size_t)W * (6 * sizeof(double) + sizeof(LmFields) + 8 * sizeof(int)); }
 };
 
 struct BeamLds {
-  static size_t bytes(int W, int V, int CMAX, int WP2, int HS) {
+  static size_t bytes(int W, int V, int CMAX, int WP2, int HS, bool lm) {
     return sizeof(double) * ((size_t)CMAX + 2 * V + WP2 + kSelSmall) +
            sizeof(int) * ((size_t)WP2 + kSelSmall + 2 * (size_t)W * V + 2 * kSelBins + 64 + 4 * (size_t)HS) +
-           2 * Members::bytes(W) + 64;
+           2 * Members::bytes(W) + (lm ? 2 * sizeof(LmAnswer) * (size_t)W * V : 0) + 64;
   }
 };
 
@@ -514,6 +643,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   int* hist = (int*)q8; q8 += sizeof(int) * 2 * kSelBins;
   int* s_part = (int*)q8; q8 += sizeof(int) * 64;
   int* const sm0 = (int*)q8; q8 += sizeof(int) * 4 * p.HS;            // [set][key | val][HS]
+  LmAnswer* const lmc0 = (LmAnswer*)q8; if (LM) q8 += 2 * sizeof(LmAnswer) * (size_t)W * V;   // [set][member][V] the LM's answers
   auto slot_map = [&](int set) { SlotMap m; m.key = sm0 + set * 2 * p.HS; m.val = m.key + p.HS; m.mask = p.HS - 1; return m; };
   __shared__ int s_next_node, s_err, s_krem, s_done, s_bin, s_total_new;
   __shared__ unsigned s_hi, s_lo;
@@ -541,6 +671,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   }
   __syncthreads();
   if (tid == 0) slot_map(0).insert(0, 0);
+  if (LM) for (int c = tid; c < V; c += kThreads) if (c != blank && c != p.space_id) lmc0[c] = lm_query(p, M0.lm[0], -1, c);
   __syncthreads();
   int n = 1, cur = 0;
 #ifdef E2E_BEAM_PROFILE
@@ -556,6 +687,8 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     const SlotMap mapB = slot_map(cur ^ 1);          // ... among the members this step selects (filled in the rebuild)
     const int* const ctab = ctab0 + (size_t)cur * W * V;          // child tables of the current members: [member][V]
     int* const ctabB = ctab0 + (size_t)(cur ^ 1) * W * V;         // ... of the members this step selects
+    const LmAnswer* const lmcA = lmc0 + (size_t)cur * W * V;
+    LmAnswer* const lmcB = lmc0 + (size_t)(cur ^ 1) * W * V;
     double* const srow = srow2 + (t & 1) * V;
     // the next step's row is requested now and parked in LDS at the end of the step: no global round trip at a
     // step's start
@@ -593,7 +726,9 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         // else: alive but pruned (Q7) -- the probability is lost and the slot stays taken
       } else {
         LmFields nl;
-        child_lm<LM>(p, A.lm[ii], A.last[ii], ci, nl);
+        LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
+        if (LM) ans = lmcA[ii * V + ci];
+        child_score_fields<LM>(p, A.lm[ii], A.last[ii], ci, ans, nl);
         const double sc = beam_score<LM>(p, val, ninf(), nl);                       // after next_step: prev_pnb = val, prev_pb = -inf
         *slot = sc;
         key_hi = max(key_hi, (unsigned)(okey(sc) >> 32));
@@ -778,7 +913,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
       const int d = sel[j];
       if (d < n) {
         const int i = d;
-        A.kept[i] = 1; A.newpos[i] = j;
+        A.kept[i] = 1; A.newpos[i] = j; Bm.from[j] = i;
         Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i];
         Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; copy_lm<LM>(Bm.lm[j], A.lm[i]);
         Bm.gown[j] = A.gown[i]; Bm.gchar[j] = A.gchar[i]; Bm.gnode[j] = A.gnode[i];     // (owner: position in A, for now)
@@ -788,7 +923,9 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         const int c = q / n, i = q - c * n;
         const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : A.full[i]);
         LmFields nl;
-        child_lm<LM>(p, A.lm[i], A.last[i], c, nl);
+        LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
+        if (LM) ans = lmcA[i * V + c];
+        child_lm<LM>(p, A.lm[i], A.last[i], c, ans, nl);
         int k = atomicAdd(&s_next_node, 1);                                       // make_shared<Prefix>, :254
         if (k >= p.NCAP) { s_err = 1; k = 0; }
         else {
@@ -799,6 +936,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         }
         Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.node[j] = k; Bm.last[j] = c;
         Bm.gown[j] = i; Bm.gchar[j] = c; Bm.gnode[j] = k;                         // its own guard, if its parent stays
+        Bm.from[j] = -1;
         copy_lm<LM>(Bm.lm[j], nl);
       }
     }
@@ -818,6 +956,17 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         ctabB[o * V + gc] = gn;
       } else {
         Bm.gown[j] = -1;
+      }
+    }
+    if (LM) {
+      // the LM's answers for the new beam: carried over with a member that stays, asked for a member that is new --
+      // one (member, character) per thread, so the table walks of a step overlap instead of queueing up three deep
+      // behind every thread of the pair loop
+      for (int e = tid; e < nsel * V; e += kThreads) {
+        const int j = e / V, c = e - j * V;
+        if (c == blank || c == p.space_id) continue;
+        const int f = Bm.from[j];
+        lmcB[e] = f >= 0 ? lmcA[f * V + c] : lm_query(p, Bm.lm[j], Bm.last[j], c);
       }
     }
     lds_barrier();
@@ -858,14 +1007,14 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
 
 struct BeamLayout { size_t nodes, status, total, lds; int NCAP, CMAX, WP2, HS; };
 
-BeamLayout beam_layout(int B, int T, int V, int W) {
+BeamLayout beam_layout(int B, int T, int V, int W, bool lm = false) {
   BeamLayout l;
   l.CMAX = W * V + W + 8;
   // live nodes: the beam and its ancestors (at most one root path of length <= T per member); at most W are created per step
   l.NCAP = W * (T + 3) + 8;
   l.WP2 = 64; while (l.WP2 < W) l.WP2 <<= 1;
   l.HS = 256; while (l.HS < 4 * W) l.HS <<= 1;
-  l.lds = BeamLds::bytes(W, V, l.CMAX, l.WP2, l.HS);
+  l.lds = BeamLds::bytes(W, V, l.CMAX, l.WP2, l.HS, lm);
   size_t o = 0;
   l.nodes = o; o += align_up((size_t)B * l.NCAP * sizeof(BeamNode), 256);
   l.status = o; o += align_up((size_t)B * sizeof(int), 256);
@@ -892,7 +1041,7 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   if (blank < 0 || blank >= V) { set_error("blank=%d outside [0,%d)", blank, V); return E2E_ERR_ARG; }
   if (B > 0 && (!lp || !x_len || !out || !out_len)) { set_error("null pointer argument"); return E2E_ERR_ARG; }
   if (lm && !lm->d_ng) { set_error("the language model has no device tables (it was loaded without a GPU)"); return E2E_ERR_HIP; }
-  const BeamLayout l = beam_layout(B, T, V, beam_width);
+  const BeamLayout l = beam_layout(B, T, V, beam_width, lm != nullptr);
   if (l.CMAX > kMaxCand || l.lds > (size_t)kLdsBudget || beam_width > kSelBins) {
     set_error("beam_width*alphabet = %d candidates per step (%zu B of LDS) exceed what one workgroup holds (%d, %d B)",
               l.CMAX, l.lds, kMaxCand, kLdsBudget);
