@@ -222,7 +222,7 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
     if (!has_unk) { Entry e; e.n = 1; e.ids[0] = 0; e.prob = -100.f; e.bo = 0.f; entries.push_back(e); }
   }
   // n-gram table
-  lm->ng.assign(pow2_at_least(entries.size() * 2 + 16), NgSlot{{0, 0, 0, 0, 0, 0}, 0, 0.f, 0.f});
+  lm->ng.assign(pow2_at_least(entries.size() * 4 + 16), NgSlot{{0, 0, 0, 0, 0, 0}, 0, 0.f, 0.f});   // (load <= 1/4: most misses end at the first slot)
   const uint32_t ngmask = (uint32_t)lm->ng.size() - 1;
   for (const auto& e : entries) {
     uint32_t i = (uint32_t)ngram_hash(e.ids, e.n) & ngmask;
@@ -234,7 +234,7 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
   }
   // vocabulary table keyed by the hash of the (optionally lower-cased) spelling; when two words fold to the same
   // string the reference keeps whichever its unordered_map iteration visits last (unspecified) -- here: lowest id
-  lm->vkeys.assign(pow2_at_least(words.size() * 2 + 16), 0);
+  lm->vkeys.assign(pow2_at_least(words.size() * 4 + 16), 0);
   lm->vvals.assign(lm->vkeys.size(), 0);
   const uint32_t vmask = (uint32_t)lm->vkeys.size() - 1;
   for (uint32_t id = 0; id < words.size(); id++) {
@@ -320,7 +320,7 @@ extern "C" double e2e_lm_score(const e2e_lm* lm, const uint32_t* ctx, int ctx_le
 namespace e2e {
 namespace {
 
-constexpr int kThreads = 1024;
+constexpr int kThreadsNoLm = 1024, kThreadsLm = 1024;   // (with a language model: 512 threads measured 30 % slower)
 constexpr int kMaxCand = 8192;     // W*V + W candidates per step (LDS key array)
 constexpr int kLdsBudget = 158 * 1024;
 constexpr int kSelBits = 11, kSelBins = 1 << kSelBits;   // radix-select digit (two alternating histograms in LDS)
@@ -409,60 +409,70 @@ __device__ __forceinline__ unsigned long long okey(double d) {
 // in LDS while it stays (`lmc`): the pair loop and the rebuild then read them instead of walking the n-gram tables
 // (global memory, several dependent probes) for every pair of every step.
 struct LmAnswer { float sc; uint32_t wi; };
-__device__ __forceinline__ unsigned long long spell(const BeamParams& p, unsigned long long h, int c) {
-  for (int bi = p.lm.label_off[c]; bi < p.lm.label_off[c + 1]; bi++) {
-    unsigned char ch = p.lm.label_bytes[bi];
+// (LabelTab: the labels' spellings, staged in LDS by the kernel when they fit -- two dependent global loads less per query)
+struct LabelTab { const int* off; const unsigned char* bytes; };
+constexpr int kLabelLdsBytes = 512;
+__device__ __forceinline__ unsigned long long spell(const BeamParams& p, const LabelTab& lt, unsigned long long h, int c) {
+  for (int bi = lt.off[c]; bi < lt.off[c + 1]; bi++) {
+    unsigned char ch = lt.bytes[bi];
     if (p.lm.fold_case && ch >= 'A' && ch <= 'Z') ch += 32;
     h = fnv_step(h, ch);
   }
   return h;
 }
-// one n-gram of the signature table: the first probe's entry is already loaded
-__device__ __forceinline__ bool ngs_resolve(const LmView& lm, uint64_t h, NgSig e, float& prob, float& backoff) {
-  for (uint32_t i = (uint32_t)h & lm.ngmask;;) {
-    if (e.sig == h) { prob = e.prob; backoff = e.backoff; return true; }
-    if (e.sig == 0) return false;
-    i = (i + 1) & lm.ngmask;
-    e = lm.ngs[i];
-  }
-}
 // lm_base_score for contexts of up to kParCtx words with every table probe of the back-off chain in flight at once:
 // the (k+1)-grams (ctx[k-1..0], word) and the context k-grams whose back-off weights the chain may need are hashed
-// first, their entries requested together, and only then combined in the chain's order (same float additions).
-constexpr int kParCtx = 3;
+// first and then probed in ROUNDS -- every lookup that is still open requests its next slot before any answer is
+// consumed -- so a query costs as many memory round trips as its longest probe sequence, not the sum over the chain
+// (which, with 64 lanes waiting for the slowest at every one of up to 2n+1 lookups, was ~20 round trips).  The
+// answers are combined in the chain's order (same float additions).
+constexpr int kParCtx = 2;
 __device__ __forceinline__ float lm_score_parallel(const LmView& lm, const uint32_t (&ctx)[kCtx], int n, uint32_t word) {
-  uint64_t hf[kParCtx + 1], hb[kParCtx + 1];
-  NgSig ef[kParCtx + 1], eb[kParCtx + 1];
+  constexpr int NL = 2 * kParCtx + 1;             // lookups: full[0..kParCtx], then bo[1..kParCtx]
+  uint64_t h[NL];
+  uint32_t idx[NL];
+  NgSig e[NL];
+  unsigned open = 0, hit = 0;                     // bit per lookup: still probing / found
 #pragma unroll
   for (int k = 0; k <= kParCtx; k++) {
-    uint64_t h = kFnvInit;
+    uint64_t hp = kFnvInit;
 #pragma unroll
-    for (int i = 0; i < k; i++) h = ng_mix(h, ctx[k - 1 - i]);
-    hb[k] = ng_finish(h, k);
-    hf[k] = ng_finish(ng_mix(h, word), k + 1);
+    for (int i = 0; i < k; i++) hp = ng_mix(hp, ctx[k - 1 - i]);
+    h[k] = ng_finish(ng_mix(hp, word), k + 1);
+    if (k <= n) open |= 1u << k;
+    if (k >= 1) { h[kParCtx + k] = ng_finish(hp, k); if (k <= n) open |= 1u << (kParCtx + k); }
   }
 #pragma unroll
-  for (int k = 0; k <= kParCtx; k++) {
-    if (k <= n) ef[k] = lm.ngs[(uint32_t)hf[k] & lm.ngmask];
-    if (k >= 1 && k <= n) eb[k] = lm.ngs[(uint32_t)hb[k] & lm.ngmask];
+  for (int l = 0; l < NL; l++) {
+    idx[l] = (uint32_t)h[l] & lm.ngmask;
+    if (open >> l & 1u) e[l] = lm.ngs[idx[l]];
+  }
+  while (open) {
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      if (open >> l & 1u) {
+        if (e[l].sig == h[l]) { hit |= 1u << l; open &= ~(1u << l); }
+        else if (e[l].sig == 0) open &= ~(1u << l);
+        else { idx[l] = (idx[l] + 1) & lm.ngmask; e[l] = lm.ngs[idx[l]]; }
+      }
+    }
   }
   float acc = 0.f, result = 0.f;
   bool found = false;
 #pragma unroll
   for (int k = kParCtx; k >= 0; k--) {
     if (k <= n && !found) {
-      float pr = 0.f, bo = 0.f;
-      if (ngs_resolve(lm, hf[k], ef[k], pr, bo)) { result = acc + pr; found = true; }
-      else if (k > 0 && ngs_resolve(lm, hb[k], eb[k], pr, bo)) acc += bo;
+      if (hit >> k & 1u) { result = acc + e[k].prob; found = true; }
+      else if (k > 0 && (hit >> (kParCtx + k) & 1u)) acc += e[kParCtx + k].backoff;
     }
   }
   if (!found) result = acc + lm.unk_prob;
   return result;
 }
-__device__ __forceinline__ LmAnswer lm_query(const BeamParams& p, const LmFields& pr, int parent_last, int c) {
+__device__ __forceinline__ LmAnswer lm_query(const BeamParams& p, const LabelTab& lt, const LmFields& pr, int parent_last, int c) {
   const bool new_word = pr.num_words == 0 || parent_last == p.space_id;                           // :258-259 (c != space)
   LmAnswer a;
-  uint64_t h = spell(p, new_word ? kFnvInit : pr.word_hash, c);
+  uint64_t h = spell(p, lt, new_word ? kFnvInit : pr.word_hash, c);
   uint32_t ctx[kCtx];
   int cn = new_word ? pr.st_n : pr.stb_n;
 #pragma unroll
@@ -480,7 +490,9 @@ __device__ __forceinline__ LmAnswer lm_query(const BeamParams& p, const LmFields
   } else {
     a.wi = lm_word_lookup(p.lm, h);
   }
-  a.sc = lm_base_score(p.lm, ctx, cn, a.wi, nullptr, nullptr);
+  // (the general walk indexes the context dynamically: give it the prefix's own arrays, so that the local copy above is
+  // only ever indexed statically and stays in registers instead of scratch memory)
+  a.sc = lm_base_score(p.lm, new_word ? pr.st : pr.stb, cn, a.wi, nullptr, nullptr);
   return a;
 }
 
@@ -489,7 +501,7 @@ __device__ __forceinline__ LmAnswer lm_query(const BeamParams& p, const LmFields
 // insertion penalty needs it -- and none of the LM state, which otherwise costs the pair loop a third of its
 // instructions and the kernel its scratch memory)
 template <bool LM>
-__device__ __forceinline__ void child_lm(const BeamParams& p, const LmFields& pr, int parent_last, int c, LmAnswer ans, LmFields& nn) {
+__device__ __forceinline__ void child_lm(const BeamParams& p, const LabelTab& lt, const LmFields& pr, int parent_last, int c, LmAnswer ans, LmFields& nn) {
   const bool new_word = c != p.space_id && (pr.num_words == 0 || parent_last == p.space_id);     // :258-259
   nn.num_words = pr.num_words + (new_word ? 1 : 0);
   nn.lm_score = 0.0; nn.num_oov = 0;
@@ -498,7 +510,7 @@ __device__ __forceinline__ void child_lm(const BeamParams& p, const LmFields& pr
   nn.word_len = 0; nn.word_hash = kFnvInit; nn.st_n = 0; nn.stb_n = 0;
   const double kLogE10 = 2.302585092994045684;
   if (c != p.space_id) {
-    nn.word_hash = spell(p, new_word ? kFnvInit : pr.word_hash, c);
+    nn.word_hash = spell(p, lt, new_word ? kFnvInit : pr.word_hash, c);
     nn.word_len = (new_word ? 0 : pr.word_len) + 1;
     if (new_word) {                                                       // :265-281
       for (int s = 0; s < pr.st_n; s++) nn.stb[s] = pr.st[s];
@@ -586,7 +598,7 @@ struct BeamLds {
   static size_t bytes(int W, int V, int CMAX, int WP2, int HS, bool lm) {
     return sizeof(double) * ((size_t)CMAX + 2 * V + WP2 + kSelSmall) +
            sizeof(int) * ((size_t)WP2 + kSelSmall + 2 * (size_t)W * V + 2 * kSelBins + 64 + 4 * (size_t)HS) +
-           2 * Members::bytes(W) + (lm ? 2 * sizeof(LmAnswer) * (size_t)W * V : 0) + 64;
+           2 * Members::bytes(W) + (lm ? 2 * sizeof(LmAnswer) * (size_t)W * V + sizeof(int) * (size_t)(V + 2) + kLabelLdsBytes : 0) + 64;
   }
 };
 
@@ -621,8 +633,10 @@ namespace e2e { namespace {
 #define BPROF(slot) do {} while (0)
 #endif
 
-template <typename IO, bool LM>
-__global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
+// NT threads per workgroup
+template <typename IO, bool LM, int NT>
+__global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
+  constexpr int kThreads = NT;
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V, W = p.W, blank = p.blank;
@@ -644,6 +658,9 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   int* s_part = (int*)q8; q8 += sizeof(int) * 64;
   int* const sm0 = (int*)q8; q8 += sizeof(int) * 4 * p.HS;            // [set][key | val][HS]
   LmAnswer* const lmc0 = (LmAnswer*)q8; if (LM) q8 += 2 * sizeof(LmAnswer) * (size_t)W * V;   // [set][member][V] the LM's answers
+  int* const lab_off = (int*)q8; if (LM) q8 += sizeof(int) * (size_t)(V + 2);
+  unsigned char* const lab_bytes = q8; if (LM) q8 += kLabelLdsBytes;
+  LabelTab lt; lt.off = p.lm.label_off; lt.bytes = p.lm.label_bytes;
   auto slot_map = [&](int set) { SlotMap m; m.key = sm0 + set * 2 * p.HS; m.val = m.key + p.HS; m.mask = p.HS - 1; return m; };
   __shared__ int s_next_node, s_err, s_krem, s_done, s_bin, s_total_new;
   __shared__ unsigned s_hi, s_lo;
@@ -658,6 +675,14 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   for (int c = tid; c < V; c += kThreads) ctab0[c] = -1;                             // set 0, member 0 = the root
   for (int h = tid; h < p.HS; h += kThreads) { sm0[h] = -1; sm0[2 * p.HS + h] = -1; }
   if (T > 0) for (int c = tid; c < V; c += kThreads) srow2[c] = (double)lp[(int64_t)c * p.sV];
+  if (LM) {
+    const int nbytes = p.lm.label_off[V];
+    if (nbytes <= kLabelLdsBytes) {                       // (uniform) the spellings fit: read them from LDS from now on
+      for (int c = tid; c <= V; c += kThreads) lab_off[c] = p.lm.label_off[c];
+      for (int i = tid; i < nbytes; i += kThreads) lab_bytes[i] = p.lm.label_bytes[i];
+      lt.off = lab_off; lt.bytes = lab_bytes;
+    }
+  }
   if (tid == 0) {
     s_next_node = 1; s_err = 0;                                                     // node 0 is taken
     BeamNode& r = nodes[0];
@@ -671,7 +696,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
   }
   __syncthreads();
   if (tid == 0) slot_map(0).insert(0, 0);
-  if (LM) for (int c = tid; c < V; c += kThreads) if (c != blank && c != p.space_id) lmc0[c] = lm_query(p, M0.lm[0], -1, c);
+  if (LM) for (int c = tid; c < V; c += kThreads) if (c != blank && c != p.space_id) lmc0[c] = lm_query(p, lt, M0.lm[0], -1, c);
   __syncthreads();
   int n = 1, cur = 0;
 #ifdef E2E_BEAM_PROFILE
@@ -790,9 +815,6 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         const unsigned long long dmask = (1ULL << width) - 1ULL;
         for (int d = tid; d < ntot; d += kThreads) {
           const unsigned long long u = okey(key[d]);
-#ifdef E2E_BEAM_PROFILE
-          if (b == 0 && pass == 0 && u != kNoCandKey && (unsigned)(u >> 32) >= L32) atomicAdd((unsigned long long*)&g_beam_prof[11], 1ULL);
-#endif
           if ((u & mask) == prefix && u != kNoCandKey) atomicAdd(&hcur[(int)((u >> shift) & dmask)], 1);
         }
         lds_barrier();
@@ -925,7 +947,7 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
         LmFields nl;
         LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
         if (LM) ans = lmcA[i * V + c];
-        child_lm<LM>(p, A.lm[i], A.last[i], c, ans, nl);
+        child_lm<LM>(p, lt, A.lm[i], A.last[i], c, ans, nl);
         int k = atomicAdd(&s_next_node, 1);                                       // make_shared<Prefix>, :254
         if (k >= p.NCAP) { s_err = 1; k = 0; }
         else {
@@ -961,12 +983,15 @@ __global__ __launch_bounds__(kThreads) void ctc_beam_kernel(BeamParams p) {
     if (LM) {
       // the LM's answers for the new beam: carried over with a member that stays, asked for a member that is new --
       // one (member, character) per thread, so the table walks of a step overlap instead of queueing up three deep
-      // behind every thread of the pair loop
+      // behind every thread of the pair loop.  (Most new members share their LM state -- the word begun, the context --
+      // with another member: 70 new per step, 22 distinct states measured.  Asking only once per state was tried; the
+      // search for the shared state cost what the saved queries gained, because every wave walks the query code
+      // anyway as long as one of its lanes has a query.)
       for (int e = tid; e < nsel * V; e += kThreads) {
-        const int j = e / V, c = e - j * V;
+        const int j2 = e / V, c = e - j2 * V;
         if (c == blank || c == p.space_id) continue;
-        const int f = Bm.from[j];
-        lmcB[e] = f >= 0 ? lmcA[f * V + c] : lm_query(p, Bm.lm[j], Bm.last[j], c);
+        const int f = Bm.from[j2];
+        lmcB[e] = f >= 0 ? lmcA[f * V + c] : lm_query(p, lt, Bm.lm[j2], Bm.last[j2], c);
       }
     }
     lds_barrier();
@@ -1064,11 +1089,12 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   p.status = reinterpret_cast<int*>(ws + l.status);
   p.NCAP = l.NCAP; p.CMAX = l.CMAX; p.WP2 = l.WP2; p.HS = l.HS;
   hipStream_t s = (hipStream_t)stream;
-  const void* fn = dtype == E2E_F32 ? (lm ? (const void*)&ctc_beam_kernel<float, true> : (const void*)&ctc_beam_kernel<float, false>)
-                                    : (lm ? (const void*)&ctc_beam_kernel<double, true> : (const void*)&ctc_beam_kernel<double, false>);
+  const void* fn = dtype == E2E_F32 ? (lm ? (const void*)&ctc_beam_kernel<float, true, kThreadsLm> : (const void*)&ctc_beam_kernel<float, false, kThreadsNoLm>)
+                                    : (lm ? (const void*)&ctc_beam_kernel<double, true, kThreadsLm> : (const void*)&ctc_beam_kernel<double, false, kThreadsNoLm>);
+  const int nthreads = lm ? kThreadsLm : kThreadsNoLm;
   E2E_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds), "hipFuncSetAttribute");
   void* args[] = { &p };
-  E2E_HIP_CHECK(hipLaunchKernel(fn, dim3(B), dim3(kThreads), args, l.lds, s), "ctc_beam_kernel launch");
+  E2E_HIP_CHECK(hipLaunchKernel(fn, dim3(B), dim3(nthreads), args, l.lds, s), "ctc_beam_kernel launch");
   E2E_HIP_CHECK(hipGetLastError(), "ctc_beam_kernel launch");
   return E2E_OK;
 }
