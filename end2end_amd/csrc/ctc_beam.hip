@@ -944,10 +944,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         const int q = d - n;
         const int c = q / n, i = q - c * n;
         const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : A.full[i]);
-        LmFields nl;
         LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
         if (LM) ans = lmcA[i * V + c];
-        child_lm<LM>(p, lt, A.lm[i], A.last[i], c, ans, nl);
+        child_lm<LM>(p, lt, A.lm[i], A.last[i], c, ans, Bm.lm[j]);                 // (straight into LDS: a local LmFields lives in scratch)
         int k = atomicAdd(&s_next_node, 1);                                       // make_shared<Prefix>, :254
         if (k >= p.NCAP) { s_err = 1; k = 0; }
         else {
@@ -959,7 +958,6 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.node[j] = k; Bm.last[j] = c;
         Bm.gown[j] = i; Bm.gchar[j] = c; Bm.gnode[j] = k;                         // its own guard, if its parent stays
         Bm.from[j] = -1;
-        copy_lm<LM>(Bm.lm[j], nl);
       }
     }
     lds_barrier();
