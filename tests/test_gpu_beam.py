@@ -135,3 +135,84 @@ def test_full_c4_shape_properties():
         gseq = gi[b, : gl[b]]
         nll_greedy, _ = O.ctc_loss(lp[b:b + 1, :n].double().numpy(), gseq[None, :], [n], [len(gseq)], 0)
         assert nll_beam[0] <= nll_greedy[0] + 1e-6
+
+
+def _write_arpa(path, letters, n_words, order, seed):
+    """A seeded synthetic ARPA of the given order over short words of `letters` (the reference's LibriSpeech model is not
+    available offline): enough entries that table probes collide, enough gaps that the back-off chain is walked."""
+    import random
+    rng = random.Random(seed)
+    words = set()
+    while len(words) < n_words:
+        words.add("".join(rng.choice(letters) for _ in range(rng.randint(1, 4))))
+    words = sorted(words)
+    grams = {1: [(w,) for w in words]}
+    for n in range(2, order + 1):
+        prev = grams[n - 1] if n > 2 else [(w,) for w in words] + [("<s>",)]
+        grams[n] = sorted({rng.choice(prev) + (rng.choice(words),) for _ in range(2 * n_words)})
+    with open(path, "w") as f:
+        f.write("\\data\\\n")
+        for n in range(1, order + 1):
+            f.write("ngram %d=%d\n" % (n, len(grams[n]) + (3 if n == 1 else 0)))
+        f.write("\n\\1-grams:\n-2.0\t<unk>\n-99\t<s>\t-0.3\n-1.5\t</s>\n")
+        for n in range(1, order + 1):
+            if n > 1:
+                f.write("\n\\%d-grams:\n" % n)
+            for g in grams[n]:
+                bo = "" if n == order else "\t%.4f" % -rng.uniform(0.05, 0.6)
+                f.write("%.4f\t%s%s\n" % (-rng.uniform(0.2, 4.0), " ".join(g), bo))
+        f.write("\n\\end\\\n")
+
+
+@pytest.mark.parametrize("order,W", [(3, 40), (4, 25), (2, 100)])
+def test_speech_alphabet_lm_beam_matches_oracle(tmp_path, order, W):
+    # 29 labels, a few hundred words: most spelled prefixes are out of vocabulary, n-grams are mostly missing (the
+    # back-off chain is walked to the unigram), the tables hold enough entries for probe sequences to collide, and the
+    # per-member answers are carried over many steps.  Order 4 takes the general device walk for contexts of 3 words.
+    labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
+    path = str(tmp_path / ("synthetic_%dgram.arpa" % order))
+    _write_arpa(path, "abcde", 150, order, seed=order)
+    lm = LanguageModel(path, labels, True)
+    olm = O.OracleLM(path)
+    g = torch.Generator().manual_seed(40 + order)
+    x = torch.randn(3, 60, 29, generator=g, dtype=torch.float64) * 2.0
+    x[:, :, [1, 2, 3, 4, 5, 27]] += 3.0                    # the model's letters and the space are likely
+    lp = torch.log_softmax(x, -1)
+    same_as_oracle(lp, [60, 47, 23], 0, W, labels, lm, olm, lmwt=1.3, wip=0.7, oov_penalty=-4.0, case_sensitive=True)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_sweep_matches_oracle(seed):
+    """A fixed-seed slice of tools/diag/fuzz_beam.py: random shapes, beam widths, blank / space positions, penalties,
+    tie-heavy and -inf-holed emissions, ragged lengths, f32 / f64 input, with and without the tiny 3-gram LM."""
+    rng = np.random.default_rng(seed)
+    for case in range(25):
+        with_lm = bool(rng.integers(0, 3) == 0)
+        B = int(rng.integers(1, 4)); T = int(rng.integers(1, 50))
+        if with_lm:
+            labels = ["_", "a", "b", " "]; V = 4; blank = 0
+            cs = bool(rng.integers(0, 2))
+            lm = LanguageModel(ARPA, labels, cs); olm = O.OracleLM(ARPA)
+            kw = dict(lmwt=float(rng.choice([0.5, 1.0, 2.0])), wip=float(rng.choice([0.0, 1.0])),
+                      oov_penalty=float(rng.choice([-1000.0, -3.0])), case_sensitive=cs)
+        else:
+            V = int(rng.integers(2, 14)); blank = int(rng.choice([0, V - 1, rng.integers(0, V)]))
+            labels = list("abcdefghijklm")[:V]
+            labels[blank] = "_"
+            if V > 2 and rng.integers(0, 2):
+                labels[int(rng.choice([i for i in range(V) if i != blank]))] = " "
+            lm = olm = None
+            kw = dict(wip=float(rng.choice([0.0, 1.0, 2.5])))
+        W = int(rng.choice([1, 2, 3, 5, 16, 40, 64, 65, 100, 128, 200]))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(B, T, V, generator=g, dtype=torch.float64) * float(rng.choice([0.3, 1.0, 3.0]))
+        style = int(rng.integers(0, 3))
+        if style == 1:
+            x = x.round()                                   # many exact ties
+        lp = torch.log_softmax(x, -1)
+        if style == 2 and V > 2:
+            lp[:, ::3, int(rng.integers(0, V))] = float("-inf")
+        xl = rng.integers(1, T + 1, size=B).tolist(); xl[0] = T
+        if rng.integers(0, 2):
+            lp = lp.float()
+        same_as_oracle(lp, xl, blank, W, labels, lm, olm, **kw)
