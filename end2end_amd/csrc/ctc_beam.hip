@@ -662,7 +662,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
   unsigned char* const lab_bytes = q8; if (LM) q8 += kLabelLdsBytes;
   LabelTab lt; lt.off = p.lm.label_off; lt.bytes = p.lm.label_bytes;
   auto slot_map = [&](int set) { SlotMap m; m.key = sm0 + set * 2 * p.HS; m.val = m.key + p.HS; m.mask = p.HS - 1; return m; };
-  __shared__ int s_next_node, s_err, s_krem, s_done, s_bin, s_total_new;
+  __shared__ int s_next_node, s_err, s_krem, s_done, s_bin, s_total_new, s_nnew;
   __shared__ unsigned s_hi, s_lo;
   __shared__ unsigned long long s_prefix;
 
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     for (int h = tid; h < p.HS; h += kThreads) mapB.key[h] = -1;
     for (int e = tid; e < W * V; e += kThreads) ctabB[e] = -1;
     for (int h = tid; h < 2 * kSelBins; h += kThreads) hist[h] = 0;        // (the second half held the previous step's sel)
-    if (tid == 0) { s_hi = 0u; s_lo = 0xffffffffu; s_total_new = 0; }
+    if (tid == 0) { s_hi = 0u; s_lo = 0xffffffffu; s_total_new = 0; s_nnew = 0; }
     lds_barrier();
     // pairs in the reference's order: character outer, prefix inner (:370-395): q = c*n + i
     const int npairs = n * V;
@@ -931,6 +931,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     }
     BPROF(3);
     // ---- rebuild the beam in the other member set ----
+    int* const newlist = sidx;                      // (the gathered candidates are dead once sel[] is written) positions of the new members
     for (int j = tid; j < nsel; j += kThreads) {
       const int d = sel[j];
       if (d < n) {
@@ -958,6 +959,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.node[j] = k; Bm.last[j] = c;
         Bm.gown[j] = i; Bm.gchar[j] = c; Bm.gnode[j] = k;                         // its own guard, if its parent stays
         Bm.from[j] = -1;
+        if (LM) newlist[atomicAdd(&s_nnew, 1)] = j;
       }
     }
     lds_barrier();
@@ -985,11 +987,19 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       // with another member: 70 new per step, 22 distinct states measured.  Asking only once per state was tried; the
       // search for the shared state cost what the saved queries gained, because every wave walks the query code
       // anyway as long as one of its lanes has a query.)
+      // Copies and queries are separate loops, and the queries run over the packed list of new members: a wave walks
+      // the whole query code as soon as one of its lanes has a query, so what counts is the number of rounds in which
+      // waves do -- ceil(new * V / 1024) instead of ceil(W * V / 1024).
       for (int e = tid; e < nsel * V; e += kThreads) {
-        const int j2 = e / V, c = e - j2 * V;
-        if (c == blank || c == p.space_id) continue;
+        const int j2 = e / V;
         const int f = Bm.from[j2];
-        lmcB[e] = f >= 0 ? lmcA[f * V + c] : lm_query(p, lt, Bm.lm[j2], Bm.last[j2], c);
+        if (f >= 0) lmcB[e] = lmcA[f * V + (e - j2 * V)];
+      }
+      const int nnew = s_nnew;
+      for (int t2 = tid; t2 < nnew * V; t2 += kThreads) {
+        const int r = t2 / V, c = t2 - r * V, j2 = newlist[r];
+        if (c == blank || c == p.space_id) continue;
+        lmcB[j2 * V + c] = lm_query(p, lt, Bm.lm[j2], Bm.last[j2], c);
       }
     }
     lds_barrier();
