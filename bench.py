@@ -230,8 +230,8 @@ def wide_alphabet_numbers(dev):
             "frames_per_s": B * T / (ms * 1e-3), "algorithmic_bytes": algo,
             "roofline": {"bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "note": "logits are read twice (row log-sum-exp, dense gradient) and the gradient written once: 3/2 of the "
-                    "algorithmic bytes, so 2/3 of the roofline is the ceiling of this structure"}
+            "note": "logits read once, gradient written once (the row stays in a wave's registers between the softmax's "
+                    "passes), then the <= S+1 label columns of each frame are corrected in place after the lattice"}
 
 
 def recorded_traffic(workload):

@@ -1,14 +1,16 @@
 // Wide alphabets (V > 64, e.g. the V=8000 word-piece / OCR shape): the lattice only ever touches the utterance's
 // own labels, so the alphabet is COMPACTED per utterance to its distinct labels + the blank (<= Smax+1 columns) and
 // the small-alphabet lattice kernels (ctc_loss_fast.hip, with the exact kernel as their fallback) run unchanged on
-// the compact log-probabilities.  Around them two streaming kernels carry all of the HBM traffic:
-//   wide_rows_kernel   one wave per frame: online max / sum-exp over the V logits (read once, 16 B per lane), writes
-//                      the row's log-sum-exp and the <= Smax+1 compact log-probs
-//   wide_emit_kernel   one wave per frame: grad[v] = exp(x[v] - lse) for all v (logits read a second time, gradient
-//                      written once), then the <= Smax+1 label columns are overwritten with (prob - posterior) from the
-//                      compact gradient
-// Bytes: 3*V*4 per frame against the algorithmic 2*V*4 (the logits cannot stay on chip between the two passes:
-// 4.2 GB per GPU at B=512, T=256, V=8000), i.e. at best 2/3 of the HBM roofline.
+// the compact log-probabilities.  Around them the streaming kernels carry all of the HBM traffic:
+//   wide_rows_dense_kernel  (rows of <= 8192 aligned columns) one wave per frame holds the WHOLE row in registers
+//                      (<= 32 float4 per lane): maximum, exp, sum, then grad[v] = softmax(x)[v] is written straight from
+//                      the registers -- the logits are read once and the gradient written once, 2*V*4 bytes per frame,
+//                      the algorithmic minimum -- plus the row's log-sum-exp and the <= Smax+1 compact log-probs
+//   wide_fix_kernel    after the lattice: the <= Smax+1 label columns of every live frame are overwritten with
+//                      (prob - posterior) from the compact gradient (scattered 4-byte writes, ~3 % extra traffic);
+//                      utterances that turned out infeasible get their slab poisoned (quirk Q2)
+//   wide_rows_kernel + wide_emit_kernel  (any stride / width): the two-pass form, logits read twice (3*V*4 bytes per
+//                      frame): online max / sum-exp first, the dense gradient with the label columns afterwards
 // Reference semantics: src/losses/ctc_loss.cpp:102-117 (gradient over the full (T,V) slab, quirks Q1/Q2).
 #include "common.h"
 
@@ -255,6 +257,129 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
   }
 }
 
+// ---- single-read form: the row stays in registers between the softmax's two passes ----
+typedef float vf4 __attribute__((ext_vector_type(4)));
+template <int NV4>          // float4 per lane: rows of up to 256*NV4 columns
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2)))      // (<= 256 VGPRs: two rows per SIMD in flight)
+void wide_rows_dense_kernel(WideParams p) {
+  // (the wave's row is made visibly uniform: the row pointers then live in scalar registers and every load / store is
+  // `scalar base + lane offset + immediate` -- with per-lane 64-bit addresses the 2*NV4 of them cost more VGPRs than the row)
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = (int64_t)blockIdx.x * kWaves + w;
+  if (row >= (int64_t)p.B * p.T) return;
+  const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
+  const float* xr = p.x + (int64_t)b * p.sB + (int64_t)t * p.sT;
+  vf4* g4 = reinterpret_cast<vf4*>(p.grads + (size_t)row * p.V);
+  const vf4* x4 = reinterpret_cast<const vf4*>(xr);
+  const int n4 = p.V >> 2;
+  const bool bad_len = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
+  const bool live = !bad_len && t < Tq;
+  if (bad_len || (!live && !p.logprobs)) {         // invalid lengths: NaN; padded frame of fused logits: 0 (else exp(lp), Q1)
+    const float f = bad_len ? __builtin_nanf("") : 0.f;
+    const vf4 o = {f, f, f, f};
+    for (int i = lane; i < n4; i += 64) __builtin_nontemporal_store(o, &g4[i]);
+    return;
+  }
+  const float ninf = -__builtin_huge_valf();
+  // Groups of 64 float4: all but at most one are complete (unconditional accesses at `scalar base + lane + immediate`);
+  // in the one partial group the lanes past the row re-read -- and later re-write, with the same value -- the row's last
+  // float4 and are left out of the sum; groups past the row (a narrower alphabet than the instantiation holds) are
+  // skipped by uniform branches.
+  vf4 v[NV4];
+  const int last = n4 - 1;
+  const int part_idx = min(lane + (n4 & ~63), last);      // this lane's float4 in the partial group
+  const bool part_in = lane + (n4 & ~63) <= last;
+#pragma unroll
+  for (int u = 0; u < NV4; u++) {
+    const vf4 none = {ninf, ninf, ninf, ninf};
+    if (64 * u + 64 <= n4) v[u] = __builtin_nontemporal_load(&x4[64 * u + lane]);
+    else if (64 * u < n4) v[u] = __builtin_nontemporal_load(&x4[part_idx]);
+    else v[u] = none;
+  }
+  float lse = 0.f;
+  if (!p.logprobs) {
+    float m = ninf;
+#pragma unroll
+    for (int u = 0; u < NV4; u++) m = fmaxf(m, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+    const float M = wave_max_f(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV4; u++) {
+      if (64 * u < n4) {
+        v[u].x = exp_acc(v[u].x - M); v[u].y = exp_acc(v[u].y - M); v[u].z = exp_acc(v[u].z - M); v[u].w = exp_acc(v[u].w - M);
+        const float part = (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        sum += (64 * u + 64 <= n4 || part_in) ? part : 0.f;
+      }
+      if (u & 1) __builtin_amdgcn_sched_barrier(0);       // (8 exps in flight are enough; interleaving all of them costs registers)
+    }
+    sum = wave_sum_f(sum);
+    const float inv = 1.f / sum;
+    lse = M + logf(sum);
+#pragma unroll
+    for (int u = 0; u < NV4; u++) {
+      if (64 * u + 64 <= n4) __builtin_nontemporal_store(v[u] * inv, &g4[64 * u + lane]);
+      else if (64 * u < n4) __builtin_nontemporal_store(v[u] * inv, &g4[part_idx]);
+      if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane == 0) p.lse[row] = lse;
+  } else {
+#pragma unroll
+    for (int u = 0; u < NV4; u++) {
+      if (64 * u < n4) {
+        const vf4 o = {exp_acc(v[u].x), exp_acc(v[u].y), exp_acc(v[u].z), exp_acc(v[u].w)};
+        if (64 * u + 64 <= n4) __builtin_nontemporal_store(o, &g4[64 * u + lane]);
+        else __builtin_nontemporal_store(o, &g4[part_idx]);
+      }
+      if (u & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!live) return;
+  // compact row, shifted so that its largest entry is 0 (see wide_rows_kernel)
+  float* xc = p.xc + (size_t)row * p.VC;
+  const int* cl = p.clabel + (size_t)b * p.VC;
+  float cm = ninf;
+  for (int k = lane; k < p.VC; k += 64) {
+    const int l = cl[k];
+    const float val = l >= 0 ? xr[l] - lse : ninf;
+    xc[k] = val;
+    cm = fmaxf(cm, val);
+  }
+  cm = wave_max_f(cm);
+  if (!(cm > ninf)) cm = 0.f;
+  for (int k = lane; k < p.VC; k += 64) xc[k] -= cm;
+  if (lane == 0) p.shift[row] = cm;
+}
+
+// after the lattice: the label columns of the live frames; the slab of an utterance that turned out infeasible
+__global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * kWaves + w;
+  if (row >= (int64_t)p.B * p.T) return;
+  const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
+  if (Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax) return;         // (poisoned by wide_rows_dense_kernel already)
+  float* gr = p.grads + (size_t)row * p.V;
+  if (!(p.losses[b] < __builtin_huge_valf())) {                      // infeasible (Q2) / NaN: the whole slab
+    const float f = __builtin_nanf("");
+    const vf4 o = {f, f, f, f};
+    vf4* g4 = reinterpret_cast<vf4*>(gr);
+    for (int i = lane; i < (p.V >> 2); i += 64) __builtin_nontemporal_store(o, &g4[i]);
+    return;
+  }
+  if (t >= Tq) return;
+  // prob - posterior, the posterior in the shifted compact space: exp(xc) - gc.  The probability is what the dense
+  // kernel left in the column (the line has to come in for the 4-byte write anyway); the compact log-prob is read from
+  // the workspace row instead of gathering the logits a second time.
+  const float* gc = p.gc + (size_t)row * p.VC;
+  const float* xc = p.xc + (size_t)row * p.VC;
+  const int* cl = p.clabel + (size_t)b * p.VC;
+  for (int k = lane; k < p.VC; k += 64) {
+    const int l = cl[k];
+    if (l >= 0) gr[l] -= exp_acc(xc[k]) - gc[k];
+  }
+}
+
 struct WideLayout { size_t targets_c, clabel, lse, shift, xc, gc, inner, total; int VC; };
 
 WideLayout wide_layout(int B, int T, int V, int Smax, bool with_exact) {
@@ -305,9 +430,14 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
   const dim3 grid_rows((unsigned)((rows + kWaves - 1) / kWaves));
   hipLaunchKernelGGL(wide_compact_kernel, dim3(a.B), dim3(256), sizeof(int) * 3 * (a.Smax > 0 ? a.Smax : 1), a.stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "wide_compact_kernel launch");
-  if (vec4) hipLaunchKernelGGL(wide_rows_kernel<true>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
+  const bool dense = vec4 && a.V <= 8192;          // the row fits a wave's registers: logits read once
+  if (dense) {
+    if (a.V <= 2048) hipLaunchKernelGGL(wide_rows_dense_kernel<8>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
+    else if (a.V <= 4096) hipLaunchKernelGGL(wide_rows_dense_kernel<16>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
+    else hipLaunchKernelGGL(wide_rows_dense_kernel<32>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
+  } else if (vec4) hipLaunchKernelGGL(wide_rows_kernel<true>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
   else hipLaunchKernelGGL(wide_rows_kernel<false>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
-  E2E_HIP_CHECK(hipGetLastError(), "wide_rows_kernel launch");
+  E2E_HIP_CHECK(hipGetLastError(), "wide rows kernel launch");
   // the lattice on the compact alphabet: log-probabilities in, (prob - posterior) out
   LossArgs c = a;
   c.x = p.xc; c.dtype = E2E_F32; c.logprobs = 1;
@@ -320,9 +450,10 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
   if (rc != E2E_OK) return rc;
   hipLaunchKernelGGL(wide_loss_fix_kernel, dim3(a.B), dim3(64), 0, a.stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "wide_loss_fix_kernel launch");
-  if (vec4) hipLaunchKernelGGL(wide_emit_kernel<true>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
+  if (dense) hipLaunchKernelGGL(wide_fix_kernel, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
+  else if (vec4) hipLaunchKernelGGL(wide_emit_kernel<true>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
   else hipLaunchKernelGGL(wide_emit_kernel<false>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
-  E2E_HIP_CHECK(hipGetLastError(), "wide_emit_kernel launch");
+  E2E_HIP_CHECK(hipGetLastError(), "wide emit kernel launch");
   return E2E_OK;
 }
 
