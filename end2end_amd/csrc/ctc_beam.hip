@@ -556,6 +556,12 @@ __device__ __forceinline__ void child_score_fields(const BeamParams& p, const Lm
 
 // get_prev_full_prob_with_lmwt, :314-318, from the already "next_step"-ed probabilities
 template <bool LM>
+__device__ __forceinline__ double beam_score_full(const BeamParams& p, double full, const LmFields& lm) {
+  const double lm_score = LM ? lm.lm_score : 0.0;
+  const int num_oov = LM ? lm.num_oov : 0;
+  return full + lm_score * p.lmwt - lm.num_words * p.wip + num_oov * p.oov;
+}
+template <bool LM>
 __device__ __forceinline__ double beam_score(const BeamParams& p, double ppnb, double ppb, const LmFields& lm) {
   // (without a language model lm_score and num_oov are zero for every prefix; the expression keeps its shape so that
   // the result has the reference's bits for any lmwt / oov the caller passes)
@@ -573,7 +579,8 @@ struct Members {
   double* ppb; double* ppnb;   // prev_prob_blank / prev_prob_not_blank
   double* npb; double* npnb;   // this step's prob_blank / prob_not_blank (become prev at next_step)
   double* inc;                 // contribution to prob_not_blank arriving from the parent (if it is in the beam)
-  double* full;                // log_sum_exp(prev_pnb, prev_pb), once per member and step
+  double* full;                // log_sum_exp(prev_pnb, prev_pb): carried from the previous step's score (nfull) / a new member's val
+  double* nfull;               // log_sum_exp(npnb, npb), computed for this step's score
   int* node; int* last; int* kept;
   int* newpos;                 // position in the beam this step selects (valid where kept)
   int* gown; int* gchar; int* gnode;   // the member's guard (see the file header): owner's position (-1: none), character, node
@@ -583,6 +590,7 @@ struct Members {
     ppb = (double*)q; q += sizeof(double) * W; ppnb = (double*)q; q += sizeof(double) * W;
     npb = (double*)q; q += sizeof(double) * W; npnb = (double*)q; q += sizeof(double) * W;
     inc = (double*)q; q += sizeof(double) * W; full = (double*)q; q += sizeof(double) * W;
+    nfull = (double*)q; q += sizeof(double) * W;
     lm = (LmFields*)q; q += sizeof(LmFields) * W;
     node = (int*)q; q += sizeof(int) * W; last = (int*)q; q += sizeof(int) * W;
     kept = (int*)q; q += sizeof(int) * W; newpos = (int*)q; q += sizeof(int) * W;
@@ -591,7 +599,7 @@ struct Members {
     from = (int*)q; q += sizeof(int) * W;        // (an even number of int arrays: the next set starts 8-byte aligned)
     return q;
   }
-  __host__ __device__ static size_t bytes(int W) { return (size_t)W * (6 * sizeof(double) + sizeof(LmFields) + 8 * sizeof(int)); }
+  __host__ __device__ static size_t bytes(int W) { return (size_t)W * (7 * sizeof(double) + sizeof(LmFields) + 8 * sizeof(int)); }
 };
 
 struct BeamLds {
@@ -691,7 +699,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     l.lm_score = 0.0; l.lm_before = 0.0; l.num_words = 0; l.num_oov = 0; l.num_oov_before = 0; l.word_len = 0;
     l.word_hash = kFnvInit; l.st_n = 0; l.stb_n = 0;
     if (p.has_lm) { l.st[0] = p.lm.bos; l.st_n = 1; l.stb[0] = p.lm.bos; l.stb_n = 1; }
-    M0.ppb[0] = 0.0; M0.ppnb[0] = ninf(); M0.node[0] = 0; M0.last[0] = -1; M0.gown[0] = -1; M0.gchar[0] = 0; M0.gnode[0] = 0;
+    M0.ppb[0] = 0.0; M0.ppnb[0] = ninf(); M0.full[0] = lse2(ninf(), 0.0); M0.node[0] = 0; M0.last[0] = -1; M0.gown[0] = -1; M0.gchar[0] = 0; M0.gnode[0] = 0;
     M0.lm[0] = l;
   }
   __syncthreads();
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     // step's start
     double next_lp = 0.0;
     if (tid < V && t + 1 < T) next_lp = (double)lp[(int64_t)(t + 1) * p.sT + (int64_t)tid * p.sV];
-    for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; A.full[i] = lse2(A.ppnb[i], A.ppb[i]); }
+    for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; }    // (A.full: set when the member was placed)
     for (int h = tid; h < p.HS; h += kThreads) mapB.key[h] = -1;
     for (int e = tid; e < W * V; e += kThreads) ctabB[e] = -1;
     for (int h = tid; h < 2 * kSelBins; h += kThreads) hist[h] = 0;        // (the second half held the previous step's sel)
@@ -774,7 +782,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       double pnb = A.inc[i];
       if (lc >= 0 && lc != blank) pnb = lse2(pnb, srow[lc] + A.ppnb[i]);
       A.npnb[i] = pnb;
-      const double sc = beam_score<LM>(p, pnb, A.npb[i], A.lm[i]);
+      const double nf = lse2(pnb, A.npb[i]);            // the score's log-sum-exp is next step's `full` if the member stays
+      A.nfull[i] = nf;
+      const double sc = beam_score_full<LM>(p, nf, A.lm[i]);
       key[i] = sc;
       const unsigned h32 = (unsigned)(okey(sc) >> 32);
       key_hi = max(key_hi, h32); key_lo = min(key_lo, h32);
@@ -937,7 +947,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       if (d < n) {
         const int i = d;
         A.kept[i] = 1; A.newpos[i] = j; Bm.from[j] = i;
-        Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i];
+        Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i]; Bm.full[j] = A.nfull[i];
         Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; copy_lm<LM>(Bm.lm[j], A.lm[i]);
         Bm.gown[j] = A.gown[i]; Bm.gchar[j] = A.gchar[i]; Bm.gnode[j] = A.gnode[i];     // (owner: position in A, for now)
         mapB.insert(A.node[i], j);
@@ -956,7 +966,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
           nodes[k] = nn;                                                          // (fire and forget)
           mapB.insert(k, j);
         }
-        Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.node[j] = k; Bm.last[j] = c;
+        Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.full[j] = lse2(val, ninf()); Bm.node[j] = k; Bm.last[j] = c;
         Bm.gown[j] = i; Bm.gchar[j] = c; Bm.gnode[j] = k;                         // its own guard, if its parent stays
         Bm.from[j] = -1;
         if (LM) newlist[atomicAdd(&s_nnew, 1)] = j;
