@@ -394,11 +394,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Candidate d >= n of a step is the pair q = d - n (q = c*n + i, the reference's order); a pair that creates no prefix
 // holds this marker instead of a score: a negative NaN, which the order-preserving key maps BELOW -inf (scores can
 // be -inf), and which every pass over the keys skips.
-constexpr unsigned long long kNoCandBits = 0xFFF8000000000000ULL;
-constexpr unsigned long long kNoCandKey = ~kNoCandBits;
+constexpr unsigned long long kNoCandKey = ~0xFFF8000000000000ULL;
 // order-preserving map double -> uint64 (larger double <=> larger key)
+// (-0.0 and +0.0 compare equal as doubles -- the oracle's order -- so the key is taken of d + 0.0, which is +0.0 for both)
 __device__ __forceinline__ unsigned long long okey(double d) {
-  unsigned long long u = (unsigned long long)__double_as_longlong(d);
+  unsigned long long u = (unsigned long long)__double_as_longlong(d + 0.0);
   return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
 }
 
@@ -718,6 +718,8 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     Bm.carve(mem0 + (size_t)(cur ^ 1) * mbytes, W);
     const SlotMap mapA = slot_map(cur);              // node -> position among the current members
     const SlotMap mapB = slot_map(cur ^ 1);          // ... among the members this step selects (filled in the rebuild)
+    unsigned long long* const ukey = reinterpret_cast<unsigned long long*>(key);   // inside the step key[] holds okey(score)
+    unsigned long long* const uskey = reinterpret_cast<unsigned long long*>(skey);
     const int* const ctab = ctab0 + (size_t)cur * W * V;          // child tables of the current members: [member][V]
     int* const ctabB = ctab0 + (size_t)(cur ^ 1) * W * V;         // ... of the members this step selects
     const LmAnswer* const lmcA = lmc0 + (size_t)cur * W * V;
@@ -748,8 +750,8 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       if (++i == n) { i = 0; c++; }
       const double curp = srow[ci];
       const double full = A.full[ii];
-      double* const slot = key + n + q;
-      *reinterpret_cast<unsigned long long*>(slot) = kNoCandBits;
+      unsigned long long* const slot = ukey + n + q;
+      *slot = kNoCandKey;
       if (ci == blank) { A.npb[ii] = curp + full; continue; }                  // :374-376 (prob_blank was -inf)
       const double val = curp + (ci == A.last[ii] ? A.ppb[ii] : full);         // :383-385 / :389-391
       const int k = ctab[ii * V + ci];
@@ -763,8 +765,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         if (LM) ans = lmcA[ii * V + ci];
         child_score_fields<LM>(p, A.lm[ii], A.last[ii], ci, ans, nl);
         const double sc = beam_score<LM>(p, val, ninf(), nl);                       // after next_step: prev_pnb = val, prev_pb = -inf
-        *slot = sc;
-        key_hi = max(key_hi, (unsigned)(okey(sc) >> 32));
+        const unsigned long long uk = okey(sc);
+        *slot = uk;
+        key_hi = max(key_hi, (unsigned)(uk >> 32));
         my_new++;
       }
     }
@@ -785,8 +788,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       const double nf = lse2(pnb, A.npb[i]);            // the score's log-sum-exp is next step's `full` if the member stays
       A.nfull[i] = nf;
       const double sc = beam_score_full<LM>(p, nf, A.lm[i]);
-      key[i] = sc;
-      const unsigned h32 = (unsigned)(okey(sc) >> 32);
+      const unsigned long long uk = okey(sc);
+      ukey[i] = uk;
+      const unsigned h32 = (unsigned)(uk >> 32);
       key_hi = max(key_hi, h32); key_lo = min(key_lo, h32);
     }
     if (wid < (n + 63) / 64) {
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         const int width = nbits < kSelBits ? nbits : kSelBits;
         const unsigned long long dmask = (1ULL << width) - 1ULL;
         for (int d = tid; d < ntot; d += kThreads) {
-          const unsigned long long u = okey(key[d]);
+          const unsigned long long u = ukey[d];
           if ((u & mask) == prefix && u != kNoCandKey) atomicAdd(&hcur[(int)((u >> shift) & dmask)], 1);
         }
         lds_barrier();
@@ -844,7 +848,10 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         }
         lds_barrier();
         int above = inc - mine;                       // candidates with a larger digit than this thread's first
-        for (int w = 0; w < wid; w++) above += s_part[w];
+        {
+          const int wtot = wave_scan_i(lane < kThreads / 64 ? s_part[lane] : 0);
+          if (wid > 0) above += __builtin_amdgcn_readlane(wtot, wid - 1);
+        }
         const unsigned long long digit_mask = dmask << shift;
         if (above < krem && above + mine >= krem) {   // the threshold digit is one of this thread's
 #pragma unroll
@@ -883,22 +890,26 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       unsigned cls = 0;                              // two bits per candidate of this thread: 1 above, 2 in the threshold bin
       static_assert(kMaxCand <= 16 * kThreads, "classification bits per thread");
       for (int d = d0, sh2 = 0; d < d1; d++, sh2 += 2) {
-        const unsigned long long uf = okey(key[d]), u = OKEY_CMP(uf);
+        const unsigned long long uf = ukey[d], u = OKEY_CMP(uf);
         const bool gt = u > Tk, eq = u == Tk && uf != kNoCandKey;
         ngt += gt; neq += eq;
         cls |= (gt ? 1u : eq ? 2u : 0u) << sh2;
       }
-      const int ig = wave_scan_i(ngt), ie = wave_scan_i(neq);
-      if (lane == 63) { s_part[wid] = ig; s_part[16 + wid] = ie; }
+      // (both counts ride in one integer -- at most 8192 candidates, 16 bits each -- through one wave scan, and the 16
+      // waves' totals through one 16-lane scan instead of a 16-step loop in every wave)
+      const int iboth = wave_scan_i(ngt | (neq << 16));
+      if (lane == 63) s_part[wid] = iboth;
       lds_barrier();
-      int bg = 0, be = 0, tg = 0;
-      for (int w = 0; w < kThreads / 64; w++) { if (w < wid) { bg += s_part[w]; be += s_part[16 + w]; } tg += s_part[w]; }
-      int og = bg + ig - ngt, oe = be + ie - neq;
+      const int wtot = wave_scan_i(lane < kThreads / 64 ? s_part[lane] : 0);
+      const int wbase = wid > 0 ? __builtin_amdgcn_readlane(wtot, wid - 1) : 0;
+      const int tg = __builtin_amdgcn_readlane(wtot, kThreads / 64 - 1) & 0xffff;
+      const int mine_excl = wbase + iboth - (ngt | (neq << 16));
+      int og = mine_excl & 0xffff, oe = mine_excl >> 16;
       const int take = small_bin ? bin : krem;
       for (int d = d0; d < d1 && cls; d++, cls >>= 2) {
-        if (cls & 1u) { skey[og] = key[d]; sidx[og] = d; og++; }
+        if (cls & 1u) { uskey[og] = ukey[d]; sidx[og] = d; og++; }
         else if (cls & 2u) {
-          if (oe < take) { skey[tg + oe] = key[d]; sidx[tg + oe] = d; }
+          if (oe < take) { uskey[tg + oe] = ukey[d]; sidx[tg + oe] = d; }
           oe++;
         }
       }
@@ -914,10 +925,10 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         if (e < M) {
           // (the gathered list is in position order within its two parts, and the keys of the first part are all
           // larger than those of the second: among equal keys the earlier list index is the earlier position)
-          const double ke = skey[e];
+          const unsigned long long ke = uskey[e];
 #pragma unroll 4
           for (int jj = part; jj < M; jj += 8) {
-            const double kj = skey[jj];
+            const unsigned long long kj = uskey[jj];
             cnt += (kj > ke || (kj == ke && jj < e)) ? 1 : 0;
           }
         }
@@ -936,7 +947,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       int pos = n + incl - my_new;
       for (int w = 0; w < wid; w++) pos += s_part[w];
       for (int q = q0; q < q1; q++)
-        if (okey(key[n + q]) != kNoCandKey) sel[pos++] = n + q;
+        if (ukey[n + q] != kNoCandKey) sel[pos++] = n + q;
       lds_barrier();
     }
     BPROF(3);
