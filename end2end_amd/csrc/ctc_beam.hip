@@ -469,15 +469,18 @@ __device__ __forceinline__ float lm_score_parallel(const LmView& lm, const uint3
   if (!found) result = acc + lm.unk_prob;
   return result;
 }
+// FAST: the model has signature tables and at most kParCtx words of context (checked by the host): only the round-probed
+// walk is compiled in.  Otherwise: the general walk over the id tables (any order up to 6).
+template <bool FAST>
 __device__ __forceinline__ LmAnswer lm_query(const BeamParams& p, const LabelTab& lt, const LmFields& pr, int parent_last, int c) {
   const bool new_word = pr.num_words == 0 || parent_last == p.space_id;                           // :258-259 (c != space)
   LmAnswer a;
   uint64_t h = spell(p, lt, new_word ? kFnvInit : pr.word_hash, c);
-  uint32_t ctx[kCtx];
   int cn = new_word ? pr.st_n : pr.stb_n;
+  if (FAST) {
+    uint32_t ctx[kCtx];
 #pragma unroll
-  for (int s2 = 0; s2 < kCtx; s2++) ctx[s2] = new_word ? pr.st[s2] : pr.stb[s2];
-  if (p.lm.ngs) {
+    for (int s2 = 0; s2 < kCtx; s2++) ctx[s2] = new_word ? pr.st[s2] : pr.stb[s2];
     if (h == 0) h = 1;
     a.wi = 0;
     for (uint32_t i = (uint32_t)h & p.lm.vmask;; i = (i + 1) & p.lm.vmask) {
@@ -486,13 +489,11 @@ __device__ __forceinline__ LmAnswer lm_query(const BeamParams& p, const LabelTab
       if (e.key == 0) break;                      // NotFound() == <unk> == 0
     }
     if (cn > p.lm.order - 1) cn = p.lm.order - 1;
-    if (cn <= kParCtx) { a.sc = lm_score_parallel(p.lm, ctx, cn, a.wi); return a; }
+    a.sc = lm_score_parallel(p.lm, ctx, cn, a.wi);
   } else {
     a.wi = lm_word_lookup(p.lm, h);
+    a.sc = lm_base_score(p.lm, new_word ? pr.st : pr.stb, cn, a.wi, nullptr, nullptr);
   }
-  // (the general walk indexes the context dynamically: give it the prefix's own arrays, so that the local copy above is
-  // only ever indexed statically and stays in registers instead of scratch memory)
-  a.sc = lm_base_score(p.lm, new_word ? pr.st : pr.stb, cn, a.wi, nullptr, nullptr);
   return a;
 }
 
@@ -642,9 +643,11 @@ namespace e2e { namespace {
 #endif
 
 // NT threads per workgroup
-template <typename IO, bool LM, int NT>
+// LMK: 0 no language model, 1 the general LM walk, 2 the fast one (see lm_query)
+template <typename IO, int LMK, int NT>
 __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
   constexpr int kThreads = NT;
+  constexpr bool LM = LMK != 0;
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V, W = p.W, blank = p.blank;
@@ -704,7 +707,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
   }
   __syncthreads();
   if (tid == 0) slot_map(0).insert(0, 0);
-  if (LM) for (int c = tid; c < V; c += kThreads) if (c != blank && c != p.space_id) lmc0[c] = lm_query(p, lt, M0.lm[0], -1, c);
+  if (LM) for (int c = tid; c < V; c += kThreads) if (c != blank && c != p.space_id) lmc0[c] = lm_query<LMK == 2>(p, lt, M0.lm[0], -1, c);
   __syncthreads();
   int n = 1, cur = 0;
 #ifdef E2E_BEAM_PROFILE
@@ -1020,7 +1023,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       for (int t2 = tid; t2 < nnew * V; t2 += kThreads) {
         const int r = t2 / V, c = t2 - r * V, j2 = newlist[r];
         if (c == blank || c == p.space_id) continue;
-        lmcB[j2 * V + c] = lm_query(p, lt, Bm.lm[j2], Bm.last[j2], c);
+        lmcB[j2 * V + c] = lm_query<LMK == 2>(p, lt, Bm.lm[j2], Bm.last[j2], c);
       }
     }
     lds_barrier();
@@ -1118,8 +1121,14 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   p.status = reinterpret_cast<int*>(ws + l.status);
   p.NCAP = l.NCAP; p.CMAX = l.CMAX; p.WP2 = l.WP2; p.HS = l.HS;
   hipStream_t s = (hipStream_t)stream;
-  const void* fn = dtype == E2E_F32 ? (lm ? (const void*)&ctc_beam_kernel<float, true, kThreadsLm> : (const void*)&ctc_beam_kernel<float, false, kThreadsNoLm>)
-                                    : (lm ? (const void*)&ctc_beam_kernel<double, true, kThreadsLm> : (const void*)&ctc_beam_kernel<double, false, kThreadsNoLm>);
+  const bool fast_lm = lm && lm->d_ngs && lm->order - 1 <= kParCtx;
+  const void* fn;
+  if (dtype == E2E_F32)
+    fn = !lm ? (const void*)&ctc_beam_kernel<float, 0, kThreadsNoLm>
+             : fast_lm ? (const void*)&ctc_beam_kernel<float, 2, kThreadsLm> : (const void*)&ctc_beam_kernel<float, 1, kThreadsLm>;
+  else
+    fn = !lm ? (const void*)&ctc_beam_kernel<double, 0, kThreadsNoLm>
+             : fast_lm ? (const void*)&ctc_beam_kernel<double, 2, kThreadsLm> : (const void*)&ctc_beam_kernel<double, 1, kThreadsLm>;
   const int nthreads = lm ? kThreadsLm : kThreadsNoLm;
   E2E_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds), "hipFuncSetAttribute");
   void* args[] = { &p };
