@@ -955,7 +955,15 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     }
     BPROF(3);
     // ---- rebuild the beam in the other member set ----
-    int* const newlist = sidx;                      // (the gathered candidates are dead once sel[] is written) positions of the new members
+    // (LM: scratch of the answer phase below, in regions that are dead by now -- the first histogram, the gathered
+    // candidates, the candidate keys)
+    int* const newlist = sidx;                                                        // new members that have to ask
+    int* const ldr = reinterpret_cast<int*>(skey);                                    // leader of member j
+    unsigned long long* const sg = reinterpret_cast<unsigned long long*>(key);        // state signature of member j
+    constexpr int kStateSlots = 512;                                                  // (>= 2 * 200 members at the widest beam that fits)
+    unsigned long long* const tsig = reinterpret_cast<unsigned long long*>(hist);     // open addressing: signature -> smallest rank
+    int* const tval = hist + 2 * kStateSlots;
+    if (LM) for (int h = tid; h < kStateSlots; h += kThreads) { tsig[h] = 0ULL; tval[h] = 0x7fffffff; }
     for (int j = tid; j < nsel; j += kThreads) {
       const int d = sel[j];
       if (d < n) {
@@ -983,7 +991,6 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.full[j] = lse2(val, ninf()); Bm.node[j] = k; Bm.last[j] = c;
         Bm.gown[j] = i; Bm.gchar[j] = c; Bm.gnode[j] = k;                         // its own guard, if its parent stays
         Bm.from[j] = -1;
-        if (LM) newlist[atomicAdd(&s_nnew, 1)] = j;
       }
     }
     lds_barrier();
@@ -1005,15 +1012,60 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       }
     }
     if (LM) {
-      // the LM's answers for the new beam: carried over with a member that stays, asked for a member that is new --
-      // one (member, character) per thread, so the table walks of a step overlap instead of queueing up three deep
-      // behind every thread of the pair loop.  (Most new members share their LM state -- the word begun, the context --
-      // with another member: 70 new per step, 22 distinct states measured.  Asking only once per state was tried; the
-      // search for the shared state cost what the saved queries gained, because every wave walks the query code
-      // anyway as long as one of its lanes has a query.)
-      // Copies and queries are separate loops, and the queries run over the packed list of new members: a wave walks
-      // the whole query code as soon as one of its lanes has a query, so what counts is the number of rounds in which
-      // waves do -- ceil(new * V / 1024) instead of ceil(W * V / 1024).
+      // The LM's answers for the new beam: carried over with a member that stays, asked for a member that is new -- but
+      // only once per LM STATE.  What is asked depends on the member's state only (the word begun, the context, whether
+      // a word starts), and most new members share theirs with another member: prefixes that differ further back than
+      // the model looks (measured: 70 new members per step, 22 distinct states).  A wave walks the whole query code as
+      // soon as one of its lanes has a query, so the queries are packed: one (asking member, character) per thread.
+      //   1. every member enters its state's signature into a small hash table, keeping the smallest rank per state
+      //      (members that stay rank before new ones: their answers are already there);
+      //   2. a new member looks its state up; if the holder really has the same state (the signature is a filter) it
+      //      follows the holder, else it asks itself and joins the packed list;
+      //   3. rows are copied (staying members) / asked (list);  4. followers copy their leader's row.
+      BPROF(11);
+      auto state_of = [&](int j2, bool& nw, int& cn, unsigned long long& wh) {
+        const LmFields& m = Bm.lm[j2];
+        nw = m.num_words == 0 || Bm.last[j2] == p.space_id;
+        cn = nw ? m.st_n : m.stb_n;
+        wh = nw ? 0ULL : m.word_hash;
+      };
+      for (int j2 = tid; j2 < nsel; j2 += kThreads) {
+        bool nw; int cn; unsigned long long wh;
+        state_of(j2, nw, cn, wh);
+        unsigned long long h = wh;
+        for (int q2 = 0; q2 < cn; q2++) h = ng_mix(h, nw ? Bm.lm[j2].st[q2] : Bm.lm[j2].stb[q2]);
+        h = ng_mix(h, (uint32_t)cn + (nw ? 100u : 0u));
+        if (h == 0) h = 1;
+        sg[j2] = h;
+        const int rank = Bm.from[j2] >= 0 ? j2 : j2 + 4096;
+        for (unsigned sl = (unsigned)(h >> 20) & (kStateSlots - 1);; sl = (sl + 1) & (kStateSlots - 1)) {
+          const unsigned long long old = atomicCAS(&tsig[sl], 0ULL, h);
+          if (old == 0ULL || old == h) { atomicMin(&tval[sl], rank); break; }
+        }
+      }
+      lds_barrier();
+      BPROF(12);
+      for (int j2 = tid; j2 < nsel; j2 += kThreads) {
+        int leader = j2;
+        if (Bm.from[j2] < 0) {
+          const unsigned long long h = sg[j2];
+          unsigned sl = (unsigned)(h >> 20) & (kStateSlots - 1);
+          while (tsig[sl] != h) sl = (sl + 1) & (kStateSlots - 1);
+          const int o = tval[sl] & 4095;
+          if (o != j2) {
+            bool nw, nw2; int cn, cn2; unsigned long long wh, wh2;
+            state_of(j2, nw, cn, wh); state_of(o, nw2, cn2, wh2);
+            bool same = nw2 == nw && cn2 == cn && wh2 == wh;
+            for (int q2 = 0; q2 < cn && same; q2++)
+              same = (nw ? Bm.lm[o].st[q2] : Bm.lm[o].stb[q2]) == (nw ? Bm.lm[j2].st[q2] : Bm.lm[j2].stb[q2]);
+            if (same) leader = o;
+          }
+          if (leader == j2) newlist[atomicAdd(&s_nnew, 1)] = j2;
+        }
+        ldr[j2] = leader;
+      }
+      lds_barrier();
+      BPROF(13);
       for (int e = tid; e < nsel * V; e += kThreads) {
         const int j2 = e / V;
         const int f = Bm.from[j2];
@@ -1024,6 +1076,13 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         const int r = t2 / V, c = t2 - r * V, j2 = newlist[r];
         if (c == blank || c == p.space_id) continue;
         lmcB[j2 * V + c] = lm_query<LMK == 2>(p, lt, Bm.lm[j2], Bm.last[j2], c);
+      }
+      lds_barrier();
+      BPROF(14);
+      for (int e = tid; e < nsel * V; e += kThreads) {
+        const int j2 = e / V;
+        const int o = ldr[j2];
+        if (o != j2) lmcB[e] = lmcB[o * V + (e - j2 * V)];
       }
     }
     lds_barrier();
