@@ -18,14 +18,15 @@
 //   No global atomics, no reads of the node pool inside the step loop.
 // All scores are IEEE doubles with the reference's two-argument log-sum-exp.  The beam (probabilities, LM state, child
 // tables) lives in LDS; prefixes are created LAZILY: a step scores all W*V would-be prefixes, selects the W survivors
-// (8-pass radix select on an order-preserving 64-bit key, ties by position, then a one-wavefront bitonic sort of the
-// survivors into (score descending, position ascending) order -- the reference's nth_element leaves ties unspecified,
-// quirk Q9; the oracle uses the same total order) and only then allocates nodes for the new ones.  Upstream a new prefix
-// that does not survive its first pruning is destroyed at once, so this is equivalent and saves ~W*V allocations,
-// LM-state writes and frees per step.
+// (radix select on an order-preserving 64-bit key started below the bits the best and the worst surviving score share --
+// one pass in practice -- then a rank-by-counting of the <= W+63 gathered candidates into (score descending, position
+// ascending) order: the reference's nth_element leaves ties unspecified, quirk Q9; the oracle uses the same total order)
+// and only then allocates nodes for the new ones.  Upstream a new prefix that does not survive its first pruning is
+// destroyed at once, so this is equivalent and saves ~W*V allocations, LM-state writes and frees per step.
 //
 // The language model stands where KenLM stands upstream (src/decoders/ctc_decoder.cpp:60-71,77-88,264-308):
-// host-side ARPA reader (plain or gzip), device-resident open-addressing tables, standard back-off scoring.
+// host-side ARPA reader (plain or gzip), device-resident open-addressing tables, standard back-off scoring.  A beam
+// member's V answers are looked up once per LM state when it enters the beam and kept in LDS (see lm_query).
 #include <zlib.h>
 
 #include <algorithm>
