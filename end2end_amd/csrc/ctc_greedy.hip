@@ -115,6 +115,123 @@ __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(GreedyParams p) {
   if (tid == 0) p.out_len[b] = n;
 }
 
+// ---- streaming form for contiguous rows of a small alphabet ------------------------------------------------------
+// The kernel above synchronises the workgroup seven times per 256 frames and waits for every tile's loads before it
+// touches them.  Here each WAVE streams 64-frame chunks on its own: the chunk after the one being worked on is already
+// requested (16-byte loads into registers), the chunk itself goes through a wave-private LDS tile (lane = frame, odd
+// row stride), and the only workgroup barriers are three per super-tile of 4096 frames, around the collapse.  The
+// symbols of a super-tile and its compacted output live in LDS as bytes (V <= 64); the output is written coalesced.
+// LDS per workgroup stays below 40 KB so that four workgroups share a CU: B = 1024 utterances then run in one round.
+constexpr int kChunk = 64;           // frames per wave and chunk
+constexpr int kSuper = 1024;         // frames per super-tile
+constexpr int kStreamWaves = 4;
+constexpr int kMaxPf = 16;           // 16-byte loads per lane and chunk (V <= 64 floats, or V <= 32 doubles)
+
+template <typename IO, int NPF>      // NPF >= ceil(64 * V * sizeof(IO) / 1024): 16-byte pieces per lane and chunk
+__global__ __launch_bounds__(64 * kStreamWaves) void ctc_greedy_stream_kernel(GreedyParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  typedef int i4 __attribute__((ext_vector_type(4)));
+  constexpr int EPV = 16 / (int)sizeof(IO);                       // elements per 16-byte load
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int V = p.V, Tmax = p.T, blank = p.blank;
+  const int ldv = V | 1;
+  const IO* x = reinterpret_cast<const IO*>(p.x) + (int64_t)b * p.sB;
+  int64_t* out = p.out + (int64_t)b * Tmax;
+  int64_t Tq = p.x_len[b];
+  const int T = Tq < 0 ? 0 : (Tq > Tmax ? Tmax : (int)Tq);
+  IO* tile = reinterpret_cast<IO*>(smem) + (size_t)wid * kChunk * ldv;                 // wave-private
+  unsigned char* sym = smem + (size_t)kStreamWaves * kChunk * ldv * sizeof(IO);
+  unsigned char* comp = sym + kSuper;
+  __shared__ int wave_tot[kStreamWaves];
+  __shared__ int carry_prev, carry_n;
+  if (tid == 0) { carry_prev = blank; carry_n = 0; }
+  const unsigned vmagic = (1u << 20) / (unsigned)V + 1u;          // i / V for i < 64 * 64
+
+  for (int s0 = 0; s0 < T; s0 += kSuper) {
+    const int sn = min(kSuper, T - s0);
+    const int nchunks = (sn + kChunk - 1) / kChunk;
+    // ---- phase 1: per-frame arg-max, one wave per chunk, the next chunk's loads in flight ----
+    // (every load is a whole 16-byte piece at a clamped index: pieces past the chunk, or past the utterance's slab of
+    // Tmax frames, re-read the slab's last piece -- frames past the utterance's end never reach sym[])
+    i4 pf[NPF];
+    const int slab_pieces = (int)(((int64_t)Tmax * V) / EPV);
+    const i4* const xp = reinterpret_cast<const i4*>(x);
+    auto request = [&](int c) {
+      const int p0 = (s0 + c * kChunk) * V / EPV;                 // (64 * V is a multiple of EPV)
+#pragma unroll
+      for (int u = 0; u < NPF; u++) pf[u] = __builtin_nontemporal_load(&xp[min(p0 + lane + 64 * u, slab_pieces - 1)]);
+    };
+    if (wid < nchunks) request(wid);
+    for (int c = wid; c < nchunks; c += kStreamWaves) {
+      // park the chunk in the tile (row stride ldv: element i of the chunk lands at i + i / V when V is even)
+#pragma unroll
+      for (int u = 0; u < NPF; u++) {
+        const int e = (lane + 64 * u) * EPV;
+        if (e < kChunk * V) {
+          if (ldv == V) *reinterpret_cast<i4*>(&tile[e]) = pf[u];
+          else {
+            const IO* q = reinterpret_cast<const IO*>(&pf[u]);
+#pragma unroll
+            for (int k = 0; k < EPV; k++) tile[e + k + (int)(((unsigned)(e + k) * vmagic) >> 20)] = q[k];
+          }
+        }
+      }
+      if (c + kStreamWaves < nchunks) request(c + kStreamWaves);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (wave-private tile: no barrier)
+      const int t = c * kChunk + lane;                            // frame within the super-tile
+      const IO* row = tile + lane * ldv;
+      // first maximum; NaN counts as the maximum (torch.argmax): the plain scan ignores NaNs, a row that has one is redone
+      IO bv = row[0]; int bi = 0; bool has_nan = bv != bv;
+      int v = 1;
+      for (; v + 3 < V; v += 4) {                                  // four LDS reads in flight per trip
+        const IO c0 = row[v], c1 = row[v + 1], c2 = row[v + 2], c3 = row[v + 3];
+        has_nan |= (c0 != c0) | (c1 != c1) | (c2 != c2) | (c3 != c3);
+        if (c0 > bv) { bv = c0; bi = v; }
+        if (c1 > bv) { bv = c1; bi = v + 1; }
+        if (c2 > bv) { bv = c2; bi = v + 2; }
+        if (c3 > bv) { bv = c3; bi = v + 3; }
+      }
+      for (; v < V; v++) { const IO cv = row[v]; has_nan |= cv != cv; if (cv > bv) { bv = cv; bi = v; } }
+      if (has_nan) {
+        bv = row[0]; bi = 0;
+        for (int v2 = 1; v2 < V; v2++) { const IO cv = row[v2]; if (better(cv, v2, bv, bi)) { bv = cv; bi = v2; } }
+      }
+      if (t < sn) sym[t] = (unsigned char)bi;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the tile is rewritten by the next chunk
+    }
+    __syncthreads();
+    // ---- phase 2: collapse (emit iff sym != blank && sym != previous frame's sym, ctc_decoder.cpp:475-481) ----
+    constexpr int kPer = kSuper / (64 * kStreamWaves);            // consecutive frames per thread
+    const int f0 = tid * kPer;
+    int prev = f0 == 0 ? carry_prev : (f0 - 1 < sn ? (int)sym[f0 - 1] : blank);
+    int mine[kPer], cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int sy = f0 + k < sn ? (int)sym[f0 + k] : -1;
+      mine[k] = (sy >= 0 && sy != blank && sy != prev) ? sy : -1;
+      cnt += mine[k] >= 0;
+      prev = sy;
+    }
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    int pos = incl - cnt, total = 0;
+    for (int w = 0; w < kStreamWaves; w++) { if (w < wid) pos += wave_tot[w]; total += wave_tot[w]; }
+#pragma unroll
+    for (int k = 0; k < kPer; k++) if (mine[k] >= 0) comp[pos++] = (unsigned char)mine[k];
+    const int base = carry_n, last = (int)sym[sn - 1];
+    __syncthreads();
+    for (int i = tid; i < total; i += 64 * kStreamWaves) out[base + i] = (int64_t)comp[i];
+    if (tid == 0) { carry_n = base + total; carry_prev = last; }
+    __syncthreads();
+  }
+  __syncthreads();
+  const int n = carry_n;
+  for (int i = n + tid; i < Tmax; i += 64 * kStreamWaves) out[i] = 0;   // zeros_like padding (Q5)
+  if (tid == 0) p.out_len[b] = n;
+}
+
 }  // namespace
 
 int launch_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV, const int64_t* x_len,
@@ -122,6 +239,23 @@ int launch_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV, 
   GreedyParams p{x, sB, sT, sV, x_len, B, T, V, blank, out, out_len};
   if (B == 0) return E2E_OK;
   const size_t esz = dtype == E2E_F32 ? 4 : 8;
+  {
+    // contiguous 16-byte aligned rows of a small alphabet: the streaming kernel
+    const size_t lds_stream = (size_t)kStreamWaves * kChunk * (V | 1) * esz + 2 * kSuper;
+    const bool aligned = reinterpret_cast<uintptr_t>(x) % 16 == 0 && (sB * (int64_t)esz) % 16 == 0;
+    if (sV == 1 && sT == V && aligned && V >= 1 && (size_t)V * esz <= 16 * kMaxPf && lds_stream <= 60 * 1024) {
+      const int npf = (int)((64 * (size_t)V * esz + 1023) / 1024);
+      if (dtype == E2E_F32) {
+        if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<float, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        else hipLaunchKernelGGL((ctc_greedy_stream_kernel<float, 16>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+      } else {
+        if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<double, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        else hipLaunchKernelGGL((ctc_greedy_stream_kernel<double, 16>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+      }
+      E2E_HIP_CHECK(hipGetLastError(), "ctc_greedy_stream_kernel launch");
+      return E2E_OK;
+    }
+  }
   const size_t lds = V <= kSmallV ? (size_t)kThreads * (V | 1) * esz : 16;
   if (dtype == E2E_F32)
     hipLaunchKernelGGL(ctc_greedy_kernel<float>, dim3(B), dim3(kThreads), lds, stream, p);
