@@ -736,43 +736,50 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; }    // (A.full: set when the member was placed)
     for (int h = tid; h < p.HS; h += kThreads) mapB.key[h] = -1;
     for (int e = tid; e < W * V; e += kThreads) ctabB[e] = -1;
-    for (int h = tid; h < 2 * kSelBins; h += kThreads) hist[h] = 0;        // (the second half held the previous step's sel)
+    for (int h = tid; h < kSelBins; h += kThreads) hist[h] = 0;            // (the second histogram is cleared by the pass before it)
     if (tid == 0) { s_hi = 0u; s_lo = 0xffffffffu; s_total_new = 0; s_nnew = 0; }
     lds_barrier();
-    // pairs in the reference's order: character outer, prefix inner (:370-395): q = c*n + i
+    BPROF(0);
+    // pairs: candidate q = c*n + i is the reference's order (character outer, prefix inner, :370-395).  The threads are
+    // laid out member-major -- P threads per member, each taking every P-th character -- so that what a pair needs of
+    // its member (probabilities, last character, word count, LM state) is read once per thread, not once per pair.
     const int npairs = n * V;
-    const int chunk = (npairs + kThreads - 1) / kThreads;
-    const int q0 = min(tid * chunk, npairs), q1 = min(q0 + chunk, npairs);
-    const int c_first = q0 / n, i_first = q0 - c_first * n;                      // (the only division: the chunk walks on from here)
+    const int P = n < kThreads ? kThreads / n : 1;            // threads per member
+    const int members_per_pass = kThreads / P;
+    const int part = tid % P;
     int my_new = 0;
-    // the pairs: blank shares, child shares, scores of the would-be prefixes (weak child lookup, :250-252)
+    // blank shares, child shares, scores of the would-be prefixes (weak child lookup, :250-252)
     // (the high words of the largest key of all and of the smallest key of the old members bracket the selection
     // threshold; they are collected while the keys are produced)
     unsigned key_hi = 0u, key_lo = 0xffffffffu;
-    for (int q = q0, c = c_first, i = i_first; q < q1; q++) {
-      const int ci = c, ii = i;
-      if (++i == n) { i = 0; c++; }
-      const double curp = srow[ci];
-      const double full = A.full[ii];
-      unsigned long long* const slot = ukey + n + q;
-      *slot = kNoCandKey;
-      if (ci == blank) { A.npb[ii] = curp + full; continue; }                  // :374-376 (prob_blank was -inf)
-      const double val = curp + (ci == A.last[ii] ? A.ppb[ii] : full);         // :383-385 / :389-391
-      const int k = ctab[ii * V + ci];
-      if (k >= 0) {
-        const int j = mapA.find(k);
-        if (j >= 0) A.inc[j] = val;            // the child is a beam member: its share from this parent
-        // else: alive but pruned (Q7) -- the probability is lost and the slot stays taken
-      } else {
-        LmFields nl;
-        LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
-        if (LM) ans = lmcA[ii * V + ci];
-        child_score_fields<LM>(p, A.lm[ii], A.last[ii], ci, ans, nl);
-        const double sc = beam_score<LM>(p, val, ninf(), nl);                       // after next_step: prev_pnb = val, prev_pb = -inf
-        const unsigned long long uk = okey(sc);
+    for (int ii = tid / P; ii < n; ii += members_per_pass) {
+      const double full = A.full[ii], ppb = A.ppb[ii];
+      const int last = A.last[ii];
+      LmFields pr;                                              // (only the fields the scores need are ever loaded)
+      pr.num_words = A.lm[ii].num_words;
+      if (LM) { pr.lm_score = A.lm[ii].lm_score; pr.lm_before = A.lm[ii].lm_before; pr.num_oov = A.lm[ii].num_oov; pr.num_oov_before = A.lm[ii].num_oov_before; }
+      for (int ci = part; ci < V; ci += P) {
+        const double curp = srow[ci];
+        unsigned long long* const slot = ukey + n + ci * n + ii;
+        if (ci == blank) { *slot = kNoCandKey; A.npb[ii] = curp + full; continue; }   // :374-376 (prob_blank was -inf)
+        const double val = curp + (ci == last ? ppb : full);                     // :383-385 / :389-391
+        const int k = ctab[ii * V + ci];
+        unsigned long long uk = kNoCandKey;
+        if (k >= 0) {
+          const int j = mapA.find(k);
+          if (j >= 0) A.inc[j] = val;            // the child is a beam member: its share from this parent
+          // else: alive but pruned (Q7) -- the probability is lost and the slot stays taken
+        } else {
+          LmFields nl;
+          LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
+          if (LM) ans = lmcA[ii * V + ci];
+          child_score_fields<LM>(p, pr, last, ci, ans, nl);
+          const double sc = beam_score<LM>(p, val, ninf(), nl);                  // after next_step: prev_pnb = val, prev_pb = -inf
+          uk = okey(sc);
+          key_hi = max(key_hi, (unsigned)(uk >> 32));
+          my_new++;
+        }
         *slot = uk;
-        key_hi = max(key_hi, (unsigned)(uk >> 32));
-        my_new++;
       }
     }
     {
@@ -846,10 +853,8 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         for (int jj = 0; jj < kPer; jj++) { cnt[jj] = hcur[top - jj]; mine += cnt[jj]; }
         const int inc = wave_scan_i(mine);
         if (lane == 63) s_part[wid] = inc;
-        if (pass > 0) {
 #pragma unroll
-          for (int jj = 0; jj < kPer; jj++) hnext[top - jj] = 0;
-        }
+        for (int jj = 0; jj < kPer; jj++) hnext[top - jj] = 0;    // (at pass 0 this is the region that held the previous step's sel)
         lds_barrier();
         int above = inc - mine;                       // candidates with a larger digit than this thread's first
         {
@@ -945,10 +950,14 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     } else {
       // nothing is pruned (the first steps of an utterance): old members, then the pairs that exist, in order
       for (int j = tid; j < n; j += kThreads) sel[j] = j;
-      const int incl = wave_scan_i(my_new);
+      const int chunk = (npairs + kThreads - 1) / kThreads;
+      const int q0 = min(tid * chunk, npairs), q1 = min(q0 + chunk, npairs);
+      int mine = 0;
+      for (int q = q0; q < q1; q++) mine += ukey[n + q] != kNoCandKey;
+      const int incl = wave_scan_i(mine);
       if (lane == 63) s_part[wid] = incl;
       lds_barrier();
-      int pos = n + incl - my_new;
+      int pos = n + incl - mine;
       for (int w = 0; w < wid; w++) pos += s_part[w];
       for (int q = q0; q < q1; q++)
         if (ukey[n + q] != kNoCandKey) sel[pos++] = n + q;
