@@ -58,3 +58,26 @@ def test_time_major_view_and_full_c3_properties():
     xt = x[:8].permute(1, 0, 2).contiguous().permute(1, 0, 2)
     o2, l2 = U.c_abi_greedy(xt, xl[:8], 0)
     assert np.array_equal(o2, out[:8]) and np.array_equal(l2, lens[:8])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_streaming_kernel_corner_cases(dtype):
+    """Contiguous small-alphabet input takes the streaming kernel (64-frame chunks per wave, 1024-frame super-tiles): several
+    super-tiles with the collapse carried across them, NaN / inf rows (torch.argmax: first NaN wins, else first maximum),
+    utterances that end inside a chunk -- and the same data through an unaligned view, which takes the tiled kernel."""
+    g = torch.Generator().manual_seed(99)
+    B, T, V = 3, 5000, 29
+    x = (torch.randn(B, T, V, generator=g, dtype=torch.float64) * 2).to(dtype)
+    x[0, 5::97, 7] = float("nan"); x[0, 5::97, 3] = float("nan")       # two NaNs in a row: the first one wins
+    x[1, ::211] = float("-inf"); x[1, ::211, 11] = float("inf")
+    x[2, 1000:1100] = 0.0                                                # a long run of exact ties (symbol 0)
+    xl = torch.tensor([T, 4097, 1025])
+    for blank in (0, 7):
+        out, lens = U.c_abi_greedy(x, xl, blank)
+        o_out, o_len = O.ctc_greedy(x.double().numpy(), xl.numpy(), blank)
+        assert np.array_equal(lens, o_len) and np.array_equal(out, o_out)
+        # unaligned: drop the first column of a wider tensor (row stride 30, element offset 1)
+        wide = torch.zeros(B, T, V + 1, dtype=dtype)
+        wide[:, :, 1:] = x
+        o2, l2 = U.c_abi_greedy(wide[:, :, 1:], xl, blank)
+        assert np.array_equal(l2, o_len) and np.array_equal(o2, o_out)
