@@ -269,6 +269,35 @@ def test_wide_alphabet_edge_cases(algo, logprobs):
     U.assert_same(grads, g_o, F32_RTOL, 1e-6, "grads")
 
 
+@pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS.get)
+@pytest.mark.parametrize("logprobs", [False, True])
+@pytest.mark.parametrize("V", [204, 2052, 4100])
+def test_wide_alphabet_edge_cases_single_read(algo, logprobs, V):
+    # contiguous rows of a multiple of 4 columns take the single-read form (the row is held in a wave's registers:
+    # 8 / 16 / 32 float4 per lane for these widths, the last group partial); same corner cases as above -- ragged
+    # lengths (padded frames: exp(lp) in log-prob mode, 0 for fused logits), repeats, an empty target, an infeasible
+    # utterance whose slab is poisoned after the lattice, blank in the middle of the alphabet
+    g = torch.Generator().manual_seed(78 + V)
+    B, T, S = 5, 40, 12
+    x = torch.randn(B, T, V, generator=g) * 2
+    if logprobs:
+        x = torch.log_softmax(x, -1)
+    tg = torch.randint(0, V - 1, (B, S), generator=g)
+    tg[tg == 100] = 101                                              # blank id 100 must not appear
+    tg[1, 3] = tg[1, 4] = tg[1, 5]                                   # repeats
+    xl = torch.tensor([40, 31, 40, 9, 22])
+    tl = torch.tensor([12, 7, 0, 12, 5])                             # utterance 3: T=9 < S=12 -> infeasible
+    lp = (x if logprobs else torch.log_softmax(x.double(), -1)).double().numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 100)
+    if not logprobs:
+        for b in range(B):
+            if np.isfinite(l_o[b]):
+                g_o[b, xl[b]:] = 0.0
+    losses, grads = run(x, tg, xl, tl, 100, logprobs, algo, l_o)
+    U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads, g_o, F32_RTOL, 1e-6, "grads")
+
+
 def test_full_c5_shape_properties():
     # one GPU's share of BASELINE configs[4]: B=512, T=256, V=8000, S<=64 (4.2 GB of logits)
     g = torch.Generator().manual_seed(5)
