@@ -734,10 +734,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     double next_lp = 0.0;
     if (tid < V && t + 1 < T) next_lp = (double)lp[(int64_t)(t + 1) * p.sT + (int64_t)tid * p.sV];
     for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; }    // (A.full: set when the member was placed)
-    for (int h = tid; h < p.HS; h += kThreads) mapB.key[h] = -1;
-    for (int e = tid; e < W * V; e += kThreads) ctabB[e] = -1;
-    for (int h = tid; h < kSelBins; h += kThreads) hist[h] = 0;            // (the second histogram is cleared by the pass before it)
     if (tid == 0) { s_hi = 0u; s_lo = 0xffffffffu; s_total_new = 0; s_nnew = 0; }
+    // (the next beam's slot map and child tables and the selection's first histogram are cleared during the members
+    // phase below, by the waves that have no member to update)
     lds_barrier();
     BPROF(0);
     // pairs: candidate q = c*n + i is the reference's order (character outer, prefix inner, :370-395).  The threads are
@@ -808,6 +807,17 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       key_hi = (unsigned)wave_max_i((int)(key_hi ^ 0x80000000u)) ^ 0x80000000u;
       key_lo = ~((unsigned)wave_max_i((int)((~key_lo) ^ 0x80000000u)) ^ 0x80000000u);
       if (lane == 0) { atomicMax(&s_hi, key_hi); atomicMin(&s_lo, key_lo); }
+    }
+    {
+      // housekeeping for the phases that follow, by the waves without members (all waves if every wave has some): the
+      // member update above is two dependent f64 log-sum-exps on two waves, the other fourteen would only wait
+      const int mw = (n + 63) >> 6, nw = kThreads / 64;
+      const int ctid = mw < nw ? tid - 64 * mw : tid, cstride = 64 * (mw < nw ? nw - mw : nw);
+      if (ctid >= 0) {
+        for (int h = ctid; h < p.HS; h += cstride) mapB.key[h] = -1;
+        for (int e = ctid; e < W * V; e += cstride) ctabB[e] = -1;
+        for (int h = ctid; h < kSelBins; h += cstride) hist[h] = 0;      // (the second histogram is cleared by the pass before it)
+      }
     }
     lds_barrier();
     BPROF(2);
