@@ -674,8 +674,11 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
   unsigned char* const lab_bytes = q8; if (LM) q8 += kLabelLdsBytes;
   LabelTab lt; lt.off = p.lm.label_off; lt.bytes = p.lm.label_bytes;
   auto slot_map = [&](int set) { SlotMap m; m.key = sm0 + set * 2 * p.HS; m.val = m.key + p.HS; m.mask = p.HS - 1; return m; };
-  __shared__ int s_next_node, s_err, s_krem, s_done, s_bin, s_total_new, s_nnew;
-  __shared__ unsigned s_hi, s_lo;
+  __shared__ int s_next_node, s_err, s_krem, s_done, s_bin;
+  // per-step accumulators, double-buffered by step parity: a step resets the NEXT step's set while nobody uses it, so
+  // that no barrier is needed between the end of one step and the pair loop of the next
+  __shared__ int s_total_new2[2], s_nnew2[2];
+  __shared__ unsigned s_hi2[2], s_lo2[2];
   __shared__ unsigned long long s_prefix;
 
   BeamNode* nodes = p.nodes + (size_t)b * p.NCAP;
@@ -697,13 +700,14 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
   }
   if (tid == 0) {
     s_next_node = 1; s_err = 0;                                                     // node 0 is taken
+    s_hi2[0] = 0u; s_lo2[0] = 0xffffffffu; s_total_new2[0] = 0; s_nnew2[0] = 0;
     BeamNode& r = nodes[0];
     r.parent = -1; r.last_char = -1;
     LmFields l;
     l.lm_score = 0.0; l.lm_before = 0.0; l.num_words = 0; l.num_oov = 0; l.num_oov_before = 0; l.word_len = 0;
     l.word_hash = kFnvInit; l.st_n = 0; l.stb_n = 0;
     if (p.has_lm) { l.st[0] = p.lm.bos; l.st_n = 1; l.stb[0] = p.lm.bos; l.stb_n = 1; }
-    M0.ppb[0] = 0.0; M0.ppnb[0] = ninf(); M0.full[0] = lse2(ninf(), 0.0); M0.node[0] = 0; M0.last[0] = -1; M0.gown[0] = -1; M0.gchar[0] = 0; M0.gnode[0] = 0;
+    M0.ppb[0] = 0.0; M0.ppnb[0] = ninf(); M0.full[0] = lse2(ninf(), 0.0); M0.inc[0] = ninf(); M0.kept[0] = 0; M0.node[0] = 0; M0.last[0] = -1; M0.gown[0] = -1; M0.gchar[0] = 0; M0.gnode[0] = 0;
     M0.lm[0] = l;
   }
   __syncthreads();
@@ -733,12 +737,12 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     // step's start
     double next_lp = 0.0;
     if (tid < V && t + 1 < T) next_lp = (double)lp[(int64_t)(t + 1) * p.sT + (int64_t)tid * p.sV];
-    for (int i = tid; i < n; i += kThreads) { A.inc[i] = ninf(); A.kept[i] = 0; }    // (A.full: set when the member was placed)
-    if (tid == 0) { s_hi = 0u; s_lo = 0xffffffffu; s_total_new = 0; s_nnew = 0; }
-    // (the next beam's slot map and child tables and the selection's first histogram are cleared during the members
-    // phase below, by the waves that have no member to update)
-    lds_barrier();
-    BPROF(0);
+    // (no barrier here: a member's inc / kept / full were set when it was placed, this step's accumulators were reset
+    // during the previous step, and the next beam's slot map, child tables and the selection's first histogram are
+    // cleared during the members phase below)
+    const int ps = t & 1;
+    unsigned& s_hi = s_hi2[ps]; unsigned& s_lo = s_lo2[ps];
+    int& s_total_new = s_total_new2[ps]; int& s_nnew = s_nnew2[ps];
     // pairs: candidate q = c*n + i is the reference's order (character outer, prefix inner, :370-395).  The threads are
     // laid out member-major -- P threads per member, each taking every P-th character -- so that what a pair needs of
     // its member (probabilities, last character, word count, LM state) is read once per thread, not once per pair.
@@ -813,6 +817,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       // member update above is two dependent f64 log-sum-exps on two waves, the other fourteen would only wait
       const int mw = (n + 63) >> 6, nw = kThreads / 64;
       const int ctid = mw < nw ? tid - 64 * mw : tid, cstride = 64 * (mw < nw ? nw - mw : nw);
+      if (ctid == 0) { s_hi2[ps ^ 1] = 0u; s_lo2[ps ^ 1] = 0xffffffffu; s_total_new2[ps ^ 1] = 0; s_nnew2[ps ^ 1] = 0; }
       if (ctid >= 0) {
         for (int h = ctid; h < p.HS; h += cstride) mapB.key[h] = -1;
         for (int e = ctid; e < W * V; e += cstride) ctabB[e] = -1;
@@ -825,7 +830,45 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     const int nreal = n + total_new;                // candidates that exist
     const int ntot = n + npairs;                    // entries of key[]
     const int nsel = nreal > W ? W : nreal;
-    int* const sel = hist + kSelBins;               // the selected candidates in beam order (valid after the block below)
+    int* const sel = hist + kSelBins;               // (no pruning only) the candidates in beam order
+    // (LM: scratch of the answer phase, in regions that are dead by then -- the first histogram, the gathered candidates,
+    // the candidate keys)
+    int* const newlist = sidx;                                                        // new members that have to ask
+    int* const ldr = reinterpret_cast<int*>(skey);                                    // leader of member j
+    unsigned long long* const sg = reinterpret_cast<unsigned long long*>(key);        // state signature of member j
+    constexpr int kStateSlots = 512;                                                  // (>= 2 * 200 members at the widest beam that fits)
+    unsigned long long* const tsig = reinterpret_cast<unsigned long long*>(hist);     // open addressing: signature -> smallest rank
+    int* const tval = hist + 2 * kStateSlots;
+    // candidate d takes place j of the new beam (the other member set): a member that stays is copied, a pair becomes a
+    // prefix -- node, LM state, its own guard.  Called by the thread that has just worked out the candidate's rank.
+    auto place = [&](int j, int d) {
+      if (d < n) {
+        const int i = d;
+        A.kept[i] = 1; A.newpos[i] = j; Bm.from[j] = i;
+        Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i]; Bm.full[j] = A.nfull[i];
+        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; copy_lm<LM>(Bm.lm[j], A.lm[i]);
+        Bm.gown[j] = A.gown[i]; Bm.gchar[j] = A.gchar[i]; Bm.gnode[j] = A.gnode[i];     // (owner: position in A, for now)
+        mapB.insert(A.node[i], j);
+      } else {
+        const int q = d - n;
+        const int c = q / n, i = q - c * n;
+        const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : A.full[i]);
+        LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
+        if (LM) ans = lmcA[i * V + c];
+        child_lm<LM>(p, lt, A.lm[i], A.last[i], c, ans, Bm.lm[j]);                 // (straight into LDS: a local LmFields lives in scratch)
+        int k = atomicAdd(&s_next_node, 1);                                       // make_shared<Prefix>, :254
+        if (k >= p.NCAP) { s_err = 1; k = 0; }
+        else {
+          BeamNode nn;
+          nn.parent = A.node[i]; nn.last_char = c;
+          nodes[k] = nn;                                                          // (fire and forget)
+          mapB.insert(k, j);
+        }
+        Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.full[j] = lse2(val, ninf()); Bm.node[j] = k; Bm.last[j] = c;
+        Bm.gown[j] = i; Bm.gchar[j] = c; Bm.gnode[j] = k;                         // its own guard, if its parent stays
+        Bm.from[j] = -1;
+      }
+    };
     if (nreal > W) {                                                             // :405-415
       // ---- radix select of the W-th largest score on the order-preserving 64-bit key, 11 bits per pass ----
       // Where to start: the threshold lies between the smallest score of a full beam's old members (W candidates are
@@ -938,6 +981,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       BPROF(8);
       // ---- rank the gathered candidates by (score desc, position asc): eight lanes count for one candidate; rank < W
       //      is the candidate's place in the new beam (the surplus of a small threshold bin falls off the end) ----
+      if (LM) for (int h = tid; h < kStateSlots; h += kThreads) { tsig[h] = 0ULL; tval[h] = 0x7fffffff; }
       for (int e0 = 0; e0 < M; e0 += kThreads / 8) {
         const int e = e0 + (tid >> 3), part = tid & 7;
         int cnt = 0;
@@ -954,9 +998,8 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
         cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
         cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror: the other quad of the 8
-        if (e < M && part == 0 && cnt < W) sel[cnt] = sidx[e];
+        if (e < M && part == 0 && cnt < W) place(cnt, sidx[e]);     // (no list of the selected in between: the ranking thread builds the member)
       }
-      lds_barrier();
     } else {
       // nothing is pruned (the first steps of an utterance): old members, then the pairs that exist, in order
       for (int j = tid; j < n; j += kThreads) sel[j] = j;
@@ -971,56 +1014,19 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       for (int w = 0; w < wid; w++) pos += s_part[w];
       for (int q = q0; q < q1; q++)
         if (ukey[n + q] != kNoCandKey) sel[pos++] = n + q;
+      if (LM) for (int h = tid; h < kStateSlots; h += kThreads) { tsig[h] = 0ULL; tval[h] = 0x7fffffff; }
       lds_barrier();
-    }
-    BPROF(3);
-    // ---- rebuild the beam in the other member set ----
-    // (LM: scratch of the answer phase below, in regions that are dead by now -- the first histogram, the gathered
-    // candidates, the candidate keys)
-    int* const newlist = sidx;                                                        // new members that have to ask
-    int* const ldr = reinterpret_cast<int*>(skey);                                    // leader of member j
-    unsigned long long* const sg = reinterpret_cast<unsigned long long*>(key);        // state signature of member j
-    constexpr int kStateSlots = 512;                                                  // (>= 2 * 200 members at the widest beam that fits)
-    unsigned long long* const tsig = reinterpret_cast<unsigned long long*>(hist);     // open addressing: signature -> smallest rank
-    int* const tval = hist + 2 * kStateSlots;
-    if (LM) for (int h = tid; h < kStateSlots; h += kThreads) { tsig[h] = 0ULL; tval[h] = 0x7fffffff; }
-    for (int j = tid; j < nsel; j += kThreads) {
-      const int d = sel[j];
-      if (d < n) {
-        const int i = d;
-        A.kept[i] = 1; A.newpos[i] = j; Bm.from[j] = i;
-        Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i]; Bm.full[j] = A.nfull[i];
-        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; copy_lm<LM>(Bm.lm[j], A.lm[i]);
-        Bm.gown[j] = A.gown[i]; Bm.gchar[j] = A.gchar[i]; Bm.gnode[j] = A.gnode[i];     // (owner: position in A, for now)
-        mapB.insert(A.node[i], j);
-      } else {
-        const int q = d - n;
-        const int c = q / n, i = q - c * n;
-        const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : A.full[i]);
-        LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
-        if (LM) ans = lmcA[i * V + c];
-        child_lm<LM>(p, lt, A.lm[i], A.last[i], c, ans, Bm.lm[j]);                 // (straight into LDS: a local LmFields lives in scratch)
-        int k = atomicAdd(&s_next_node, 1);                                       // make_shared<Prefix>, :254
-        if (k >= p.NCAP) { s_err = 1; k = 0; }
-        else {
-          BeamNode nn;
-          nn.parent = A.node[i]; nn.last_char = c;
-          nodes[k] = nn;                                                          // (fire and forget)
-          mapB.insert(k, j);
-        }
-        Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.full[j] = lse2(val, ninf()); Bm.node[j] = k; Bm.last[j] = c;
-        Bm.gown[j] = i; Bm.gchar[j] = c; Bm.gnode[j] = k;                         // its own guard, if its parent stays
-        Bm.from[j] = -1;
-      }
+      for (int j = tid; j < nsel; j += kThreads) place(j, sel[j]);
     }
     lds_barrier();
-    BPROF(4);
+    BPROF(3);
     // ---- guards and child tables of the new beam ----
     // A guard whose owner left the beam is inherited from the owner's guard (the next alive prefix up the path whose
     // parent was a member), until an owner that stays is found or the path runs out.  Every alive child of a member is
     // some member's guard: writing the guards into the cleared tables reproduces exactly the entries whose weak_ptr has
     // not expired upstream.
     for (int j = tid; j < nsel; j += kThreads) {
+      Bm.inc[j] = ninf(); Bm.kept[j] = 0;                      // (what the next step's pair loop expects to find)
       int go = Bm.gown[j], gc = Bm.gchar[j], gn = Bm.gnode[j];
       while (go >= 0 && !A.kept[go]) { const int o = go; go = A.gown[o]; gc = A.gchar[o]; gn = A.gnode[o]; }
       if (go >= 0) {
@@ -1105,9 +1111,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         if (o != j2) lmcB[e] = lmcB[o * V + (e - j2 * V)];
       }
     }
+    if (tid < V) srow2[((t + 1) & 1) * V + tid] = next_lp;          // (the other half of the double buffer: nobody reads it this step)
     lds_barrier();
     BPROF(5);
-    if (tid < V) srow2[((t + 1) & 1) * V + tid] = next_lp;          // (read after the first barrier of the next step)
     n = nsel; cur ^= 1;
     if (s_err) break;
   }

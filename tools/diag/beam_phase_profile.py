@@ -21,7 +21,7 @@ eng.decode(x, xl); eng.decode(x, xl)
 buf = (C.c_ulonglong * 16)()
 L = _lib.load(); L.e2e_debug_beam_profile.argtypes = [C.c_void_p]
 assert L.e2e_debug_beam_profile(buf) == 0
-names = ["step start (clears)", "pairs", "members", "select: rank", "rebuild", "guards+tables / LM followers", "(unused)", "select: radix passes", "select: gather", "(unused)", "(passes)", "guards (LM kernel)", "LM state signatures", "LM leaders", "LM rows"]
+names = ["(unused)", "pairs", "members", "select: rank + place", "(unused)", "guards+tables / LM followers", "(unused)", "select: radix passes", "select: gather", "(unused)", "(passes)", "guards (LM kernel)", "LM state signatures", "LM leaders", "LM rows"]
 tot = sum(buf[k] for k in range(15) if k != 10)
 for k, nm in enumerate(names):
     if k != 10 and buf[k]: print("%-16s %8.0f cycles/step (%4.1f%%)" % (nm, buf[k] / T, 100.0 * buf[k] / tot))
