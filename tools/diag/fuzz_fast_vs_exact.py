@@ -62,7 +62,11 @@ for case in range(n_cases):
             if not np.isfinite(le[b]):
                 assert not np.isfinite(la[b]) or np.isnan(la[b]) or la[b] == le[b], (case, b)
                 continue
-            viol = (np.abs(ga[b].astype(np.float64) - ge[b].astype(np.float64)) - (2e-6 + 1e-4 * np.abs(ge[b].astype(np.float64)))).max()
+            # (f32 noise floor: a posterior row recomputed over 16 f32 steps carries a few 1e-6 relative error, which is
+            # an absolute error of that size where the posterior is ~1 -- logits of scale >= 8; the tests' 2e-6 holds up
+            # to scale 5)
+            atol = 2e-6 if sharp < 8 else 6e-6
+            viol = (np.abs(ga[b].astype(np.float64) - ge[b].astype(np.float64)) - (atol + 1e-4 * np.abs(ge[b].astype(np.float64)))).max()
             if viol > 0 or abs(float(la[b]) - float(le[b])) > 1e-4 * max(1.0, abs(float(le[b]))):
                 auto_bad += 1
                 print("AUTO case %d utt %d: beyond tolerance by %.2e, loss %.6g vs %.6g (fast path flagged: %s; B=%d T=%d V=%d S=%d sharp=%g fused=%d blank=%d xl=%d tl=%d)" % (
