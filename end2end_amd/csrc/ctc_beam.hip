@@ -325,6 +325,7 @@ constexpr int kThreadsNoLm = 1024, kThreadsLm = 1024;   // (with a language mode
 constexpr int kMaxCand = 8192;     // W*V + W candidates per step (LDS key array)
 constexpr int kLdsBudget = 158 * 1024;
 constexpr int kSelBits = 11, kSelBins = 1 << kSelBits;   // radix-select digit (two alternating histograms in LDS)
+constexpr int kStateSlots = 512;                       // LM state table of a step (open addressing, <= half full: checked by the host)
 constexpr int kSelSmall = 64;                           // a threshold bin this small is finished exactly by one wave
 
 // LM-related state of a prefix (Prefix::lm_*, num_*, last_word, ctc_decoder.h:79-86)
@@ -836,7 +837,6 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     int* const newlist = sidx;                                                        // new members that have to ask
     int* const ldr = reinterpret_cast<int*>(skey);                                    // leader of member j
     unsigned long long* const sg = reinterpret_cast<unsigned long long*>(key);        // state signature of member j
-    constexpr int kStateSlots = 512;                                                  // (>= 2 * 200 members at the widest beam that fits)
     unsigned long long* const tsig = reinterpret_cast<unsigned long long*>(hist);     // open addressing: signature -> smallest rank
     int* const tval = hist + 2 * kStateSlots;
     // candidate d takes place j of the new beam (the other member set): a member that stays is copied, a pair becomes a
@@ -1184,6 +1184,10 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   if (B > 0 && (!lp || !x_len || !out || !out_len)) { set_error("null pointer argument"); return E2E_ERR_ARG; }
   if (lm && !lm->d_ng) { set_error("the language model has no device tables (it was loaded without a GPU)"); return E2E_ERR_HIP; }
   const BeamLayout l = beam_layout(B, T, V, beam_width, lm != nullptr);
+  if (lm && 2 * beam_width > kStateSlots) {
+    set_error("beam_width = %d with a language model: at most %d", beam_width, kStateSlots / 2);
+    return E2E_ERR_UNSUPPORTED;
+  }
   if (l.CMAX > kMaxCand || l.lds > (size_t)kLdsBudget || beam_width > kSelBins) {
     set_error("beam_width*alphabet = %d candidates per step (%zu B of LDS) exceed what one workgroup holds (%d, %d B)",
               l.CMAX, l.lds, kMaxCand, kLdsBudget);
