@@ -242,7 +242,10 @@ int launch_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV, 
   {
     // contiguous 16-byte aligned rows of a small alphabet: the streaming kernel
     const size_t lds_stream = (size_t)kStreamWaves * kChunk * (V | 1) * esz + 2 * kSuper;
-    const bool aligned = reinterpret_cast<uintptr_t>(x) % 16 == 0 && (sB * (int64_t)esz) % 16 == 0;
+    // (every utterance's slab of T*V elements starts on a 16-byte boundary and is a whole number of 16-byte pieces: the
+    // kernel's clamped piece loads then never leave the slab)
+    const bool aligned = reinterpret_cast<uintptr_t>(x) % 16 == 0 && (sB * (int64_t)esz) % 16 == 0 &&
+                         ((int64_t)T * V * (int64_t)esz) % 16 == 0;
     if (sV == 1 && sT == V && aligned && V >= 1 && (size_t)V * esz <= 16 * kMaxPf && lds_stream <= 60 * 1024) {
       const int npf = (int)((64 * (size_t)V * esz + 1023) / 1024);
       if (dtype == E2E_F32) {
