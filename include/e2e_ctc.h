@@ -126,6 +126,10 @@ double e2e_lm_score(const e2e_lm* lm, const uint32_t* ctx /* host */, int ctx_le
  *   out       (B,max_out) int64, zero-filled; out_len (B) int64.  When the
  *             empty prefix wins the result is the single id -1 (quirk Q6).
  *   workspace >= e2e_ctc_beam_workspace_bytes(...)
+ * Limits (E2E_ERR_UNSUPPORTED beyond them; the reference has none): one workgroup holds an
+ * utterance's beam in LDS -- beam_width*V + beam_width <= 8184 candidates per step,
+ * beam_width <= 2048, and <= 256 with a language model (whose per-member state and answers
+ * also live there: e.g. beam 100 at V = 29 with an LM of any order up to 6).
  */
 size_t e2e_ctc_beam_workspace_bytes(int B, int T, int V, int beam_width);
 
