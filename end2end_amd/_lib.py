@@ -1,7 +1,9 @@
-"""ctypes binding of libe2e_ctc.so (the C ABI in include/e2e_ctc.h).
+"""ctypes view of libe2e_ctc.so: the raw C ABI of include/e2e_ctc.h, symbol by symbol.
 
-There is no CPU fallback: if the HIP library is missing or no MI355X is visible
-the product raises.  Nothing here touches oracle/.
+This is what the parity tests (tests/gpu_util.py), bench.py's C-ABI leg and tools/diag call, so that what they
+exercise is the boundary itself -- plain pointers and sizes, return codes, e2e_last_error().  The product's engines
+(end2end_amd/engines.py) reach the same entry points through the pybind11 layer end2end_amd._C instead.
+There is no CPU fallback.  Nothing here touches oracle/.
 """
 import ctypes as C
 import os
@@ -14,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libe2e_ctc.so")
 
 F32, F64 = 0, 1
 ALGO_AUTO, ALGO_EXACT, ALGO_FAST = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 _lock = threading.Lock()
@@ -56,6 +58,8 @@ def load():
         L.e2e_lm_free.argtypes = [vp]
         L.e2e_lm_order.restype = C.c_int
         L.e2e_lm_order.argtypes = [vp]
+        L.e2e_lm_device.restype = C.c_int
+        L.e2e_lm_device.argtypes = [vp]
         L.e2e_lm_word_index.restype = C.c_uint32
         L.e2e_lm_word_index.argtypes = [vp, C.c_char_p]
         L.e2e_lm_score.restype = C.c_double
@@ -66,8 +70,6 @@ def load():
         L.e2e_ctc_beam.argtypes = [vp, C.c_int, i64, i64, i64, i64p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_double,
                                    i64p, i64, i64p, vp, C.c_size_t, vp]
-        L.e2e_ctc_beam_status.restype = C.c_int
-        L.e2e_ctc_beam_status.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         if L.e2e_ctc_abi_version() != ABI_VERSION:
             raise ImportError("end2end_amd: %s has ABI %d, expected %d" % (LIB_PATH, L.e2e_ctc_abi_version(), ABI_VERSION))
         _lib = L
@@ -85,33 +87,12 @@ def require_gpu():
                            "there is no CPU fallback in this package")
 
 
-def compute_device(t):
-    """Device the kernels run on for tensor t: its own if it is on a GPU, else the current GPU."""
-    if t.is_cuda:
-        return t.device
-    require_gpu()
-    return torch.device("cuda", torch.cuda.current_device())
-
-
 def dtype_code(dt):
     if dt == torch.float32:
         return F32
     if dt == torch.float64:
         return F64
     raise TypeError("unsupported dtype %s" % dt)
-
-
-_workspaces = {}
-
-
-def workspace(device, nbytes):
-    """A cached per-(device, stream) scratch buffer of at least nbytes (grown geometrically)."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _workspaces.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _workspaces[key] = buf
-    return buf
 
 
 def stream_ptr(device):

@@ -95,20 +95,24 @@ __host__ __device__ inline const NgSlot* lm_ngram_find(const LmView& lm, const u
   }
 }
 
-// log10 p(word | ctx) with ARPA back-off; ctx is most-recent-first.  Float accumulation like KenLM.
+// log10 p(word | ctx) with ARPA back-off; ctx is most-recent-first.  Float accumulation in KenLM's order: the prob of
+// the longest listed n-gram, then the back-off weights of the longer contexts, shortest context first.
 __host__ __device__ inline float lm_base_score(const LmView& lm, const uint32_t* ctx, int ctx_len, uint32_t word,
                                                uint32_t* out_ctx, int* out_len) {
   int n = ctx_len; if (n > lm.order - 1) n = lm.order - 1;
   uint32_t ids[kLmMaxOrder];
-  float acc = 0.f, result = 0.f; bool found = false;
-  for (int k = n; k >= 0 && !found; k--) {
+  float bo[kLmMaxOrder + 1];
+  float result = 0.f; int found_k = -1;
+  for (int k = n; k >= 0; k--) {
     for (int i = 0; i < k; i++) ids[i] = ctx[k - 1 - i];
     ids[k] = word;
     const NgSlot* s = lm_ngram_find(lm, ids, k + 1);
-    if (s) { result = acc + s->prob; found = true; break; }
-    if (k > 0) { const NgSlot* c = lm_ngram_find(lm, ids, k); if (c) acc += c->backoff; }
+    if (s) { result = s->prob; found_k = k; break; }
+    bo[k] = 0.f;
+    if (k > 0) { const NgSlot* c = lm_ngram_find(lm, ids, k); if (c) bo[k] = c->backoff; }
   }
-  if (!found) { const uint32_t z = 0; const NgSlot* u = lm_ngram_find(lm, &z, 1); result = acc + (u ? u->prob : -100.f); }
+  if (found_k < 0) { const uint32_t z = 0; const NgSlot* u = lm_ngram_find(lm, &z, 1); result = u ? u->prob : -100.f; found_k = 0; }
+  for (int k = found_k + 1; k <= n; k++) result += bo[k];
   if (out_ctx) {
     int m = n + 1; if (m > lm.order - 1) m = lm.order - 1;
     uint32_t tmp[kLmMaxOrder];
@@ -138,6 +142,7 @@ struct e2e_lm {
   unsigned char* d_label_bytes = nullptr; int* d_label_off = nullptr;
   e2e::NgSig* d_ngs = nullptr; e2e::VEntry* d_vt = nullptr;     // (d_ngs stays null if two n-grams share a hash)
   float unk_prob = -100.f;
+  int device = -1;                                       // HIP device that holds the tables (-1: host only)
   e2e::LmView host_view() const {
     return {order, vkeys.data(), vvals.data(), (uint32_t)vkeys.size() - 1, ng.data(), (uint32_t)ng.size() - 1, bos,
             label_bytes.data(), label_off.data(), fold_case, nullptr, nullptr, unk_prob};
@@ -289,6 +294,8 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
     (void)hipFree(lm->d_label_bytes); (void)hipFree(lm->d_label_off); (void)hipFree(lm->d_ngs); (void)hipFree(lm->d_vt);
     lm->d_vkeys = nullptr; lm->d_vvals = nullptr; lm->d_ng = nullptr; lm->d_label_bytes = nullptr; lm->d_label_off = nullptr;
     lm->d_ngs = nullptr; lm->d_vt = nullptr;
+  } else if (hipGetDevice(&lm->device) != hipSuccess) {
+    lm->device = -1;
   }
   *out = lm;
   return E2E_OK;
@@ -302,6 +309,7 @@ extern "C" void e2e_lm_free(e2e_lm* lm) {
 }
 
 extern "C" int e2e_lm_order(const e2e_lm* lm) { return lm ? lm->order : 0; }
+extern "C" int e2e_lm_device(const e2e_lm* lm) { return lm ? lm->device : -1; }
 
 // get_idx(string), ctc_decoder.cpp:77-82: exact lookup when case sensitive, else lower-cased lookup
 extern "C" uint32_t e2e_lm_word_index(const e2e_lm* lm, const char* word) {
@@ -351,7 +359,7 @@ struct BeamParams {
   int B, T, V, blank, W, space_id;
   int has_lm; LmView lm; double lmwt, wip, oov;
   int64_t* out; int64_t max_out; int64_t* out_len;
-  BeamNode* nodes; int* status;                       // per-utterance workspace
+  BeamNode* nodes;                                    // per-utterance workspace
   int NCAP, CMAX, WP2, HS;
 };
 
@@ -459,16 +467,15 @@ __device__ __forceinline__ float lm_score_parallel(const LmView& lm, const uint3
       }
     }
   }
-  float acc = 0.f, result = 0.f;
-  bool found = false;
+  // longest listed n-gram, then the back-off weights of the longer contexts, shortest first (KenLM's float order)
+  int found_k = 0;
+  float result = lm.unk_prob;
 #pragma unroll
-  for (int k = kParCtx; k >= 0; k--) {
-    if (k <= n && !found) {
-      if (hit >> k & 1u) { result = acc + e[k].prob; found = true; }
-      else if (k > 0 && (hit >> (kParCtx + k) & 1u)) acc += e[kParCtx + k].backoff;
-    }
-  }
-  if (!found) result = acc + lm.unk_prob;
+  for (int k = 0; k <= kParCtx; k++)
+    if (k <= n && (hit >> k & 1u)) { result = e[k].prob; found_k = k; }
+#pragma unroll
+  for (int k = 1; k <= kParCtx; k++)
+    if (k > found_k && k <= n && (hit >> (kParCtx + k) & 1u)) result += e[kParCtx + k].backoff;
   return result;
 }
 // FAST: the model has signature tables and at most kParCtx words of context (checked by the host): only the round-probed
@@ -1140,14 +1147,13 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     int64_t at = m;
     for (int k = best; k >= 0; k = nodes[k].parent)
       if (k == best || nodes[k].parent >= 0) { at--; if (at < p.max_out) out[at] = nodes[k].last_char; }
-    p.out_len[b] = m;
-    int st = s_err;
-    if (m > p.max_out) st = 3;
-    p.status[b] = st;
+    // in-band status (include/e2e_ctc.h): a length above max_out says "truncated, m were needed"; -1 = node pool
+    // exhausted (the sentence is then that of the last completed step and must not be used)
+    p.out_len[b] = s_err ? (int64_t)-1 : m;
   }
 }
 
-struct BeamLayout { size_t nodes, status, total, lds; int NCAP, CMAX, WP2, HS; };
+struct BeamLayout { size_t nodes, total, lds; int NCAP, CMAX, WP2, HS; };
 
 BeamLayout beam_layout(int B, int T, int V, int W, bool lm = false) {
   BeamLayout l;
@@ -1159,7 +1165,6 @@ BeamLayout beam_layout(int B, int T, int V, int W, bool lm = false) {
   l.lds = BeamLds::bytes(W, V, l.CMAX, l.WP2, l.HS, lm);
   size_t o = 0;
   l.nodes = o; o += align_up((size_t)B * l.NCAP * sizeof(BeamNode), 256);
-  l.status = o; o += align_up((size_t)B * sizeof(int), 256);
   l.total = o;
   return l;
 }
@@ -1183,6 +1188,21 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   if (blank < 0 || blank >= V) { set_error("blank=%d outside [0,%d)", blank, V); return E2E_ERR_ARG; }
   if (B > 0 && (!lp || !x_len || !out || !out_len)) { set_error("null pointer argument"); return E2E_ERR_ARG; }
   if (lm && !lm->d_ng) { set_error("the language model has no device tables (it was loaded without a GPU)"); return E2E_ERR_HIP; }
+  if (lm) {
+    int cur = -1;
+    E2E_HIP_CHECK(hipGetDevice(&cur), "hipGetDevice");
+    if (cur != lm->device) {
+      set_error("the language model's tables are on device %d but the call runs on device %d: load it once per device",
+                lm->device, cur);
+      return E2E_ERR_ARG;
+    }
+    // the kernel spells words with label_off[0..V]: the model must have been loaded with exactly this alphabet
+    if ((int)lm->label_off.size() - 1 != V) {
+      set_error("the language model was loaded with %d labels but the log-probabilities have %d columns",
+                (int)lm->label_off.size() - 1, V);
+      return E2E_ERR_ARG;
+    }
+  }
   const BeamLayout l = beam_layout(B, T, V, beam_width, lm != nullptr);
   if (lm && 2 * beam_width > kStateSlots) {
     set_error("beam_width = %d with a language model: at most %d", beam_width, kStateSlots / 2);
@@ -1207,7 +1227,6 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   p.wip = wip; p.oov = oov_penalty;
   p.out = out; p.max_out = max_out; p.out_len = out_len;
   p.nodes = reinterpret_cast<BeamNode*>(ws + l.nodes);
-  p.status = reinterpret_cast<int*>(ws + l.status);
   p.NCAP = l.NCAP; p.CMAX = l.CMAX; p.WP2 = l.WP2; p.HS = l.HS;
   hipStream_t s = (hipStream_t)stream;
   const bool fast_lm = lm && lm->d_ngs && lm->order - 1 <= kParCtx;
@@ -1223,18 +1242,6 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   void* args[] = { &p };
   E2E_HIP_CHECK(hipLaunchKernel(fn, dim3(B), dim3(nthreads), args, l.lds, s), "ctc_beam_kernel launch");
   E2E_HIP_CHECK(hipGetLastError(), "ctc_beam_kernel launch");
-  return E2E_OK;
-}
-
-// pool-exhaustion / truncation report of the last call that used `workspace` (synchronises): 0 = ok
-extern "C" int e2e_ctc_beam_status(const void* workspace, int B, int T, int V, int beam_width) {
-  const BeamLayout l = beam_layout(B, T, V, beam_width);
-  uintptr_t base = reinterpret_cast<uintptr_t>(workspace);
-  const char* ws = reinterpret_cast<const char*>((base + 255) & ~(uintptr_t)255);
-  std::vector<int> st((size_t)B);
-  if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
-  if (B && hipMemcpy(st.data(), ws + l.status, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost) != hipSuccess) return E2E_ERR_HIP;
-  for (int v : st) if (v) { set_error("beam search: utterance status %d (1 node pool, 3 output truncated)", v); return E2E_ERR_UNSUPPORTED; }
   return E2E_OK;
 }
 

@@ -284,11 +284,26 @@ __device__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, 
   const int T = (int)Tq, S = (int)Sq, L = 2 * S + 1;
 
   // ---- P0: extended targets (ctc_loss.cpp:25-31), label order, row lse ----
-  for (int j = tid; j < L; j += kThreads)
-    ext[j] = (j & 1) ? (int)p.targets[(int64_t)b * p.tgt_stride + (j >> 1)] : blank;
+  int bad_label = 0;
+  for (int j = tid; j < L; j += kThreads) {
+    int64_t lab = blank;
+    if (j & 1) {
+      lab = p.targets[(int64_t)b * p.tgt_stride + (j >> 1)];
+      bad_label |= (lab < 0) | (lab >= V);
+    }
+    ext[j] = (int)lab;
+  }
   for (int v = tid; v < V; v += kThreads) post[v] = 0.0;
   if (tid == 0) red[8] = 0.0;
-  __syncthreads();
+  if (__syncthreads_or(bad_label)) {
+    // a target outside [0,V) would index the row and the per-label sums out of bounds (the reference reads garbage
+    // there): poison like invalid lengths, do not crash
+    const double qnan = __builtin_nan("");
+    if (tid == 0) losses[b] = (IO)qnan;
+    for (size_t i = tid; i < (size_t)Tmax * V; i += kThreads) grads[i] = (IO)qnan;
+    __syncthreads();
+    return;
+  }
   // stable rank of target i among the S targets by label value (same-label cells keep increasing j,
   // so the per-label sums below run in the reference's order, ctc_loss.cpp:109-114)
   for (int i = tid; i < S; i += kThreads) {

@@ -1,6 +1,7 @@
 """CTCDecoder wrapper with the reference's constructor, defaults and return type
-(pytorch_end2end/decoders/ctc_decoder.py:25-149).  Tensors stay on the GPU instead of being
-copied to the host (`.cpu()` at :100,:137 upstream); results come back on the input's device.
+(pytorch_end2end/decoders/ctc_decoder.py:25-149).  The inputs stay on the GPU instead of being copied to
+the host (`.cpu()` at :100,:137 upstream); the results are CPU tensors as upstream unless
+``keep_on_device=True`` (an extension: ids and lengths then stay on the GPU that decoded them).
 """
 import os
 from collections import namedtuple
@@ -29,10 +30,11 @@ class CTCDecoder:
     :param wip: word insertion penalty
     :param oov_penalty: penalty per out-of-vocabulary word
     :param case_sensitive: look words up in the language model with their case
+    :param keep_on_device: (extension) leave the decoded ids and lengths on the GPU
     """
 
     def __init__(self, beam_width=100, after_logsoftmax=False, blank_idx=0, time_major=False, labels=None,
-                 lm_path=None, lmwt=1.0, wip=1.0, oov_penalty=-10, case_sensitive=True):
+                 lm_path=None, lmwt=1.0, wip=1.0, oov_penalty=-10, case_sensitive=True, keep_on_device=False):
         self._beam_width = beam_width
         self._blank_idx = blank_idx
         self._after_logsoftmax = after_logsoftmax
@@ -45,12 +47,14 @@ class CTCDecoder:
         self._case_sensitive = case_sensitive
         self._check_params()
         self._decoder = CTCDecoderEngine(self._blank_idx, self._beam_width, self._labels, self._lm_path,
-                                         self._lmwt, self._wip, self._oov_penalty, self._case_sensitive)
+                                         self._lmwt, self._wip, self._oov_penalty, self._case_sensitive,
+                                         keep_on_device=keep_on_device)
 
     def _check_params(self):
         if self._lm_path:
-            if not self._labels:
-                raise CTCDecoderError("To decode with language model you should pass labels")
+            # (upstream also tests `self._labels is None` here, which cannot hold after `labels or []`,
+            # pytorch_end2end/decoders/ctc_decoder.py:53,69: a model without labels is accepted at construction;
+            # decode() then fails because the alphabet cannot spell words)
             if not os.path.isfile(self._lm_path):
                 raise CTCDecoderError("Can't find a model: {}".format(self._lm_path))
 

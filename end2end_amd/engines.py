@@ -1,19 +1,23 @@
-"""Python mirrors of the reference's two pybind engines, backed by the HIP C ABI.
+"""The two engines of the reference's pybind modules, computed on the MI355X.
 
-CTCLossEngine  <-> cpp_ctc_loss.CTCLossEngine      (src/losses/ctc_loss_py.cpp:8-16)
-CTCDecoderEngine <-> cpp_ctc_decoder.CTCDecoder    (src/decoders/ctc_decoder_py.cpp:8-38)
+CTCLossEngine    <-> cpp_ctc_loss.CTCLossEngine     (src/losses/ctc_loss_py.cpp:8-16)
+CTCDecoderEngine <-> cpp_ctc_decoder.CTCDecoder     (src/decoders/ctc_decoder_py.cpp:8-38)
+
+Same constructor arguments, keyword names, defaults and results.  The top-level modules `cpp_ctc_loss` and
+`cpp_ctc_decoder` of this repository export them under the reference's names, so that the reference's own callers
+(`import_module("cpp_ctc_loss")`, pytorch_end2end/modules/ctc_loss.py:74; `import cpp_ctc_decoder`,
+pytorch_end2end/decoders/ctc_decoder.py:13) find them.
 
 Unlike the reference (which copies GPU tensors to the host and computes in C++ threads,
-src/losses/forward_backward.cpp:12-19), tensors stay on the GPU; CPU tensors are moved to
-the current GPU and the results moved back to the source device, mirroring the reference's
-"results on the source device and dtype" contract (forward_backward.cpp:55-56).
+src/losses/forward_backward.cpp:12-19) tensors stay on the GPU: the engines hand device addresses, strides and sizes
+to the C ABI (include/e2e_ctc.h) through the pybind11 layer `end2end_amd._C`.  CPU tensors are moved to the current GPU
+and the loss results moved back to the source device and dtype (forward_backward.cpp:55-56); decode results are CPU
+tensors as upstream (ctc_decoder.cpp:157,449) unless `keep_on_device` is set.
 """
-import ctypes as C
-import os
-
 import torch
 
-from . import _lib
+from . import _runtime as R
+from ._runtime import _C
 
 
 def _as_long(t, device):
@@ -25,20 +29,18 @@ def _as_long(t, device):
 class CTCLossEngine:
     """blank_idx -> .compute(logits, targets, logits_lengths, targets_lengths) -> (losses[B], grads[B,T,V])."""
 
-    def __init__(self, blank_idx, algo=_lib.ALGO_AUTO):
+    def __init__(self, blank_idx, algo=R.ALGO_AUTO):
         self.blank_idx = int(blank_idx)
         self.algo = algo
-        _lib.load()
 
     def compute(self, logits, targets, logits_lengths, targets_lengths, input_is_logprobs=True):
         """`logits` is batch-major (B,T,V) (any strides).  With input_is_logprobs=True this is the
         reference engine: log-probabilities in, grads = exp(lp) - posterior.  With False the
         log-softmax is fused in and grads are d loss / d logits."""
-        L = _lib.load()
         if logits.dim() != 3:
             raise ValueError("logits must be (batch, time, alphabet)")
         src_device, src_dtype = logits.device, logits.dtype
-        dev = _lib.compute_device(logits)
+        dev = R.compute_device(logits)
         x = logits.detach()
         if x.dtype not in (torch.float32, torch.float64):
             x = x.to(torch.float32)
@@ -56,54 +58,70 @@ class CTCLossEngine:
         grads = torch.empty((B, T, V), dtype=x.dtype, device=dev)
         if B == 0:
             return losses.to(src_device, src_dtype), grads.to(src_device, src_dtype)
-        code = _lib.dtype_code(x.dtype)
+        code = R.dtype_code(x.dtype)
         with torch.cuda.device(dev):
-            nbytes = L.e2e_ctc_loss_workspace_bytes(B, T, V, Smax, code, self.algo)
-            ws = _lib.workspace(dev, nbytes)
+            nbytes = _C.ctc_loss_workspace_bytes(B, T, V, Smax, code, self.algo)
+            ws = R.workspace(dev, nbytes)
             sB, sT, sV = x.stride()
-            _lib.check(L.e2e_ctc_loss_fwd_bwd(
-                x.data_ptr(), code, 1 if input_is_logprobs else 0, sB, sT, sV,
-                targets.data_ptr(), targets.stride(0), xl.data_ptr(), tl.data_ptr(),
-                B, T, V, Smax, self.blank_idx,
-                losses.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(),
-                self.algo, _lib.stream_ptr(dev)))
+            _C.ctc_loss_fwd_bwd(x.data_ptr(), code, bool(input_is_logprobs), sB, sT, sV,
+                                targets.data_ptr(), targets.stride(0), xl.data_ptr(), tl.data_ptr(),
+                                B, T, V, Smax, self.blank_idx,
+                                losses.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(),
+                                self.algo, R.stream_handle(dev))
         if src_device != dev or src_dtype != x.dtype:
             losses = losses.to(src_device, src_dtype)
             grads = grads.to(src_device, src_dtype)
         return losses, grads
 
+    @staticmethod
+    def scale_grads_(grads, scale):
+        """grads[b] *= scale[b] in place on the GPU (the multiply of functions/forward_backward.py:33 upstream,
+        without a second (B,T,V) tensor).  `grads` must be a contiguous CUDA tensor, `scale` a (B,) tensor."""
+        if not (grads.is_cuda and grads.is_contiguous()):
+            raise ValueError("scale_grads_ needs a contiguous GPU tensor")
+        B = grads.shape[0]
+        scale = scale.detach().to(device=grads.device, dtype=grads.dtype).contiguous().view(-1)
+        if scale.numel() != B:
+            raise ValueError("scale must have one entry per utterance")
+        if grads.numel():
+            with torch.cuda.device(grads.device):
+                _C.ctc_scale_grads(grads.data_ptr(), R.dtype_code(grads.dtype), scale.data_ptr(), B,
+                                   grads.numel() // B, R.stream_handle(grads.device))
+        return grads
+
 
 class LanguageModel:
-    """Device-resident n-gram table built from an ARPA file (stands where KenLM stands)."""
+    """n-gram model read from an ARPA file (plain or .gz); stands where KenLM stands upstream
+    (ctc_decoder.cpp:60-71).  The device tables belong to one GPU: `on(device)` returns the copy for that device,
+    loading it on first use."""
 
     def __init__(self, path, labels, case_sensitive):
-        L = _lib.load()
-        self._h = C.c_void_p()
-        arr = (C.c_char_p * len(labels))(*[s.encode("utf-8") for s in labels])
-        _lib.check(L.e2e_lm_load_arpa(os.fsencode(path), arr, len(labels), 1 if case_sensitive else 0,
-                                      C.byref(self._h)))
+        self.path, self.labels, self.case_sensitive = path, list(labels), bool(case_sensitive)
+        self._per_device = {}
+        self._first = self._load()
 
-    @property
-    def handle(self):
-        return self._h
+    def _load(self):
+        lm = _C.LanguageModel(self.path, self.labels, self.case_sensitive)
+        self._per_device[lm.device()] = lm
+        return lm
+
+    def on(self, device):
+        lm = self._per_device.get(device.index)
+        if lm is None:
+            with torch.cuda.device(device):
+                lm = self._load()
+            if lm.device() != device.index:
+                raise R.E2EError("the language model could not be loaded on %s" % device)
+        return lm
 
     def order(self):
-        return _lib.load().e2e_lm_order(self._h)
+        return self._first.order()
 
     def word_index(self, word):
-        return _lib.load().e2e_lm_word_index(self._h, word.encode("utf-8"))
+        return self._first.word_index(word)
 
     def score(self, ctx, word):
-        a = (C.c_uint32 * max(len(ctx), 1))(*ctx)
-        return _lib.load().e2e_lm_score(self._h, a, len(ctx), word)
-
-    def __del__(self):
-        try:
-            if self._h:
-                _lib.load().e2e_lm_free(self._h)
-                self._h = C.c_void_p()
-        except Exception:
-            pass
+        return self._first.score(list(ctx), word)
 
 
 class CTCDecoderEngine:
@@ -111,8 +129,7 @@ class CTCDecoderEngine:
     (src/decoders/ctc_decoder_py.cpp:8-24); methods keep the reference's keyword names."""
 
     def __init__(self, blank_idx, beam_width_=100, labels=None, lm_path="", lmwt_=1.0, wip_=0.0,
-                 oov_penalty_=-1000.0, case_sensitive=False):
-        _lib.load()
+                 oov_penalty_=-1000.0, case_sensitive=False, keep_on_device=False):
         self.blank_idx = int(blank_idx)
         self.beam_width = int(beam_width_)
         self.labels = list(labels or [])
@@ -120,28 +137,27 @@ class CTCDecoderEngine:
         self.wip = float(wip_)
         self.oov_penalty = float(oov_penalty_)
         self.case_sensitive = bool(case_sensitive)
+        self.keep_on_device = bool(keep_on_device)
         # index of " " among the labels, else -1 (src/decoders/ctc_decoder.cpp:55-59)
         self.space_id = self.labels.index(" ") if " " in self.labels else -1
         self.lm = None
         if lm_path:
-            _lib.require_gpu()
+            R.require_gpu()
             self.lm = LanguageModel(lm_path, self.labels, self.case_sensitive)
         else:
             self.lmwt = 0.0   # ctc_decoder.cpp:72-74
 
-    def _strings(self, ids, lens):
-        # indices2str, ctc_decoder.cpp:203-220: "" when there are no labels
+    def _strings(self, rows, lens):
+        # indices2str, ctc_decoder.cpp:203-220: "" when there are no labels.  The empty prefix wins as [-1] (quirk Q6);
+        # the reference then reads labels[-1] out of bounds (undefined behaviour) -- here that id spells nothing.
         if not self.labels:
             return ["" for _ in lens]
-        out = []
-        for row, n in zip(ids, lens):
-            out.append("".join(self.labels[k] for k in row[:n]))
-        return out
+        return ["".join(self.labels[k] for k in row[:n] if k >= 0) for row, n in zip(rows, lens)]
 
     def _prep(self, logits_, logits_lengths_):
         if logits_.dim() != 3:
             raise ValueError("logits must be (batch, time, alphabet)")
-        dev = _lib.compute_device(logits_)
+        dev = R.compute_device(logits_)
         x = logits_.detach()
         if x.dtype not in (torch.float32, torch.float64):
             x = x.to(torch.float32)
@@ -149,12 +165,19 @@ class CTCDecoderEngine:
         xl = _as_long(logits_lengths_, dev)
         if xl.numel() != x.shape[0]:
             raise ValueError("logits_lengths_ must have one entry per utterance")
+        V = x.shape[2]
+        if not 0 <= self.blank_idx < V:
+            raise ValueError("blank_idx %d outside the alphabet of %d columns" % (self.blank_idx, V))
+        if self.labels and len(self.labels) != V:
+            # upstream indexes labels[id] unchecked (ctc_decoder.cpp:203-220); a mismatch would spell garbage
+            raise ValueError("the decoder has %d labels but the logits have %d columns" % (len(self.labels), V))
         return x, xl, dev
+
+    def _result(self, t):
+        return t if self.keep_on_device else t.cpu()
 
     def decode_greedy(self, logits_, logits_lengths_):
         """argmax + blank/repeat collapse -> (targets (B,Tmax) int64 zero padded, lengths (B), sentences)."""
-        L = _lib.load()
-        src_device = logits_.device
         x, xl, dev = self._prep(logits_, logits_lengths_)
         B, T, V = x.shape
         out = torch.empty((B, T), dtype=torch.long, device=dev)
@@ -162,16 +185,14 @@ class CTCDecoderEngine:
         if B:
             with torch.cuda.device(dev):
                 sB, sT, sV = x.stride()
-                _lib.check(L.e2e_ctc_greedy(x.data_ptr(), _lib.dtype_code(x.dtype), sB, sT, sV, xl.data_ptr(),
-                                            B, T, V, self.blank_idx, out.data_ptr(), out_len.data_ptr(),
-                                            _lib.stream_ptr(dev)))
+                _C.ctc_greedy(x.data_ptr(), R.dtype_code(x.dtype), sB, sT, sV, xl.data_ptr(), B, T, V,
+                              self.blank_idx, out.data_ptr(), out_len.data_ptr(), R.stream_handle(dev))
+        out, out_len = self._result(out), self._result(out_len)
         sentences = self._strings(out.tolist(), out_len.tolist()) if self.labels else ["" for _ in range(B)]
-        return out.to(src_device), out_len.to(src_device), sentences
+        return out, out_len, sentences
 
     def decode(self, logits_, logits_lengths_):
         """Prefix beam search on LOG-PROBABILITIES -> (indices (B,maxlen) int64, lengths (B), sentences)."""
-        L = _lib.load()
-        src_device = logits_.device
         x, xl, dev = self._prep(logits_, logits_lengths_)
         B, T, V = x.shape
         max_out = T + 1
@@ -179,30 +200,25 @@ class CTCDecoderEngine:
         out_len = torch.empty(B, dtype=torch.long, device=dev)
         if B:
             with torch.cuda.device(dev):
-                nbytes = L.e2e_ctc_beam_workspace_bytes(B, T, V, self.beam_width)
-                ws = _lib.workspace(dev, nbytes)
+                lm = self.lm.on(dev).handle if self.lm is not None else 0
+                nbytes = _C.ctc_beam_workspace_bytes(B, T, V, self.beam_width)
+                ws = R.workspace(dev, nbytes)
                 sB, sT, sV = x.stride()
-                _lib.check(L.e2e_ctc_beam(x.data_ptr(), _lib.dtype_code(x.dtype), sB, sT, sV, xl.data_ptr(),
-                                          B, T, V, self.blank_idx, self.beam_width, self.space_id,
-                                          self.lm.handle if self.lm is not None else None,
-                                          self.lmwt, self.wip, self.oov_penalty,
-                                          out.data_ptr(), max_out, out_len.data_ptr(),
-                                          ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)))
-                # pool exhaustion / truncated output are reported per utterance (synchronises, like .tolist() below)
-                _lib.check(L.e2e_ctc_beam_status(ws.data_ptr(), B, T, V, self.beam_width))
+                _C.ctc_beam(x.data_ptr(), R.dtype_code(x.dtype), sB, sT, sV, xl.data_ptr(),
+                            B, T, V, self.blank_idx, self.beam_width, self.space_id, lm,
+                            self.lmwt, self.wip, self.oov_penalty,
+                            out.data_ptr(), max_out, out_len.data_ptr(),
+                            ws.data_ptr(), ws.numel(), R.stream_handle(dev))
         lens = out_len.tolist()
+        # per-utterance status rides on the lengths (include/e2e_ctc.h): no extra call, no extra synchronisation
+        for b, n in enumerate(lens):
+            if n < 0 or n > max_out:
+                raise R.E2EError("beam search: utterance %d %s" % (
+                    b, "ran out of prefix-tree nodes" if n < 0 else "needs %d output ids, %d provided" % (n, max_out)))
         width = max(lens) if lens else 0
         ids = out[:, :width].contiguous()    # packed to the longest result (ctc_decoder.cpp:192-200)
-        rows = ids.tolist()
-        if self.labels:
-            sentences = []
-            for row, n in zip(rows, lens):
-                # the empty prefix wins as [-1]; the reference then reads labels[-1] out of bounds
-                # (undefined behaviour, quirk Q6) -- here that id spells nothing
-                sentences.append("".join(self.labels[k] for k in row[:n] if k >= 0))
-        else:
-            sentences = ["" for _ in range(B)]
-        return ids.to(src_device), out_len.to(src_device), sentences
+        ids, out_len = self._result(ids), self._result(out_len)
+        return ids, out_len, self._strings(ids.tolist(), lens)
 
     def print_scores_for_sentence(self, words):
         """src/decoders/ctc_decoder.cpp:141-151: word, decoder index, vocabulary index, log10 score."""

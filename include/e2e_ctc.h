@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define E2E_CTC_ABI_VERSION 1
+#define E2E_CTC_ABI_VERSION 2
 
 /* element types of the logits / log-prob tensor (losses and grads use the same) */
 #define E2E_F32 0
@@ -64,7 +64,10 @@ const char* e2e_last_error(void);
  *                   t < x_len[b], 0 for padded rows), i.e. what
  *                   pytorch_end2end/modules/ctc_loss.py:37-40 + autograd give.
  *   targets      (B,*) int64, row stride tgt_stride, first t_len[b] entries used
- *   x_len,t_len  (B) int64 (1 <= x_len[b] <= T, 0 <= t_len[b] <= Smax)
+ *   x_len,t_len  (B) int64 (1 <= x_len[b] <= T, 0 <= t_len[b] <= Smax).  An utterance whose lengths are
+ *                outside these ranges, or whose first t_len[b] targets contain a value outside [0,V), gets
+ *                loss = NaN and a NaN gradient slab (the reference reads out of bounds there); the other
+ *                utterances of the batch are unaffected and the call still returns 0.
  *   losses       (B)  same dtype as x;  +inf for an infeasible alignment (Q2)
  *   grads        (B,T,V) contiguous, same dtype as x; NaN slab when infeasible
  *   workspace    >= e2e_ctc_loss_workspace_bytes(...) bytes, 256-B aligned
@@ -81,8 +84,8 @@ int e2e_ctc_loss_fwd_bwd(const void* x, int dtype, int input_is_logprobs,
                          void* workspace, size_t workspace_bytes,
                          int algo, void* stream);
 
-/* grads[b,:,:] *= scale[b]  in place (the multiply of
- * pytorch_end2end/functions/forward_backward.py:34 without a second tensor). */
+/* grads[b,:,:] *= scale[b]  in place: the multiply of the autograd backward
+ * (pytorch_end2end/functions/forward_backward.py:33) without a second (B,T,V) tensor. */
 int e2e_ctc_scale_grads(void* grads, int dtype, const void* scale /* (B) same dtype */,
                         int B, int64_t row_elems /* T*V */, void* stream);
 
@@ -106,10 +109,13 @@ int e2e_ctc_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV,
  * strings (UTF-8): words are spelled with them.
  */
 typedef struct e2e_lm e2e_lm;
+/* Reads the model and uploads its tables to the CURRENT HIP device (this call allocates and synchronises; it is
+ * the one entry point that does).  A model serves calls on that device only: load it once per device. */
 int e2e_lm_load_arpa(const char* path /* host */, const char* const* labels /* host */, int V,
                      int case_sensitive, e2e_lm** out);
 void e2e_lm_free(e2e_lm* lm);
 int e2e_lm_order(const e2e_lm* lm);
+int e2e_lm_device(const e2e_lm* lm);   /* HIP device index of the tables; -1 = host tables only (no GPU at load) */
 /* host-side scoring helpers (testing / print_scores_for_sentence,
  * src/decoders/ctc_decoder.cpp:141-151): word index (0 = <unk>) and
  * log10 p(word | most-recent-first context ids). */
@@ -122,9 +128,16 @@ double e2e_lm_score(const e2e_lm* lm, const uint32_t* ctx /* host */, int ctx_le
  *   :247-312 (get_next_prefix), :314-318 (score).
  *   lp        (B,T,V) LOG-PROBABILITIES, strides sB,sT,sV, f32/f64
  *   space_id  index of " " among the labels, or -1 (:55-59)
- *   lm        NULL for none (lmwt then counts as 0, :72-74)
+ *   lm        NULL for none (lmwt then counts as 0, :72-74); else a model loaded on the current device
+ *             with exactly V labels (E2E_ERR_ARG otherwise)
  *   out       (B,max_out) int64, zero-filled; out_len (B) int64.  When the
  *             empty prefix wins the result is the single id -1 (quirk Q6).
+ *             Per-utterance status rides on out_len (no separate call, nothing synchronises):
+ *               0 <= out_len[b] <= max_out   the sentence is out[b, :out_len[b]]
+ *               out_len[b] > max_out         the sentence has out_len[b] ids, only the first max_out were
+ *                                            written (max_out = x_len[b] + 1 can never be exceeded)
+ *               out_len[b] == -1             the prefix-tree node pool ran out (cannot happen with a workspace
+ *                                            of e2e_ctc_beam_workspace_bytes(); the row must not be used)
  *   workspace >= e2e_ctc_beam_workspace_bytes(...)
  * Limits (E2E_ERR_UNSUPPORTED beyond them; the reference has none): one workgroup holds an
  * utterance's beam in LDS -- beam_width*V + beam_width <= 8184 candidates per step,

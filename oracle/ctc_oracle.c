@@ -357,25 +357,29 @@ uint32_t oracle_lm_word_index(const oracle_lm* lm, const char* word) {
 }
 
 /* ARPA back-off: p(w|c_1..c_n) = p(c..w) if listed, else bo(c) + p(w|c_2..c_n).
- * ctx is most-recent-first.  Float accumulation like KenLM (float prob/backoff
- * summed in float, returned as float widened to double). */
+ * ctx is most-recent-first.  Float accumulation in KenLM's order (lm/model.cc FullScore: the float prob of the
+ * longest listed n-gram, then the float back-off weights of the longer contexts added shortest context first),
+ * returned as float widened to double. */
 double oracle_lm_base_score(const oracle_lm* lm, const uint32_t* ctx, int ctx_len,
                             uint32_t word, uint32_t* out_ctx, int* out_ctx_len) {
   int n = ctx_len; if (n > lm->order - 1) n = lm->order - 1;
   uint32_t ids[LM_MAX_ORDER];
-  float acc = 0.0f, result = 0.0f; int found = 0;
-  for (int k = n; k >= 0 && !found; k--) {
+  float bo[LM_MAX_ORDER + 1];
+  float result = 0.0f; int found_k = -1;
+  for (int k = n; k >= 0; k--) {
     /* k context words, oldest first, then the word */
     for (int i = 0; i < k; i++) ids[i] = ctx[k - 1 - i];
     ids[k] = word;
     ngram_slot* s = ngram_find(lm, ids, k + 1, 0);
-    if (s) { result = acc + s->prob; found = 1; break; }
+    if (s) { result = s->prob; found_k = k; break; }
+    bo[k] = 0.0f;
     if (k > 0) {
       ngram_slot* c = ngram_find(lm, ids, k, 0);   /* the context n-gram */
-      if (c) acc += c->backoff;
+      if (c) bo[k] = c->backoff;
     }
   }
-  if (!found) { uint32_t z = 0; result = acc + ngram_find(lm, &z, 1, 0)->prob; }
+  if (found_k < 0) { uint32_t z = 0; result = ngram_find(lm, &z, 1, 0)->prob; found_k = 0; }
+  for (int k = found_k + 1; k <= n; k++) result += bo[k];
   if (out_ctx) {
     int m = n + 1; if (m > lm->order - 1) m = lm->order - 1;
     uint32_t tmp[LM_MAX_ORDER];

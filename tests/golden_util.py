@@ -17,6 +17,21 @@ def known_answers():
         return json.load(f)
 
 
+def beam_bruteforce_cases():
+    """Exhaustive-enumeration decode answers (tests/golden/make_beam_golden.py; independent of oracle and product)."""
+    with open(os.path.join(GOLDEN, "beam_bruteforce.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        labels = [chr(ord("a") + i) for i in range(c["V"])]
+        labels[c["blank"]] = "_"
+        if c["space_id"] >= 0:
+            labels[c["space_id"]] = " "
+        c["labels"] = labels
+        # the empty sentence wins as the single id -1 (quirk Q6, src/decoders/ctc_decoder.cpp:232-245)
+        c["want_ids"] = c["best"] if c["best"] else [-1]
+    return cases
+
+
 def encoder_cases():
     with open(os.path.join(GOLDEN, "encoder.json")) as f:
         return json.load(f)

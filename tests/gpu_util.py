@@ -92,9 +92,10 @@ def c_abi_beam(lp, x_len=None, blank=0, beam_width=100, labels=None, lm=None, lm
     ws = torch.empty(n, dtype=torch.uint8, device=d)
     sB, sT, sV = lp.stride()
     _lib.check(L.e2e_ctc_beam(lp.data_ptr(), _lib.dtype_code(lp.dtype), sB, sT, sV, xl.data_ptr(), B, T, V, blank,
-                              beam_width, space_id, lm.handle if lm is not None else None, lmwt, wip, oov_penalty,
+                              beam_width, space_id, lm.on(d).handle if lm is not None else None, lmwt, wip, oov_penalty,
                               out.data_ptr(), max_out, out_len.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(d)))
-    _lib.check(L.e2e_ctc_beam_status(ws.data_ptr(), B, T, V, beam_width))
     lens = out_len.cpu().numpy()
+    # in-band status (include/e2e_ctc.h): -1 = node pool exhausted, > max_out = truncated
+    assert ((lens >= 0) & (lens <= max_out)).all(), lens
     width = int(lens.max()) if B else 0
     return out[:, :width].cpu().numpy(), lens

@@ -172,10 +172,15 @@ def load_reference_engine():
     if not os.path.exists(so):
         return None
     import torch  # noqa: F401  (libtorch must be loaded first)
-    if REF_DIR not in sys.path:
-        sys.path.insert(0, REF_DIR)
+    # loaded by file path and NOT entered into sys.modules: the repository's own top-level `cpp_ctc_loss` module (the
+    # product under the reference's name) must keep that name
+    import importlib.machinery
+    import importlib.util
     try:
-        import cpp_ctc_loss
-        return cpp_ctc_loss
+        loader = importlib.machinery.ExtensionFileLoader("cpp_ctc_loss", so)
+        spec = importlib.util.spec_from_file_location("cpp_ctc_loss", so, loader=loader)
+        mod = importlib.util.module_from_spec(spec)
+        loader.exec_module(mod)
+        return mod
     except Exception:
         return None

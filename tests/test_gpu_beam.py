@@ -216,3 +216,103 @@ def test_random_sweep_matches_oracle(seed):
         if rng.integers(0, 2):
             lp = lp.float()
         same_as_oracle(lp, xl, blank, W, labels, lm, olm, **kw)
+
+
+@pytest.mark.parametrize("case", G.beam_bruteforce_cases(), ids=lambda c: c["name"])
+def test_against_exhaustive_enumeration(case):
+    """Independent pin (tests/golden/make_beam_golden.py: every alignment enumerated in pure Python): a beam that never
+    prunes returns argmax over all labellings of log P - wip * num_words.  f64 and f32 inputs."""
+    lp = torch.tensor(case["log_probs"], dtype=torch.float64)[None]
+    for x in (lp, lp.float()):
+        ids, lens = U.c_abi_beam(x, None, case["blank"], case["beam_width"], case["labels"], wip=case["wip"])
+        assert ids[0, : lens[0]].tolist() == case["want_ids"]
+
+
+def _c4_inputs():
+    """BASELINE configs[3] exactly as bench.py builds it: B=64, T=1500, V=29, beam 100, seeded 10k-word 3-gram."""
+    import bench
+    labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1024, 1500, 29, generator=g) * 3
+    return labels, torch.log_softmax(x[:64], -1), bench.synthetic_arpa
+
+
+def test_full_c4_with_the_3gram_lm_matches_oracle(tmp_path):
+    """BASELINE configs[3] at FULL size with the LM (the bench's inputs and model): every one of the 64 utterances x 1500
+    frames must come out identical to the oracle, twice (reproducible)."""
+    labels, lp, synthetic_arpa = _c4_inputs()
+    path = str(tmp_path / "synthetic_3gram.arpa")
+    synthetic_arpa(path, labels)
+    lm = LanguageModel(path, labels, True)
+    olm = O.OracleLM(path)
+    kw = dict(lmwt=1.0, wip=1.0, oov_penalty=-10.0)
+    ids, lens = U.c_abi_beam(lp, None, 0, 100, labels, lm, **kw)
+    ids2, lens2 = U.c_abi_beam(lp, None, 0, 100, labels, lm, **kw)
+    assert np.array_equal(ids, ids2) and np.array_equal(lens, lens2)
+    o_ids, o_lens, _ = O.ctc_beam(lp.double().numpy(), None, 0, 100, labels, olm, case_sensitive=True,
+                                  n_threads=min(64, os.cpu_count() or 8), **kw)
+    assert lens.tolist() == o_lens.tolist()
+    assert np.array_equal(ids, o_ids)
+    # the LM took part: decoding the same emissions without it gives other sentences
+    ids0, lens0 = U.c_abi_beam(lp[:4], None, 0, 100, labels, wip=1.0)
+    assert any(ids0[b, : lens0[b]].tolist() != ids[b, : lens[b]].tolist() for b in range(4))
+
+
+def test_c4_shape_in_vocabulary_speech_with_the_3gram_lm_matches_oracle(tmp_path):
+    """Same shape and model, emissions that favour sentences of the model's own words (listed bigrams and trigrams are
+    hit, not only <unk> / back-off to the unigram), ragged lengths, a second LM weight."""
+    import random
+    labels, _, synthetic_arpa = _c4_inputs()
+    path = str(tmp_path / "synthetic_3gram.arpa")
+    synthetic_arpa(path, labels)
+    tri = [ln.split("\t")[1].split() for ln in open(path).read().split("\\3-grams:")[1].splitlines() if "\t" in ln]
+    rng = random.Random(5)
+    B, T = 16, 1500
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, T, 29, generator=g) * 1.5
+    xl = []
+    for b in range(B):
+        text, t = [], 0
+        while t < T - 40:
+            for w in rng.choice(tri):
+                for ch in w + " ":
+                    c = labels.index(ch)
+                    d = rng.randint(1, 3)
+                    x[b, t:t + d, c] += 6.0
+                    t += d
+                    x[b, t:t + 1, 0] += 6.0                  # a blank between characters (also separates doubles)
+                    t += 1
+                    if t >= T - 40:
+                        break
+                if t >= T - 40:
+                    break
+        xl.append(rng.randint(T // 2, T))
+    xl[0] = T
+    lp = torch.log_softmax(x, -1)
+    lm = LanguageModel(path, labels, True)
+    olm = O.OracleLM(path)
+    for lmwt in (1.0, 2.5):
+        kw = dict(lmwt=lmwt, wip=0.5, oov_penalty=-10.0)
+        ids, lens = U.c_abi_beam(lp, xl, 0, 100, labels, lm, **kw)
+        o_ids, o_lens, sents = O.ctc_beam(lp.double().numpy(), xl, 0, 100, labels, olm, case_sensitive=True,
+                                          n_threads=min(B, os.cpu_count() or 8), **kw)
+        assert lens.tolist() == o_lens.tolist() and np.array_equal(ids, o_ids)
+    words = set(w for t3 in tri for w in t3)
+    hit = sum(w in words for w in sents[0].split())
+    assert hit >= 0.8 * max(1, len(sents[0].split()))         # the decoded text is made of the model's words
+
+
+@pytest.mark.parametrize("name", ["lm_order4", "lm_order3_nounk"])
+def test_device_lm_tables_with_the_definition_pinned_models(name):
+    """The golden ARPA models whose host-side scores are pinned to the ARPA definition (tests/test_lm_cpu.py) drive
+    the DEVICE tables here: order 4 takes the general walk, order 3 the round-probed one; a model without <unk>."""
+    labels = ["_", "a", "b", "c", "d", "e", "'", " "]
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".arpa")
+    lm = LanguageModel(path, labels, True)
+    olm = O.OracleLM(path)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(4, 90, 8, generator=g, dtype=torch.float64) * 2.0
+    x[:, :, 7] += 1.0
+    lp = torch.log_softmax(x, -1)
+    for W, kw in ((30, dict(lmwt=1.0, wip=0.0, oov_penalty=-5.0)), (100, dict(lmwt=2.0, wip=1.0, oov_penalty=-1000.0))):
+        same_as_oracle(lp, [90, 71, 33, 5], 0, W, labels, lm, olm, case_sensitive=True, **kw)

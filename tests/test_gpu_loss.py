@@ -157,6 +157,37 @@ def test_invalid_lengths_poison_not_crash(algo):
     assert np.isnan(grads[1]).all() and np.isnan(grads[2]).all() and np.isfinite(grads[0]).all()
 
 
+@pytest.mark.parametrize("algo", ALGOS, ids=lambda a: ALGO_IDS[a])
+@pytest.mark.parametrize("V", [4, 200])
+def test_out_of_range_targets_poison_not_crash(algo, V):
+    # a -1 padding value inside t_len, or an id == V: NaN for that utterance only (include/e2e_ctc.h), no memory fault
+    if algo == _lib.ALGO_FAST and V > 96:
+        pytest.skip("E2E_ALGO_FAST proper covers V <= 96; the wide path is reached through AUTO")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 9, V, generator=g)
+    tg = [[1, 2, 3], [1, -1, 2], [1, V, 2], [1, V + 5, -7]]
+    for dt in (torch.float32, torch.float64):
+        if algo == _lib.ALGO_FAST and dt != torch.float32:
+            continue
+        losses, grads = U.c_abi_loss(x.to(dt), tg, [9, 9, 9, 9], [3, 3, 3, 2], 0, False, algo)
+        assert np.isfinite(losses[0]) and np.isfinite(grads[0]).all()
+        assert np.isnan(losses[1]) and np.isnan(losses[2]) and np.isnan(grads[1]).all() and np.isnan(grads[2]).all()
+        assert np.isfinite(losses[3]) and np.isfinite(grads[3]).all()      # the bad entries lie beyond t_len
+
+
+def test_scale_grads_in_place_both_dtypes():
+    L = _lib.load()
+    d = U.dev()
+    for dt, code in ((torch.float32, _lib.F32), (torch.float64, _lib.F64)):
+        g = torch.randn(5, 7, 3, dtype=dt, device=d)
+        s = torch.tensor([1.0, 0.0, -2.5, 1.0, 3.0], dtype=dt, device=d)
+        want = g * s.view(-1, 1, 1)
+        _lib.check(L.e2e_ctc_scale_grads(g.data_ptr(), code, s.data_ptr(), 5, 21, _lib.stream_ptr(d)))
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)
+    assert L.e2e_ctc_scale_grads(None, 9, None, 1, 1, None) == -1
+
+
 def test_argument_errors_are_reported():
     L = _lib.load()
     rc = L.e2e_ctc_loss_fwd_bwd(None, 5, 1, 1, 1, 1, None, 0, None, None, 1, 1, 1, 0, 0, None, None, None, 0, 0, None)

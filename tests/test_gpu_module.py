@@ -75,7 +75,8 @@ def test_decoder_known_answers(case):
         xd = x.to(dev)
         res = dec.decode_greedy(xd, xl.to(dev) if xl is not None else None)
         assert isinstance(res, DecoderResults) and res.decoded_sentences == case["greedy"]
-        assert res.decoded_targets.device.type == dev and res.decoded_targets.dtype == torch.long
+        # results are CPU tensors whatever the input's device, as upstream (ctc_decoder.cpp:157,449)
+        assert res.decoded_targets.device.type == "cpu" and res.decoded_targets.dtype == torch.long
         if "greedy_targets" in case:
             assert res.decoded_targets.tolist() == case["greedy_targets"]
             assert res.decoded_targets_lengths.tolist() == case["greedy_lengths"]
@@ -95,3 +96,88 @@ def test_decoder_time_major_and_raw_logits():
     assert a.decoded_sentences == b.decoded_sentences
     _, _, want = O.ctc_beam(torch.log_softmax(x.double(), -1).numpy(), None, 0, 15, labels, wip=0.5)
     assert a.decoded_sentences == want
+
+
+@pytest.mark.parametrize("m", G.meta()["module"], ids=lambda m: m["name"])
+def test_reference_call_pattern_through_the_reference_module_names(m):
+    """The reference's own module code path, statement by statement (pytorch_end2end/modules/ctc_loss.py:37-57,74-75 and
+    functions/forward_backward.py:18-35), with the engine found the way upstream finds it:
+    import_module("cpp_ctc_loss").CTCLossEngine(blank_idx).  Fixtures: the reference module's own outputs."""
+    from importlib import import_module
+    import torch.nn.functional as F
+    engine = import_module("cpp_ctc_loss").CTCLossEngine(m["kwargs"].get("blank_idx", 0))
+
+    class RefStyleFunction(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, engine, logits, targets, logits_lengths, targets_lengths):
+            loss, grads = engine.compute(logits, targets, logits_lengths, targets_lengths)
+            ctx.grads = grads
+            return loss
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            loss_grads = ctx.grads
+            if grad_output.is_cuda:
+                loss_grads = loss_grads.cuda(grad_output.get_device())
+            return None, loss_grads.contiguous() * grad_output.contiguous().view(-1, 1, 1), None, None, None
+
+    c = G.module_case(m["name"])
+    kw = m["kwargs"]
+    x = torch.from_numpy(c["input"]).cuda().requires_grad_()
+    tg, xl, tl = (torch.from_numpy(c[k]) for k in ("targets", "x_len", "t_len"))      # CPU ints, as users pass them
+    lsm = x if kw.get("after_logsoftmax") else F.log_softmax(x, dim=2)
+    if kw.get("time_major"):
+        lsm = lsm.permute(1, 0, 2)
+    loss = RefStyleFunction.apply(engine, lsm, tg, xl, tl)
+    if kw.get("reduce"):
+        loss = loss.mean() if kw.get("size_average") else loss.sum()
+    w = torch.arange(1, loss.numel() + 1, dtype=loss.dtype, device=loss.device).reshape(loss.shape) / 2.0
+    (loss * w).sum().backward()
+    rt, at = (1e-9, 1e-11) if m["dtype"] == "float64" else (1e-4, 2e-6)
+    U.assert_same(loss.detach().cpu().numpy(), c["loss"], rt, at, "loss")
+    U.assert_same(x.grad.cpu().numpy(), c["input_grad"], rt, at, "input grad")
+
+
+def test_reference_decoder_engine_name_keywords_and_cpu_results():
+    """cpp_ctc_decoder.CTCDecoder called the way pytorch_end2end/decoders/ctc_decoder.py:61-64,108-110,145-147 calls it:
+    positional constructor arguments, CPU tensors, the keywords logits_= / logits_lengths_=; results are CPU tensors."""
+    import cpp_ctc_decoder
+    for case in G.known_answers()["decode"]:
+        x = torch.tensor(case["x"], dtype=torch.float32)
+        lp = torch.log(x) if case["input_kind"] == "log_of_probs" else torch.log_softmax(x, -1)
+        xl = torch.tensor(case["x_len"], dtype=torch.int32) if "x_len" in case else \
+            torch.zeros(x.shape[0], dtype=torch.int).fill_(x.shape[1])
+        dec = cpp_ctc_decoder.CTCDecoder(case["blank"], max(case["beam_width"], 2), case["labels"], "", 1.0,
+                                         case.get("wip", 0.0), -10, True)
+        ids, lens, sents = dec.decode_greedy(logits_=x, logits_lengths_=xl)
+        assert sents == case["greedy"] and ids.device.type == "cpu" and lens.device.type == "cpu"
+        assert ids.shape == x.shape[:2]                                   # (B, Tmax) zero padded (quirk Q5)
+        if case["beam_width"] > 1:
+            ids, lens, sents = dec.decode(logits_=lp, logits_lengths_=xl)
+            assert sents == case["beam"] and ids.device.type == "cpu" and ids.dtype == torch.long
+            assert ids.shape[1] == int(lens.max())                        # packed to the longest (ctc_decoder.cpp:192)
+
+
+def test_backward_scales_in_place_and_a_retained_graph_can_be_walked_again():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 12, 5, generator=g).cuda().requires_grad_()
+    tg, xl, tl = torch.tensor([[1, 2, 2], [3, 1, 0], [4, 4, 4]]), torch.tensor([12, 9, 12]), torch.tensor([3, 2, 3])
+    loss = CTCLoss()(x, tg, xl, tl)
+    w = torch.tensor([0.5, 0.0, -2.0], device="cuda")
+    (loss * w).sum().backward(retain_graph=True)
+    g1 = x.grad.clone()
+    x.grad = None
+    (loss * w).sum().backward()            # the first walk gave its buffer away: the engine is asked again
+    assert torch.equal(g1, x.grad)
+    lp = torch.log_softmax(x.detach().cpu().double(), -1).numpy()
+    _, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    for b in range(3):
+        g_o[b, xl[b]:] = 0
+    U.assert_same(g1.cpu().numpy(), g_o * w.cpu().numpy()[:, None, None], 1e-4, 2e-6, "scaled grad")
+    assert (g1[1] == 0).all()
+
+
+def test_decoder_rejects_an_alphabet_that_does_not_match_the_labels():
+    dec = CTCDecoder(beam_width=4, labels=["_", "a", "b"])
+    with pytest.raises(ValueError, match="labels"):
+        dec.decode(torch.randn(1, 5, 4).cuda())

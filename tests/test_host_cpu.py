@@ -1,7 +1,7 @@
 """CPU: the C-ABI library loads and exports every symbol include/e2e_ctc.h declares; host logic."""
-import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -12,16 +12,69 @@ import golden_util as G
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "e2e_ctc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return set(re.findall(r"\b(e2e_[a-z0-9_]+)\s*\(", hdr))
+
+
+def _exported():
+    from end2end_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("e2e_")}
+
+
 def test_library_exports_every_declared_symbol():
     from end2end_amd import _lib
     L = _lib.load()
-    hdr = open(os.path.join(ROOT, "include", "e2e_ctc.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(e2e_[a-z0-9_]+)\s*\(", hdr))
+    names = _declared()
     assert {"e2e_ctc_loss_fwd_bwd", "e2e_ctc_greedy", "e2e_ctc_beam", "e2e_lm_load_arpa"} <= names
     for n in sorted(names):
         assert hasattr(L, n), n
     assert L.e2e_ctc_abi_version() == _lib.ABI_VERSION
+
+
+def test_header_declares_every_exported_symbol():
+    # the other direction: nothing a caller may need (status words, helpers) hides outside the header.
+    # e2e_debug_* are instrumentation of profiling builds and not part of the contract.
+    extra = {n for n in _exported() - _declared() if not n.startswith("e2e_debug_")}
+    assert not extra, "exported but not declared in include/e2e_ctc.h: %s" % sorted(extra)
+
+
+def test_pybind_layer_loads_and_reports_errors():
+    from end2end_amd import _C, _runtime
+    assert _C.abi_version() == _C.ABI_VERSION == _runtime.ABI_VERSION
+    assert _C.ctc_loss_workspace_bytes(4, 50, 28, 30, _C.F32, _C.ALGO_AUTO) > 0
+    with pytest.raises(_C.E2EError, match="dtype"):          # argument checks run before any GPU call
+        _C.ctc_loss_fwd_bwd(0, 5, True, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+    assert issubclass(_C.E2EError, RuntimeError)
+
+
+def test_reference_module_names_resolve_to_the_engines():
+    # pytorch_end2end/modules/ctc_loss.py:74 (import_module("cpp_ctc_loss")), decoders/ctc_decoder.py:13
+    import inspect
+    from importlib import import_module
+    loss_mod, dec_mod = import_module("cpp_ctc_loss"), import_module("cpp_ctc_decoder")
+    eng = loss_mod.CTCLossEngine(0)
+    assert list(inspect.signature(eng.compute).parameters)[:4] == ["logits", "targets", "logits_lengths", "targets_lengths"]
+    sig = inspect.signature(dec_mod.CTCDecoder.__init__)
+    got = [(k, v.default) for k, v in sig.parameters.items() if k not in ("self", "keep_on_device")]
+    assert got[0][0] == "blank_idx"
+    # keyword names and defaults of src/decoders/ctc_decoder_py.cpp:17-24
+    assert [(k, (d or type(d)())) for k, d in got[1:]] == [("beam_width_", 100), ("labels", type(None)()), ("lm_path", ""),
+                                                         ("lmwt_", 1.0), ("wip_", 0.0), ("oov_penalty_", -1000.0),
+                                                         ("case_sensitive", False)]
+    for name in ("decode", "decode_greedy"):
+        assert list(inspect.signature(getattr(dec_mod.CTCDecoder, name)).parameters)[1:] == ["logits_", "logits_lengths_"]
+    assert list(inspect.signature(dec_mod.CTCDecoder.print_scores_for_sentence).parameters)[1:] == ["words"]
+    import pytorch_end2end
+    import end2end_amd
+    assert pytorch_end2end.CTCLoss is end2end_amd.CTCLoss and pytorch_end2end.CTCDecoder is end2end_amd.CTCDecoder
+    assert pytorch_end2end.CTCEncoder is end2end_amd.CTCEncoder
+    from pytorch_end2end.modules.ctc_loss import CTCLoss as A
+    from pytorch_end2end.decoders.ctc_decoder import CTCDecoder as B, CTCDecoderError  # noqa: F401
+    from pytorch_end2end.functions.forward_backward import ForwardBackwardLossFunction  # noqa: F401
+    assert A is end2end_amd.CTCLoss and B is end2end_amd.CTCDecoder
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -61,6 +114,8 @@ def test_decoder_wrapper_parameter_checks(tmp_path):
     from end2end_amd import CTCDecoder, CTCDecoderError
     with pytest.raises(CTCDecoderError, match="Can't find a model"):
         CTCDecoder(labels=["_", "a"], lm_path=str(tmp_path / "missing.arpa"))
+    with pytest.raises(CTCDecoderError, match="Can't find a model"):     # the labels check upstream can never fire
+        CTCDecoder(lm_path=str(tmp_path / "missing.arpa"))
     d = CTCDecoder(beam_width=1, labels=["_", "a", " "])
     assert d._decoder.space_id == 2 and d._decoder.lmwt == 0.0
     assert d._wip == 1.0 and d._oov_penalty == -10 and d._case_sensitive is True   # wrapper defaults

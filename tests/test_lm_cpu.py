@@ -56,8 +56,102 @@ def test_case_folding_and_errors(tmp_path):
     assert lm_cs.word_index("ab") == 0 and lm_cs.word_index("AB") != 0
     bad = tmp_path / "bad.arpa"
     bad.write_text("this is not an arpa file\n")
-    from end2end_amd._lib import E2EError
+    from end2end_amd._runtime import E2EError
     with pytest.raises(E2EError, match="ARPA"):
         LanguageModel(str(bad), LABELS, True)
     with pytest.raises(E2EError, match="cannot open"):
         LanguageModel(str(tmp_path / "missing.arpa"), LABELS, True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Independent pin: expected scores derived in pure Python from the ARPA definition (tests/golden/make_lm_golden.py,
+# which shares no code with either C implementation).  Product (host tables of libe2e_ctc.so) AND oracle are held to it.
+# ---------------------------------------------------------------------------------------------------------------------
+import json  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+with open(os.path.join(GOLD, "lm_golden.json")) as _f:
+    LM_GOLDEN = json.load(_f)["models"]
+GLABELS = ["_", "a", "b", "c", "d", "e", "'", " "]
+
+
+def _tol(abs_terms):
+    # float32 probabilities / back-offs (parsed from 4-decimal text) added in float32
+    return 2.5e-7 * abs_terms + 1e-7
+
+
+class _Product:
+    def __init__(self, path):
+        self.lm = LanguageModel(path, GLABELS, case_sensitive=True)
+
+    def idx(self, w):
+        return self.lm.word_index(w)
+
+    def score(self, ctx_ids, wid):
+        return self.lm.score(ctx_ids, wid)
+
+    def order(self):
+        return self.lm.order()
+
+
+class _Oracle:
+    def __init__(self, path):
+        self.lm = O.OracleLM(path)
+
+    def idx(self, w):
+        return self.lm.word_index(w)
+
+    def score(self, ctx_ids, wid):
+        return self.lm.base_score(ctx_ids, wid)[0]
+
+    def order(self):
+        return self.lm.order()
+
+
+@pytest.mark.parametrize("impl", [_Product, _Oracle], ids=["product", "oracle"])
+@pytest.mark.parametrize("model", LM_GOLDEN, ids=lambda m: m["name"])
+def test_scores_against_the_arpa_definition(model, impl):
+    assert model["n_entries"] >= 200
+    m = impl(os.path.join(GOLD, model["arpa"]))
+    assert m.order() == model["order"]
+    assert m.idx("<unk>") == 0 and m.idx("zz") == 0 and m.idx("Ab") == 0
+    n_absent = 0
+    for ctx, word, want, abs_terms, _state_len, suffix_absent in model["queries"]:
+        ids = [m.idx(w) for w in ctx.split()] if ctx else []
+        got = m.score(ids[: model["order"] - 1], m.idx(word))
+        assert abs(got - want) <= _tol(abs_terms), (ctx, word, got, want)
+        n_absent += suffix_absent
+    assert n_absent >= 3          # listed trigrams whose suffix bigram is not listed are found all the same
+
+
+@pytest.mark.parametrize("impl", [_Product, _Oracle], ids=["product", "oracle"])
+@pytest.mark.parametrize("model", LM_GOLDEN, ids=lambda m: m["name"])
+def test_state_kept_after_a_word_is_score_equivalent_to_kenlms(model, impl):
+    """KenLM keeps `kenlm_state_len` words after scoring a word; the implementations here keep order-1 words.  Both must
+    score every next word the same (checked from the minimised and from the full history)."""
+    m = impl(os.path.join(GOLD, model["arpa"]))
+    probe = [m.idx(w) for w in ("a", "b", "abc", "dead", "zz", "</s>")]
+    k = 0
+    for ctx, word, _want, _t, state_len, _ in model["queries"]:
+        if state_len is None or not ctx:
+            continue
+        k += 1
+        if k % 7:
+            continue
+        full = ([m.idx(word)] + [m.idx(w) for w in ctx.split()])[: model["order"] - 1]
+        for w2 in probe:
+            a, b = m.score(full, w2), m.score(full[:state_len], w2)
+            assert abs(a - b) <= 1e-6, (ctx, word, state_len)
+
+
+@pytest.mark.parametrize("impl", [_Product, _Oracle], ids=["product", "oracle"])
+@pytest.mark.parametrize("model", LM_GOLDEN, ids=lambda m: m["name"])
+def test_sentences_walked_from_begin_of_sentence(model, impl):
+    m = impl(os.path.join(GOLD, model["arpa"]))
+    for s in model["sentences"]:
+        hist = [m.idx("<s>")]
+        for w, (want, abs_terms) in zip(s["words"], s["scores"]):
+            wid = m.idx(w)
+            got = m.score(hist[: model["order"] - 1], wid)
+            assert abs(got - want) <= _tol(abs_terms), (s["words"], w, got, want)
+            hist = [wid] + hist

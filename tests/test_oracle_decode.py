@@ -79,3 +79,13 @@ def test_word_insertion_penalty_prefers_fewer_words():
     # a lone " " carries no word, so with a heavy penalty it outranks "a" (num_words counts word STARTS,
     # ctc_decoder.cpp:258-262,314-318)
     assert s0 == "a a" and len(s5.split()) < 2
+
+
+@pytest.mark.parametrize("case", G.beam_bruteforce_cases(), ids=lambda c: c["name"])
+def test_beam_against_exhaustive_enumeration(case):
+    """Independent pin: with a beam wide enough never to prune, the search must return the labelling that maximises
+    log P - wip * num_words over ALL labellings (enumerated alignment by alignment in tests/golden/make_beam_golden.py)."""
+    lp = np.array(case["log_probs"], dtype=np.float64)[None]
+    for W in (case["beam_width"], case["beam_width"] + 37):
+        ids, lens, _ = O.ctc_beam(lp, None, case["blank"], W, case["labels"], wip=case["wip"])
+        assert ids[0, : lens[0]].tolist() == case["want_ids"]
