@@ -11,30 +11,63 @@ data-path collective) and the scalar loss is all-reduced over RCCL.
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM peak with
-ALGORITHMIC bytes (2*V*4 B per frame: logits read once, gradient written once);
-`cpu_baseline` times the reference's own C++ engine (oracle/_ref, kind "reference") or, if
-that is absent, the C restatement (kind "port") on this box's host cores.
+Started plainly with --gpus N > 1 (no RANK in the environment) it launches the N ranks itself,
+as children, before anything touches a GPU, and relays rank 0's line.
+
+Rank 0 prints ONE JSON line:
+  value / ms_per_step       the C-ABI step above (the drop-in boundary), whole job
+  module_ms_per_step        the metric as SURVEY.md 8(d) words it, through the Python surface:
+                            loss = CTCLoss(reduce=True, size_average=True)(logits, ...); loss.backward()
+  roofline                  the call's kernels against HBM peak with ALGORITHMIC bytes (2*V*4 B per frame: logits read
+                            once, gradient written once); peak = 8 TB/s spec, peak_measured = an on-box device copy
+  wide_alphabet             one GPU's share of BASELINE configs[4] (B=512 T=256 V=8000), at every N
+  cpu_baseline (N=1)        the reference's own C++ engine (oracle/_ref, kind "reference") or the C restatement
+                            (kind "port") on this box's host cores; decode.*.cpu_baseline likewise (port)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 WORKLOAD = dict(name="ctc_fwd_bwd_B256_T1000_V29_S200_f32", B=256, T=1000, V=29, S=200)
+WIDE = dict(name="ctc_fwd_bwd_B512_T256_V8000_S64_f32", B=512, T=256, V=8000, S=64)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the secondary decode-throughput numbers")
+    ap.add_argument("--no-wide", action="store_true", help="skip the V=8000 share")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run, one process
+    per GPU, rendezvous on 127.0.0.1) BEFORE this process touches a GPU, and relay their output."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def make_batch(seed, B, T, V, S, device):
     """logits randn, targets in [1,V), target lengths in [S/2,S], full-length inputs."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     logits = torch.randn(B, T, V, generator=g)
     targets = torch.randint(1, V, (B, S), generator=g)
@@ -48,7 +81,9 @@ class HotPath:
     """Pre-bound C-ABI call (no per-step allocation, graph-capturable)."""
 
     def __init__(self, dev_batch, blank=0):
+        import torch
         from end2end_amd import _lib
+        self.torch = torch
         self.lib = _lib
         self.L = _lib.load()
         self.x, self.targets, self.x_len, self.t_len = dev_batch
@@ -64,7 +99,7 @@ class HotPath:
         self.means = torch.zeros((2, self.bucket), dtype=torch.float32, device=self.dev)   # double-buffered buckets
         self.k = 0
 
-    def step(self):
+    def call(self):
         sB, sT, sV = self.x.stride()
         self.lib.check(self.L.e2e_ctc_loss_fwd_bwd(
             self.x.data_ptr(), self.lib.F32, 0, sB, sT, sV,
@@ -72,15 +107,43 @@ class HotPath:
             self.B, self.T, self.V, self.S, self.blank,
             self.losses.data_ptr(), self.grads.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
             self.lib.ALGO_AUTO, self.lib.stream_ptr(self.dev)))
+
+    def step(self):
+        self.call()
         m = self.means[(self.k // self.bucket) & 1, self.k % self.bucket]
-        torch.mean(self.losses, dim=0, out=m)
+        self.torch.mean(self.losses, dim=0, out=m)
         self.k += 1
         return m
 
 
-def cpu_baseline(host_batch, frames):
+def time_events(torch, fn, reps):
+    """Mean duration of fn() in ms, one HIP event pair per call on the launch stream."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+
+def measured_copy_gbs(torch, dev):
+    """On-box HBM rate of a plain device copy (read + write bytes per second), the achievable ceiling the guide quotes
+    beside the 8 TB/s spec."""
+    n = 1 << 28                                             # 1 GiB of f32 each way
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    ms = time_events(torch, lambda: dst.copy_(src), 10)
+    del src, dst
+    return 2.0 * n * 4 / (ms * 1e-3) / 1e9
+
+
+def cpu_baseline_loss(host_batch, frames):
     """The reference path on host cores: log_softmax + engine.compute + backward, as
     pytorch_end2end/modules/ctc_loss.py:25-57 and functions/forward_backward.py:18-35 do it."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     logits, targets, x_len, t_len = host_batch
@@ -118,11 +181,11 @@ def cpu_baseline(host_batch, frames):
     B = logits.shape[0]
     one(min(B, 16))                       # warm-up (thread pool, allocator)
     n = B
-    times = [one(n) for _ in range(2)]
+    times = [one(n) for _ in range(3)]
     best = min(times)
     per_frame = frames * n / B
     return {"value": per_frame / best, "unit": "frames/s", "cores": os.cpu_count(), "kind": kind,
-            "sample": "full %d-utterance batch of the same workload, best of 2 after a 16-utterance warm-up, "
+            "sample": "full %d-utterance batch of the same workload, best of 3 after a 16-utterance warm-up, "
                       "one thread per utterance as the reference does (%.2f s per pass)" % (n, best)}
 
 
@@ -154,10 +217,13 @@ def synthetic_arpa(path, labels, n_words=10000, seed=0):
         f.write("\n\\end\\\n")
 
 
-def decode_numbers(dev):
+def decode_numbers(dev, with_cpu):
     """Secondary metric of BASELINE.json: decode utterances/s.  Greedy at B=1024 T=1500 V=29 (configs[2]); beam=100 at
-    B=64 T=1500 V=29 without and with a 3-gram LM (configs[3], synthetic ARPA).  Inputs resident in HBM."""
+    B=64 T=1500 V=29 without and with a 3-gram LM (configs[3], synthetic ARPA).  Inputs resident in HBM.  The CPU
+    baselines are the C restatement of the reference's decoder (oracle/, kind "port": the reference decoder itself does
+    not compile without KenLM), one thread per utterance as upstream (ctc_decoder.cpp:172-189,465-486)."""
     import tempfile
+    import torch
     from end2end_amd import CTCDecoder
     labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
     out = {}
@@ -171,87 +237,80 @@ def decode_numbers(dev):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
+    def cpu_timed(fn, n_utt, what):
+        fn()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return {"value": n_utt / min(ts), "unit": "utterances/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": "%s, one thread per utterance, best of 3 (%.3f s per pass)" % (what, min(ts))}
+
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+
     g = torch.Generator().manual_seed(2)
-    x = (torch.randn(1024, 1500, 29, generator=g) * 3).to(dev)
+    xh = torch.randn(1024, 1500, 29, generator=g) * 3
+    x = xh.to(dev)
     xl = torch.full((1024,), 1500, dtype=torch.long, device=dev)
-    eng = CTCDecoder(beam_width=1, blank_idx=0)._decoder          # no labels: ids only, no per-utterance strings
+    eng = CTCDecoder(beam_width=1, blank_idx=0, keep_on_device=True)._decoder    # no labels: ids only; results stay in HBM
     dt = timed(lambda: eng.decode_greedy(x, xl), 10)
     bytes_alg = 1024 * 1500 * (29 * 4 + 8)
     out["greedy"] = {"workload": "B=1024 T=1500 V=29", "utterances_per_s": 1024 / dt, "frames_per_s": 1024 * 1500 / dt,
                      "ms": dt * 1e3, "hbm_frac_algorithmic": bytes_alg / dt / 1e9 / HBM_PEAK_GBS,
-                     "note": "wall time of the Python engine call incl. the device-to-host copy of the result lengths"}
+                     "note": "wall time of the Python engine call, results left on the device"}
+    if with_cpu:
+        xd = xh.double().numpy()
+        out["greedy"]["cpu_baseline"] = cpu_timed(lambda: O.ctc_greedy(xd, None, 0, n_threads=0), 1024,
+                                                  "the full 1024-utterance batch (f64 copy of the logits not timed)")
+        del xd
     xb = torch.log_softmax(x[:64], -1)
     xlb = xl[:64]
     eng = CTCDecoder(beam_width=100, blank_idx=0, after_logsoftmax=True, labels=labels, wip=1.0)._decoder
     dt = timed(lambda: eng.decode(xb, xlb), 2)
     out["beam100"] = {"workload": "B=64 T=1500 V=29 beam=100, no LM", "utterances_per_s": 64 / dt, "ms": dt * 1e3}
+    xbh = xb.double().cpu().numpy() if with_cpu else None
+    if with_cpu:
+        out["beam100"]["cpu_baseline"] = cpu_timed(
+            lambda: O.ctc_beam(xbh, None, 0, 100, labels, None, wip=1.0, n_threads=0), 64, "the full 64-utterance batch")
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "synthetic_3gram.arpa")
         synthetic_arpa(path, labels)
         eng = CTCDecoder(beam_width=100, blank_idx=0, after_logsoftmax=True, labels=labels, lm_path=path, lmwt=1.0,
                          wip=1.0, oov_penalty=-10.0)._decoder
         dt = timed(lambda: eng.decode(xb, xlb), 2)
-    out["beam100_lm"] = {"workload": "B=64 T=1500 V=29 beam=100 + synthetic 3-gram ARPA (10k words)",
-                         "utterances_per_s": 64 / dt, "ms": dt * 1e3}
+        out["beam100_lm"] = {"workload": "B=64 T=1500 V=29 beam=100 + synthetic 3-gram ARPA (10k words)",
+                             "utterances_per_s": 64 / dt, "ms": dt * 1e3}
+        if with_cpu:
+            olm = O.OracleLM(path)
+            out["beam100_lm"]["cpu_baseline"] = cpu_timed(
+                lambda: O.ctc_beam(xbh, None, 0, 100, labels, olm, lmwt=1.0, wip=1.0, oov_penalty=-10.0, n_threads=0),
+                64, "the full 64-utterance batch, same ARPA")
     return out
-
-
-def wide_alphabet_numbers(dev):
-    """One GPU's share of BASELINE configs[4] (B=4096 over 8 GPUs -> 512 per GPU, T=256, V=8000, S<=64): the shape on
-    which the path is genuinely HBM-bound.  Same C-ABI call as the headline, inputs resident in HBM."""
-    from end2end_amd import _lib
-    L = _lib.load()
-    B, T, V, S = 512, 256, 8000, 64
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(B, T, V, generator=g).to(dev)
-    tg = torch.randint(1, V, (B, S), generator=g).to(dev)
-    tl = torch.randint(S // 2, S + 1, (B,), generator=g).to(dev)
-    xl = torch.full((B,), T, dtype=torch.long, device=dev)
-    losses = torch.empty(B, device=dev)
-    grads = torch.empty((B, T, V), device=dev)
-    ws = torch.empty(L.e2e_ctc_loss_workspace_bytes(B, T, V, S, _lib.F32, _lib.ALGO_AUTO), dtype=torch.uint8, device=dev)
-
-    def call():
-        _lib.check(L.e2e_ctc_loss_fwd_bwd(x.data_ptr(), _lib.F32, 0, *x.stride(), tg.data_ptr(), tg.stride(0), xl.data_ptr(),
-                                          tl.data_ptr(), B, T, V, S, 0, losses.data_ptr(), grads.data_ptr(), ws.data_ptr(),
-                                          ws.numel(), _lib.ALGO_AUTO, _lib.stream_ptr(dev)))
-    for _ in range(2):
-        call()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        call()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 5
-    algo = 2.0 * V * 4 * B * T
-    return {"workload": "B=512 T=256 V=8000 S<=64 f32 (one GPU's share of configs[4])", "ms": ms,
-            "frames_per_s": B * T / (ms * 1e-3), "algorithmic_bytes": algo,
-            "roofline": {"bound": "hbm", "achieved": algo / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "note": "logits read once, gradient written once (the row stays in a wave's registers between the softmax's "
-                    "passes), then the <= S+1 label columns of each frame are corrected in place after the lattice"}
 
 
 def recorded_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            rec = json.load(f)
-        return rec["traffic_bytes_per_launch"] if rec.get("workload") == workload else None
-    except Exception:
-        return None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)
+            if rec.get("workload") == workload:
+                return rec["traffic_bytes_per_launch"]
+        except Exception:
+            pass
+    return None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-decode", action="store_true", help="skip the secondary decode-throughput numbers")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -271,6 +330,19 @@ def main():
     if args.gpus != n_gpus and rank == 0:
         print("bench.py: --gpus %d but %d rank(s) were launched; reporting n_gpus=%d" % (args.gpus, n_gpus, n_gpus),
               file=sys.stderr)
+
+    def max_over_ranks(v):
+        if not distributed:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     w = WORKLOAD
     host_batch, dev_batch = make_batch(1000 + rank, w["B"], w["T"], w["V"], w["S"], dev)
@@ -299,13 +371,11 @@ def main():
         while pending:
             pending.pop(0).wait()
 
+    # ---- leg 1: the C-ABI step (value) ------------------------------------------------------------------------------
     for _ in range(args.warmup):
         step()
     drain()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -314,36 +384,72 @@ def main():
         step()
     drain()
     ev1.record()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if distributed:
-        tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
+    fence()
+    wall = max_over_ranks(time.perf_counter() - t0)
 
-    # dominant kernel duration: HIP events on the launch stream around each of K launches (second pass,
-    # kernel only, so that the mean/all-reduce tail is not attributed to it)
-    kev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    sB, sT, sV = hp.x.stride()
-    for a, b in kev:
-        a.record()
-        hp.lib.check(hp.L.e2e_ctc_loss_fwd_bwd(
-            hp.x.data_ptr(), hp.lib.F32, 0, sB, sT, sV, hp.targets.data_ptr(), hp.targets.stride(0),
-            hp.x_len.data_ptr(), hp.t_len.data_ptr(), hp.B, hp.T, hp.V, hp.S, 0,
-            hp.losses.data_ptr(), hp.grads.data_ptr(), hp.ws.data_ptr(), hp.ws.numel(),
-            hp.lib.ALGO_AUTO, hp.lib.stream_ptr(dev)))
-        b.record()
-    torch.cuda.synchronize()
-    kernel_ms = sum(a.elapsed_time(b) for a, b in kev) / len(kev)
+    # dominant kernels' duration: HIP events on the launch stream around each of K launches (second pass,
+    # kernels only, so that the mean/all-reduce tail is not attributed to them)
+    kernel_ms = time_events(torch, hp.call, args.steps)
+
+    # ---- leg 2: the metric through the Python surface (module_ms_per_step) ------------------------------------------
+    from end2end_amd import CTCLoss
+    crit = CTCLoss(reduce=True, size_average=True, blank_idx=0)
+    xm = dev_batch[0].clone().requires_grad_()
+    tg, xl, tl = dev_batch[1], dev_batch[2], dev_batch[3]
+
+    def module_step():
+        xm.grad = None
+        loss = crit(xm, tg, xl, tl)
+        loss.backward()
+        return loss
+
+    for _ in range(args.warmup):
+        module_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lm_ = module_step()
+    fence()
+    module_wall = max_over_ranks(time.perf_counter() - t0)
+    module_loss = float(lm_.item())
+    c_abi_loss = float(hp.losses.mean().item())
+
+    # ---- leg 3: one GPU's share of configs[4] (V=8000), the HBM-bound shape, at every N ------------------------------
+    wide = None
+    if not args.no_wide:
+        ww = WIDE
+        _, wb = make_batch(5000 + rank, ww["B"], ww["T"], ww["V"], ww["S"], dev)
+        wp = HotPath(wb)
+        for _ in range(2):
+            wp.call()
+        fence()
+        reps = 5
+        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            wp.call()
+        e1.record()
+        fence()
+        wwall = max_over_ranks(time.perf_counter() - t0)
+        wms = max_over_ranks(e0.elapsed_time(e1) / reps)
+        walgo = 2.0 * ww["V"] * 4 * ww["B"] * ww["T"]
+        wide = {"workload": "B=512 per GPU, T=256 V=8000 S<=64 f32 (BASELINE configs[4] sharded by utterance)",
+                "n_gpus": n_gpus, "ms": wms, "frames_per_s": n_gpus * ww["B"] * ww["T"] * reps / wwall,
+                "algorithmic_bytes_per_gpu": walgo,
+                "roofline": {"bound": "hbm", "achieved": walgo / (wms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": walgo / (wms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "note": "same C-ABI call as the headline; ms = device time per call (max over ranks), frames_per_s = "
+                        "whole job over the wall clock of %d back-to-back calls" % reps}
+        del wp, wb
+        torch.cuda.empty_cache()
 
     if rank == 0:
         total_frames = frames * n_gpus
         ms_per_step = wall * 1e3 / args.steps
         algo_bytes = 2.0 * w["V"] * 4 * frames          # per launch (one GPU's batch)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        copy_gbs = measured_copy_gbs(torch, dev)
         out = {
             "metric": "ctc_fwd_bwd_frames_per_sec", "value": total_frames * args.steps / wall, "unit": "frames/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -354,17 +460,24 @@ def main():
                        "sharding": "utterances, %d per GPU" % w["B"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": recorded_traffic(w["name"]),
-                         "kernel": "e2e_ctc_loss_fwd_bwd = ctc_fast_chain_kernel + ctc_fast_segment_kernel (both counted)",
+                         "peak_measured": copy_gbs, "frac_of_measured": achieved / copy_gbs,
+                         "kernel": "e2e_ctc_loss_fwd_bwd: every kernel of the call counted",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
             "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
+            "module_ms_per_step": module_wall * 1e3 / args.steps,
+            "module_frames_per_s": total_frames * args.steps / module_wall,
+            "module_api": "loss = end2end_amd.CTCLoss(reduce=True, size_average=True)(logits, targets, lengths...); "
+                          "loss.backward()  (same batch; loss %.6f vs C-ABI %.6f)" % (module_loss, c_abi_loss),
         }
+        if wide is not None:
+            out["wide_alphabet"] = wide
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(host_batch, frames)
+            out["cpu_baseline"] = cpu_baseline_loss(host_batch, frames)
         if n_gpus == 1 and not args.no_decode:
-            out["decode"] = decode_numbers(dev)
-            out["wide_alphabet"] = wide_alphabet_numbers(dev)
+            out["decode"] = decode_numbers(dev, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -54,13 +54,18 @@ def brute_force(lp, blank, space_id, wip):
 
 def main():
     cases = []
-    specs = [  # (name, T, V, blank, space_id, wip, sharpness)
-        ("t4_v4", 4, 4, 0, -1, 0.0, 1.0), ("t5_v4", 5, 4, 0, -1, 0.0, 1.5), ("t6_v4", 6, 4, 0, -1, 0.0, 0.7),
+    specs = [  # (name, T, V, blank, space_id, wip, sharpness); the first group needs a beam of <= 255 prefixes
+        ("t4_v4", 4, 4, 0, -1, 0.0, 1.0), ("t4_v4_blank3_space_wip1", 4, 4, 3, 1, 1.0, 0.5),
+        ("t4_v4_flat_space_wip05", 4, 4, 0, 2, 0.5, 0.15), ("t5_v3", 5, 3, 0, -1, 0.0, 0.6),
+        ("t6_v3_space_wip1", 6, 3, 0, 2, 1.0, 0.5), ("t6_v3_blank2", 6, 3, 2, -1, 0.0, 0.3),
+        ("t7_v3", 7, 3, 0, -1, 0.0, 0.9), ("t7_v3_blank1_space_wip1", 7, 3, 1, 2, 1.0, 0.4),
+        ("t7_v3_flat", 7, 3, 0, -1, 0.0, 0.1), ("t3_v6", 3, 6, 5, -1, 0.0, 1.0), ("t3_v6_space_wip2", 3, 6, 0, 3, 2.0, 0.3),
+        ("t2_v12", 2, 12, 0, -1, 0.0, 0.5),
+        # wider than one workgroup's beam today: pinned on the CPU oracle, the GPU runs them at a narrower beam
+        ("t5_v4", 5, 4, 0, -1, 0.0, 1.5), ("t6_v4", 6, 4, 0, -1, 0.0, 0.7),
         ("t6_v4_blank2", 6, 4, 2, -1, 0.0, 1.0), ("t6_v4_space_wip1", 6, 4, 0, 3, 1.0, 0.8),
         ("t6_v4_space_wip05", 6, 4, 0, 2, 0.5, 0.5), ("t4_v5_space_wip2", 4, 5, 0, 4, 2.0, 0.6),
-        ("t7_v3", 7, 3, 0, -1, 0.0, 0.9), ("t7_v3_blank1_space_wip1", 7, 3, 1, 2, 1.0, 0.4),
         ("t6_v4_flat", 6, 4, 0, -1, 0.0, 0.15), ("t6_v4_space_wip1_flat", 6, 4, 0, 1, 1.0, 0.2),
-        ("t3_v6", 3, 6, 5, -1, 0.0, 1.0),
     ]
     for name, T, V, blank, space_id, wip, sharp in specs:
         seed = 0

@@ -169,7 +169,7 @@ def test_out_of_range_targets_poison_not_crash(algo, V):
     for dt in (torch.float32, torch.float64):
         if algo == _lib.ALGO_FAST and dt != torch.float32:
             continue
-        losses, grads = U.c_abi_loss(x.to(dt), tg, [9, 9, 9, 9], [3, 3, 3, 2], 0, False, algo)
+        losses, grads = U.c_abi_loss(x.to(dt), tg, [9, 9, 9, 9], [3, 3, 3, 1], 0, False, algo)
         assert np.isfinite(losses[0]) and np.isfinite(grads[0]).all()
         assert np.isnan(losses[1]) and np.isnan(losses[2]) and np.isnan(grads[1]).all() and np.isnan(grads[2]).all()
         assert np.isfinite(losses[3]) and np.isfinite(grads[3]).all()      # the bad entries lie beyond t_len
