@@ -99,19 +99,24 @@ class HotPath:
         self.means = torch.zeros((2, self.bucket), dtype=torch.float32, device=self.dev)   # double-buffered buckets
         self.k = 0
 
-    def call(self):
+    def call(self, mean_out=None):
+        """One e2e_ctc_loss_fwd_bwd_opt launch; mean_out: a 1-element device tensor that receives the batch-mean loss
+        (written by the tail of the call's last kernel) and makes the gradient that of the mean (grad_scale = 1/B)."""
+        import ctypes
         sB, sT, sV = self.x.stride()
-        self.lib.check(self.L.e2e_ctc_loss_fwd_bwd(
+        o = self.lib.LossOpts(1.0 / self.B if mean_out is not None else 1.0,
+                              mean_out.data_ptr() if mean_out is not None else None,
+                              self.lib.REDUCE_MEAN if mean_out is not None else self.lib.REDUCE_NONE)
+        self.lib.check(self.L.e2e_ctc_loss_fwd_bwd_opt(
             self.x.data_ptr(), self.lib.F32, 0, sB, sT, sV,
             self.targets.data_ptr(), self.targets.stride(0), self.x_len.data_ptr(), self.t_len.data_ptr(),
             self.B, self.T, self.V, self.S, self.blank,
             self.losses.data_ptr(), self.grads.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
-            self.lib.ALGO_AUTO, self.lib.stream_ptr(self.dev)))
+            self.lib.ALGO_AUTO, self.lib.stream_ptr(self.dev), ctypes.byref(o)))
 
     def step(self):
-        self.call()
-        m = self.means[(self.k // self.bucket) & 1, self.k % self.bucket]
-        self.torch.mean(self.losses, dim=0, out=m)
+        m = self.means[(self.k // self.bucket) & 1, self.k % self.bucket: self.k % self.bucket + 1]
+        self.call(m)
         self.k += 1
         return m
 
@@ -130,12 +135,17 @@ def time_events(torch, fn, reps):
 def measured_copy_gbs(torch, dev):
     """On-box HBM rate of a plain device copy (read + write bytes per second), the achievable ceiling the guide quotes
     beside the 8 TB/s spec."""
+    from end2end_amd import _lib
+    L = _lib.load()
     n = 1 << 28                                             # 1 GiB of f32 each way
     src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
     dst = torch.empty_like(src)
+
+    def copy():
+        _lib.check(L.e2e_debug_stream_copy(dst.data_ptr(), src.data_ptr(), n * 4, _lib.stream_ptr(dev)))
     for _ in range(3):
-        dst.copy_(src)
-    ms = time_events(torch, lambda: dst.copy_(src), 10)
+        copy()
+    ms = min(time_events(torch, copy, 10), time_events(torch, lambda: dst.copy_(src), 10))
     del src, dst
     return 2.0 * n * 4 / (ms * 1e-3) / 1e9
 
@@ -389,7 +399,7 @@ def main():
 
     # dominant kernels' duration: HIP events on the launch stream around each of K launches (second pass,
     # kernels only, so that the mean/all-reduce tail is not attributed to them)
-    kernel_ms = time_events(torch, hp.call, args.steps)
+    kernel_ms = time_events(torch, lambda: hp.call(hp.means[0, :1]), args.steps)
 
     # ---- leg 2: the metric through the Python surface (module_ms_per_step) ------------------------------------------
     from end2end_amd import CTCLoss
@@ -412,7 +422,7 @@ def main():
     fence()
     module_wall = max_over_ranks(time.perf_counter() - t0)
     module_loss = float(lm_.item())
-    c_abi_loss = float(hp.losses.mean().item())
+    c_abi_loss = float(hp.means[0, 0].item())
 
     # ---- leg 3: one GPU's share of configs[4] (V=8000), the HBM-bound shape, at every N ------------------------------
     wide = None
@@ -455,7 +465,8 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["name"], "B_per_gpu": w["B"], "T": w["T"], "V": w["V"], "S_max": w["S"],
-                       "input": "raw logits (log-softmax fused)", "api": "C ABI e2e_ctc_loss_fwd_bwd + mean"
+                       "input": "raw logits (log-softmax fused)",
+                       "api": "C ABI e2e_ctc_loss_fwd_bwd_opt (losses, d mean-loss / d logits, mean loss: one call)"
                        + (" + RCCL all_reduce of the per-step losses, bucketed by 8 steps" if distributed else ""),
                        "sharding": "utterances, %d per GPU" % w["B"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

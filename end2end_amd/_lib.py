@@ -22,6 +22,14 @@ _lib = None
 _lock = threading.Lock()
 
 
+REDUCE_NONE, REDUCE_SUM, REDUCE_MEAN = 0, 1, 2
+
+
+class LossOpts(C.Structure):
+    """e2e_ctc_loss_opts (include/e2e_ctc.h)."""
+    _fields_ = [("grad_scale", C.c_double), ("reduced", C.c_void_p), ("reduction", C.c_int)]
+
+
 class E2EError(RuntimeError):
     """An error reported by the native library (message from e2e_last_error())."""
 
@@ -48,6 +56,8 @@ def load():
         L.e2e_ctc_loss_fwd_bwd.argtypes = [vp, C.c_int, C.c_int, i64, i64, i64, i64p, i64, i64p, i64p,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            vp, vp, vp, C.c_size_t, C.c_int, vp]
+        L.e2e_ctc_loss_fwd_bwd_opt.restype = C.c_int
+        L.e2e_ctc_loss_fwd_bwd_opt.argtypes = L.e2e_ctc_loss_fwd_bwd.argtypes + [C.POINTER(LossOpts)]
         L.e2e_ctc_scale_grads.restype = C.c_int
         L.e2e_ctc_scale_grads.argtypes = [vp, C.c_int, vp, C.c_int, i64, vp]
         L.e2e_ctc_greedy.restype = C.c_int
@@ -70,6 +80,8 @@ def load():
         L.e2e_ctc_beam.argtypes = [vp, C.c_int, i64, i64, i64, i64p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_double,
                                    i64p, i64, i64p, vp, C.c_size_t, vp]
+        L.e2e_debug_stream_copy.restype = C.c_int
+        L.e2e_debug_stream_copy.argtypes = [vp, vp, C.c_size_t, vp]
         if L.e2e_ctc_abi_version() != ABI_VERSION:
             raise ImportError("end2end_amd: %s has ABI %d, expected %d" % (LIB_PATH, L.e2e_ctc_abi_version(), ABI_VERSION))
         _lib = L

@@ -28,15 +28,46 @@ namespace {
 template <typename IO>
 __global__ void scale_rows_kernel(IO* g, const IO* s, int64_t row_elems) {
   const IO f = s[blockIdx.y];
+  if (f == (IO)1) return;                  // nothing to do for this row: no pass over it
   IO* row = g + (size_t)blockIdx.y * (size_t)row_elems;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_elems; i += (int64_t)gridDim.x * blockDim.x)
     row[i] *= f;
 }
+
+// sum / mean of the B losses in a fixed order (deterministic), f64 accumulation
+template <typename IO>
+__global__ __launch_bounds__(256) void reduce_losses_kernel(const IO* losses, int B, int mean, IO* out) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) s += (double)losses[b];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = (IO)(mean ? part[0] / (double)B : part[0]);
+}
 }  // namespace
+
+int launch_reduce_losses(const LossArgs& a) {
+  if (!a.reduced || a.reduction == E2E_REDUCE_NONE || a.B == 0) return E2E_OK;
+  const int mean = a.reduction == E2E_REDUCE_MEAN;
+  if (a.dtype == E2E_F32)
+    hipLaunchKernelGGL(reduce_losses_kernel<float>, dim3(1), dim3(256), 0, a.stream, (const float*)a.losses, a.B, mean, (float*)a.reduced);
+  else
+    hipLaunchKernelGGL(reduce_losses_kernel<double>, dim3(1), dim3(256), 0, a.stream, (const double*)a.losses, a.B, mean, (double*)a.reduced);
+  E2E_HIP_CHECK(hipGetLastError(), "reduce_losses_kernel launch");
+  return E2E_OK;
+}
 
 int launch_scale(void* grads, int dtype, const void* scale, int B, int64_t row_elems, hipStream_t stream) {
   if (B == 0 || row_elems == 0) return E2E_OK;
-  int gx = (int)((row_elems + 255) / 256); if (gx > 64) gx = 64;
+  // enough blocks to fill the chip whatever the split into rows is (B = 1: one scalar for the whole tensor)
+  int64_t want = (row_elems + 1023) / 1024;
+  const int64_t cap = B >= 64 ? 64 : 4096 / B;
+  if (want > cap) want = cap;
+  const int gx = (int)(want < 1 ? 1 : want);
   if (dtype == E2E_F32)
     hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(gx, B), dim3(256), 0, stream,
                        (float*)grads, (const float*)scale, row_elems);
@@ -47,9 +78,34 @@ int launch_scale(void* grads, int dtype, const void* scale, int B, int64_t row_e
   return E2E_OK;
 }
 
+// Streaming copy used by bench.py to measure the box's achievable HBM rate (roofline.peak_measured): one 16-byte
+// non-temporal load and store per lane and iteration, 8 in flight, the grid sized to the chip.
+typedef float copy_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(copy_f4* __restrict__ dst, const copy_f4* __restrict__ src, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    copy_f4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(&src[i + u * stride]);
+#pragma unroll
+    for (int u = 0; u < 8; u++) __builtin_nontemporal_store(v[u], &dst[i + u * stride]);
+  }
+  for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+}
+
 }  // namespace e2e
 
 using namespace e2e;
+
+// diagnostics, not part of include/e2e_ctc.h: dst[0..bytes) = src[0..bytes), bytes a multiple of 16
+extern "C" int e2e_debug_stream_copy(void* dst, const void* src, size_t bytes, void* stream) {
+  if (!dst || !src || bytes % 16) { set_error("e2e_debug_stream_copy: bad argument"); return E2E_ERR_ARG; }
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
+                     (copy_f4*)dst, (const copy_f4*)src, bytes / 16);
+  E2E_HIP_CHECK(hipGetLastError(), "stream_copy_kernel launch");
+  return E2E_OK;
+}
 
 extern "C" {
 
@@ -85,6 +141,22 @@ int e2e_ctc_loss_fwd_bwd(const void* x, int dtype, int input_is_logprobs,
                          void* losses, void* grads,
                          void* workspace, size_t workspace_bytes,
                          int algo, void* stream) {
+  return e2e_ctc_loss_fwd_bwd_opt(x, dtype, input_is_logprobs, sB, sT, sV, targets, tgt_stride, x_len, t_len, B, T, V,
+                                  Smax, blank, losses, grads, workspace, workspace_bytes, algo, stream, nullptr);
+}
+
+int e2e_ctc_loss_fwd_bwd_opt(const void* x, int dtype, int input_is_logprobs,
+                             int64_t sB, int64_t sT, int64_t sV,
+                             const int64_t* targets, int64_t tgt_stride,
+                             const int64_t* x_len, const int64_t* t_len,
+                             int B, int T, int V, int Smax, int blank,
+                             void* losses, void* grads,
+                             void* workspace, size_t workspace_bytes,
+                             int algo, void* stream, const e2e_ctc_loss_opts* opts) {
+  if (opts && (opts->reduction < E2E_REDUCE_NONE || opts->reduction > E2E_REDUCE_MEAN ||
+               (opts->reduction != E2E_REDUCE_NONE && !opts->reduced))) {
+    set_error("bad e2e_ctc_loss_opts: reduction %d, reduced %p", opts->reduction, opts->reduced); return E2E_ERR_ARG;
+  }
   if (dtype != E2E_F32 && dtype != E2E_F64) { set_error("dtype must be E2E_F32 or E2E_F64"); return E2E_ERR_ARG; }
   if (B < 0 || T < 1 || V < 1 || Smax < 0) { set_error("bad sizes B=%d T=%d V=%d Smax=%d", B, T, V, Smax); return E2E_ERR_ARG; }
   if (blank < 0 || blank >= V) { set_error("blank=%d outside [0,%d)", blank, V); return E2E_ERR_ARG; }
@@ -98,9 +170,10 @@ int e2e_ctc_loss_fwd_bwd(const void* x, int dtype, int input_is_logprobs,
   if (workspace && workspace_bytes >= (aligned - base)) { workspace_bytes -= (aligned - base); workspace = reinterpret_cast<void*>(aligned); }
   LossArgs a{x, dtype, input_is_logprobs ? 1 : 0, sB, sT, sV, targets, tgt_stride, x_len, t_len,
              B, T, V, Smax, blank, losses, grads, workspace, workspace_bytes, (hipStream_t)stream};
+  if (opts) { a.grad_scale = opts->grad_scale; a.reduced = opts->reduced; a.reduction = opts->reduction; }
   const int r = resolve_algo(algo, dtype, T, V, Smax);
-  if (r == E2E_ALGO_EXACT) return launch_exact(a);
-  if (use_wide(dtype, T, V, Smax)) return launch_wide(a, r == E2E_ALGO_AUTO);
+  if (r == E2E_ALGO_EXACT) { const int rc = launch_exact(a); return rc != E2E_OK ? rc : launch_reduce_losses(a); }
+  if (use_wide(dtype, T, V, Smax)) { const int rc = launch_wide(a, r == E2E_ALGO_AUTO); return rc != E2E_OK ? rc : launch_reduce_losses(a); }
   if (r == E2E_ALGO_FAST) {
     if (!fast_supported(T, V, Smax, dtype)) { set_error("fast CTC path does not support this shape/dtype"); return E2E_ERR_UNSUPPORTED; }
     return launch_fast(a, false);

@@ -27,7 +27,14 @@ struct LossArgs {
   void* losses; void* grads;
   void* ws; size_t ws_bytes;
   hipStream_t stream;
+  // e2e_ctc_loss_opts (include/e2e_ctc.h): every gradient element is multiplied by grad_scale as it is written;
+  // `reduced` (one element of the I/O dtype, may be null) receives the sum / mean of the B losses
+  double grad_scale = 1.0;
+  void* reduced = nullptr;
+  int reduction = 0;
 };
+// sum / mean of the losses by one small launch (paths that have no tail to fold it into)
+int launch_reduce_losses(const LossArgs& a);
 
 // Exponential tilt of the fast path's scaled lattice (rows hold alpha[j] r^j and beta[j] r^(L-1-j)); shared by the
 // kernels that produce and that consume its checkpoints.  See LaneCells in ctc_loss_fast.hip.
@@ -41,6 +48,7 @@ constexpr int kFastSeg = 16;       // steps between two checkpoints of the fast 
 // What the flagged-utterance launch needs to redo only the SECOND kernel of the fast path in f64 (an utterance whose
 // f32 segment kernel ran out of range keeps its f64 chains' results: checkpoints, probabilities, loss).
 struct FastRetry {
+  int* ctl;                        // the fast path's control words (see FastParams::ctl)
   const float* ytab; const float* ckA; const float* ckQ; const short* ckE; const int* cumA; const int* cumB;
   const double* logz;              // [B][2] the chains' log Z (alpha side, beta side)
   int NS, NB, CELLS, PPL;

@@ -30,6 +30,9 @@ struct ExactParams {
   double* ws_lse;     // [B][T] row log-sum-exp (logits mode)
   const int* flags;   // per-utterance "redo me" words written by the fast path (mode != 0)
   int mode;           // 0: every utterance; 1: only flagged ones; 2: poison flagged ones, compute nothing
+  int* ctl;           // flagged modes: the fast path's control words (0: tickets of this launch's workgroups)
+  double gscale;      // every gradient element is multiplied by this as it is written
+  void* reduced; int reduction;   // flagged modes: optional sum / mean of the losses, written by the last workgroup
   int has_retry; FastRetry retry;   // mode 1: the fast path's checkpoints, for the f64 redo of its second kernel
 };
 
@@ -230,7 +233,7 @@ __device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, in
       for (int v = lane; v < V; v += 64) {
         double pv = post[tt * V + v];
         if (v == blank) pv += blanksum[tt];
-        grads[(size_t)(t0 + tt) * V + v] = (IO)(y(t0 + tt, v) - pv * inv);
+        grads[(size_t)(t0 + tt) * V + v] = (IO)((y(t0 + tt, v) - pv * inv) * p.gscale);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -432,7 +435,7 @@ __device__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, 
       for (int v = tid; v < V; v += kThreads) {
         // blank column = even cells (+ target cells whose label equals the blank id, red[8])
         const double pv = (v == blank) ? red[9] + red[8] : post[v];
-        grow[v] = (IO)(exp((double)xrow[(int64_t)v * p.sV] - rl) - pv);
+        grow[v] = (IO)((exp((double)xrow[(int64_t)v * p.sV] - rl) - pv) * p.gscale);
       }
     }
     // next iteration's writes to psorted/red/post happen after its own first barrier or touch
@@ -443,7 +446,7 @@ __device__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, 
   // ---- padded frames t >= T: exp(lp) in log-prob mode (Q1), 0 for fused logits ----
   for (size_t i = (size_t)T * V + tid; i < (size_t)Tmax * V; i += kThreads) {
     const int t = (int)(i / V), v = (int)(i % V);
-    grads[i] = p.logprobs ? (IO)exp((double)x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : (IO)0;
+    grads[i] = p.logprobs ? (IO)(exp((double)x[(int64_t)t * p.sT + (int64_t)v * p.sV]) * p.gscale) : (IO)0;
   }
 }
 
@@ -455,17 +458,48 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   if (p.mode != 0) {
     // flagged mode, the usual case of nothing to do: all of this workgroup's flags in ONE round trip instead of one per
     // utterance of its stride (8 dependent loads and barriers at B = 256: 5 us of every call)
+    // flagged mode, the usual case of nothing to do: the whole flag vector in ONE round trip per workgroup (every
+    // workgroup looks at all of it, so that all of them agree on whether anything is flagged)
     __shared__ int any;
     if (threadIdx.x == 0) any = 0;
     __syncthreads();
-    for (int b = blockIdx.x + threadIdx.x * gridDim.x; b < p.B; b += kThreads * gridDim.x)
+    for (int b = threadIdx.x; b < p.B; b += kThreads)
       if (p.flags[b] != 0) any = 1;
     __syncthreads();
-    if (!any) return;
+    const bool reduce = p.reduced && p.reduction != E2E_REDUCE_NONE;
+    if (!any) {
+      // nothing flagged: the losses the fast path wrote are final; workgroup 0 writes their sum / mean (fixed order)
+      if (reduce && blockIdx.x == 0 && threadIdx.x < 64) {
+        const IO* losses = reinterpret_cast<const IO*>(p.losses);
+        double s = 0.0;
+        for (int b = threadIdx.x; b < p.B; b += 64) s += (double)losses[b];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (threadIdx.x == 0) *reinterpret_cast<IO*>(p.reduced) = (IO)(p.reduction == E2E_REDUCE_MEAN ? s / (double)p.B : s);
+      }
+      return;
+    }
   }
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     ctc_exact_one<IO>(p, smem, b, blockIdx.x);
     __syncthreads();                       // LDS is reused by the next utterance
+  }
+  if (p.mode != 0 && p.reduced && p.reduction != E2E_REDUCE_NONE) {
+    // flagged utterances have their final losses now: the last workgroup to get here reduces all B of them
+    // (release / acquire at agent scope: the losses other workgroups stored must have left their XCD's L2)
+    __shared__ int s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&p.ctl[0], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x < 64) {
+      const IO* losses = reinterpret_cast<const IO*>(p.losses);
+      double s = 0.0;
+      for (int b = threadIdx.x; b < p.B; b += 64) s += (double)__hip_atomic_load(&losses[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (threadIdx.x == 0) *reinterpret_cast<IO*>(p.reduced) = (IO)(p.reduction == E2E_REDUCE_MEAN ? s / (double)p.B : s);
+    }
   }
 }
 
@@ -516,6 +550,9 @@ int launch_exact_flagged(const LossArgs& a, const int* flags, int mode, const Fa
   p.targets = a.targets; p.tgt_stride = a.tgt_stride; p.x_len = a.x_len; p.t_len = a.t_len;
   p.B = a.B; p.T = a.T; p.V = a.V; p.Smax = a.Smax; p.Lmax = 2 * a.Smax + 1; p.blank = a.blank;
   p.losses = a.losses; p.grads = a.grads; p.flags = flags; p.mode = mode;
+  p.ctl = retry ? retry->ctl : nullptr;
+  p.gscale = a.grad_scale; p.reduced = mode != 0 ? a.reduced : nullptr; p.reduction = a.reduction;
+  if (mode != 0 && !p.ctl) { set_error("internal: flagged exact launch without control words"); return E2E_ERR_ARG; }
   p.has_retry = (mode == 1 && retry && a.dtype == E2E_F32) ? 1 : 0;
   if (p.has_retry) p.retry = *retry; else memset(&p.retry, 0, sizeof(p.retry));
   p.ws_alpha = reinterpret_cast<double*>(a.ws);

@@ -58,6 +58,8 @@ struct FastParams {
   int* flags;      // [B]       != 0: redo with the exact kernel
   unsigned* cinfo; // [B][CELLS/2]  per label pair: label | sorted slot << 8 | alpha skip << 16 | beta skip << 17
   int* lstart;     // [B][130]  first label-sorted slot of every label (V+1 entries used)
+  int* ctl;        // [4]  0: fallback workgroups that have finished (F1 clears it; the last one reduces the losses)
+  float gscale;    // every gradient element is multiplied by this as it is written (e2e_ctc_loss_opts.grad_scale)
   int NS, NB, CELLS;
 };
 
@@ -716,6 +718,7 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   const int V = p.V;
   const F1Lds lds(smem, V);
 
+  if (b == 0 && tid < 4) p.ctl[tid] = 0;     // (this kernel ends before the fallback launch, which counts there, starts)
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
   if (bad) {                       // the exact kernel poisons this utterance
@@ -867,7 +870,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
       for (int k = 0; k < kHalf; k++) {
         if (FULL || k < rows) {
           const float pv = (pre_hi[k * PROW] - pre_lo[k * PROW]) + gl.isblank[s] * btot8[k];
-          const float g = yrow[k] - pv * __builtin_amdgcn_rcpf(st8[k]);
+          const float g = (yrow[k] - pv * __builtin_amdgcn_rcpf(st8[k])) * p.gscale;
           if (v < V) grads[(size_t)k * V + v] = g;
         }
       }
@@ -1124,8 +1127,7 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
 }
 
 template <int PPL>
-__global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char* smem) {
   const int b = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
   const int V = p.V, Tmax = p.T, t0 = seg * kSeg;
   const F2Lds<PPL> lds(smem, V);
@@ -1171,7 +1173,7 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
     const int tend = min(t0 + kSeg, Tmax);
     for (int t = max(t0, T); t < tend; t++)
       for (int v = lane; v < V; v += 64)
-        grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) : 0.f;
+        grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) * p.gscale : 0.f;
   }
   if (t0 >= T) return;
   const int n = min(t0 + kSeg, T) - t0;
@@ -1229,6 +1231,17 @@ __global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
   }
 }
 
+// (Folding the flagged-utterance scan and the loss reduction into this kernel's tail -- every wave takes a ticket, the
+// last one scans the flags -- was built and measured: the ticket needs the wave's flag atomics ordered before it, i.e.
+// the wave has to wait for its outstanding gradient stores instead of retiring under them, 65 -> 97 us for the kernel;
+// with a release fence at agent scope, which is an L2 write-back on this multi-XCD part, 411 us.  An empty launch costs
+// ~4.5 us here whatever it does, so the scan stays in the fallback launch, which also writes the optional reduction.)
+template <int PPL>
+__global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  segment_wave<PPL>(p, smem);
+}
+
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds1 = F1Lds::bytes(p.V);
@@ -1251,7 +1264,7 @@ int ppl_for(int Smax) {
 }
 
 struct FastLayout {
-  size_t ytab, ckA, ckQ, ckE, cumA, cumB, logz, zt2, flags, cinfo, lstart, total;
+  size_t ytab, ckA, ckQ, ckE, cumA, cumB, logz, zt2, flags, cinfo, lstart, ctl, total;
   int NS, NB, CELLS;
 };
 
@@ -1273,6 +1286,7 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
   l.flags = o; o += align_up((size_t)B * sizeof(int), 256);
   l.cinfo = o; o += align_up((size_t)B * (l.CELLS / 2) * sizeof(unsigned), 256);
   l.lstart = o; o += align_up((size_t)B * 130 * sizeof(int), 256);
+  l.ctl = o; o += 256;
   l.total = o;
   return l;
 }
@@ -1309,6 +1323,8 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.zt2 = reinterpret_cast<double*>(ws + l.zt2);
   p.logz = reinterpret_cast<double*>(ws + l.logz); p.flags = reinterpret_cast<int*>(ws + l.flags);
   p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart);
+  p.ctl = reinterpret_cast<int*>(ws + l.ctl);
+  p.gscale = (float)a.grad_scale;
   p.NS = l.NS; p.NB = l.NB; p.CELLS = l.CELLS;
   int rc;
   switch (ppl_for(a.Smax)) {
@@ -1323,7 +1339,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   // mode 1: redo flagged utterances exactly; mode 2: no fallback requested -> poison them
   FastRetry rt;
   rt.ytab = p.ytab; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.cumA = p.cumA; rt.cumB = p.cumB;
-  rt.NS = p.NS; rt.NB = p.NB; rt.CELLS = p.CELLS; rt.PPL = ppl_for(a.Smax); rt.logz = p.logz;
+  rt.NS = p.NS; rt.NB = p.NB; rt.CELLS = p.CELLS; rt.PPL = ppl_for(a.Smax); rt.logz = p.logz; rt.ctl = p.ctl;
   return launch_exact_flagged(e, p.flags, fallback_to_exact ? 1 : 2, &rt);
 }
 

@@ -25,6 +25,7 @@ struct WideParams {
   const float* x; int64_t sB, sT, sV; int logprobs;
   const int64_t* targets; int64_t tgt_stride; const int64_t* x_len; const int64_t* t_len;
   int B, T, V, Smax, VC, blank;
+  float gscale;         // every gradient element is multiplied by this as it is written
   float* grads; float* losses;
   int64_t* targets_c;   // [B][Smax]  compact id of target i
   int* clabel;          // [B][VC]    original label of compact column k (-1: unused); column VC-1 is the blank
@@ -79,8 +80,9 @@ __global__ __launch_bounds__(256) void wide_compact_kernel(WideParams p) {
       const int c = cid[rep[i]];
       // a target equal to the blank id, or outside the alphabet, keeps the reference's semantics by mapping to the
       // compact blank column: the lattice kernels then hand the utterance to the exact path (ctc_loss.cpp:53,109-113)
-      out = (li == p.blank || li < 0 || li >= p.V) ? p.VC - 1 : c;
-      if (rep[i] == i && out != p.VC - 1) p.clabel[(size_t)b * p.VC + c] = li;
+      out = li == p.blank ? p.VC - 1 : c;
+      if (li < 0 || li >= p.V) out = p.VC;       // outside the alphabet: stays outside the compact one (-> NaN, e2e_ctc.h)
+      if (rep[i] == i && out < p.VC - 1) p.clabel[(size_t)b * p.VC + c] = li;
     }
     p.targets_c[(size_t)b * p.Smax + i] = out;
   }
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
         const int l = cl[k];
         if (l >= 0) {
           const float xl = xr[(int64_t)l * p.sV] - lse;
-          fix[u] = exp_acc(xl) - (exp_acc(xl - sh) - gc[k]);
+          fix[u] = (exp_acc(xl) - (exp_acc(xl - sh) - gc[k])) * p.gscale;
           fixcol[u] = l;
         }
       }
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           const vf4 o = {exp_acc(v[u].x - lse), exp_acc(v[u].y - lse), exp_acc(v[u].z - lse), exp_acc(v[u].w - lse)};
-          __builtin_nontemporal_store(o, &g4[i + 64 * u]);
+          __builtin_nontemporal_store(o * p.gscale, &g4[i + 64 * u]);
         }
       }
       for (; i + 64 < n4; i += 128) {
@@ -235,18 +237,18 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
           const vf4 o = {exp_acc(v[u].x - lse), exp_acc(v[u].y - lse), exp_acc(v[u].z - lse), exp_acc(v[u].w - lse)};
-          __builtin_nontemporal_store(o, &g4[i + 64 * u]);
+          __builtin_nontemporal_store(o * p.gscale, &g4[i + 64 * u]);
         }
       }
       for (; i < n4; i += 64) {
         const vf4 v = x4[i];
         const vf4 o = {exp_acc(v.x - lse), exp_acc(v.y - lse), exp_acc(v.z - lse), exp_acc(v.w - lse)};
-        g4[i] = o;
+        g4[i] = o * p.gscale;
       }
     }
-    for (int i = (n4 << 2) + lane; i < p.V; i += 64) gr[i] = poison ? qnan : (zero ? 0.f : exp_acc(xr[i] - lse));
+    for (int i = (n4 << 2) + lane; i < p.V; i += 64) gr[i] = poison ? qnan : (zero ? 0.f : exp_acc(xr[i] - lse) * p.gscale);
   } else {
-    for (int i = lane; i < p.V; i += 64) gr[i] = poison ? qnan : (zero ? 0.f : exp_acc(xr[(int64_t)i * p.sV] - lse));
+    for (int i = lane; i < p.V; i += 64) gr[i] = poison ? qnan : (zero ? 0.f : exp_acc(xr[(int64_t)i * p.sV] - lse) * p.gscale);
   }
   if (live) {
     // the dense row above and these columns are written by different lanes of this wave: order them
@@ -315,11 +317,12 @@ void wide_rows_dense_kernel(WideParams p) {
     }
     sum = wave_sum_f(sum);
     const float inv = 1.f / sum;
+    const float invg = inv * p.gscale;
     lse = M + logf(sum);
 #pragma unroll
     for (int u = 0; u < NV4; u++) {
-      if (64 * u + 64 <= n4) __builtin_nontemporal_store(v[u] * inv, &g4[64 * u + lane]);
-      else if (64 * u < n4) __builtin_nontemporal_store(v[u] * inv, &g4[part_idx]);
+      if (64 * u + 64 <= n4) __builtin_nontemporal_store(v[u] * invg, &g4[64 * u + lane]);
+      else if (64 * u < n4) __builtin_nontemporal_store(v[u] * invg, &g4[part_idx]);
       if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     if (lane == 0) p.lse[row] = lse;
@@ -328,8 +331,8 @@ void wide_rows_dense_kernel(WideParams p) {
     for (int u = 0; u < NV4; u++) {
       if (64 * u < n4) {
         const vf4 o = {exp_acc(v[u].x), exp_acc(v[u].y), exp_acc(v[u].z), exp_acc(v[u].w)};
-        if (64 * u + 64 <= n4) __builtin_nontemporal_store(o, &g4[64 * u + lane]);
-        else __builtin_nontemporal_store(o, &g4[part_idx]);
+        if (64 * u + 64 <= n4) __builtin_nontemporal_store(o * p.gscale, &g4[64 * u + lane]);
+        else __builtin_nontemporal_store(o * p.gscale, &g4[part_idx]);
       }
       if (u & 1) __builtin_amdgcn_sched_barrier(0);
     }
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
   const int* cl = p.clabel + (size_t)b * p.VC;
   for (int k = lane; k < p.VC; k += 64) {
     const int l = cl[k];
-    if (l >= 0) gr[l] -= exp_acc(xc[k]) - gc[k];
+    if (l >= 0) gr[l] -= (exp_acc(xc[k]) - gc[k]) * p.gscale;
   }
 }
 
@@ -420,6 +423,7 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
   p.targets = a.targets; p.tgt_stride = a.tgt_stride; p.x_len = a.x_len; p.t_len = a.t_len;
   p.B = a.B; p.T = a.T; p.V = a.V; p.Smax = a.Smax; p.VC = l.VC; p.blank = a.blank;
   p.grads = reinterpret_cast<float*>(a.grads); p.losses = reinterpret_cast<float*>(a.losses);
+  p.gscale = (float)a.grad_scale;
   p.targets_c = reinterpret_cast<int64_t*>(ws + l.targets_c); p.clabel = reinterpret_cast<int*>(ws + l.clabel);
   p.lse = reinterpret_cast<float*>(ws + l.lse); p.shift = reinterpret_cast<float*>(ws + l.shift);
   p.xc = reinterpret_cast<float*>(ws + l.xc);
@@ -446,6 +450,8 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
   c.V = l.VC; c.blank = l.VC - 1;
   c.grads = ws + l.gc;
   c.ws = ws + l.inner; c.ws_bytes = a.ws_bytes - l.inner;
+  c.grad_scale = 1.0; c.reduced = nullptr; c.reduction = 0;      // (the compact gradient stays unscaled; the losses
+                                                                  //  are corrected below, the caller reduces them after)
   const int rc = launch_fast(c, fallback_to_exact);
   if (rc != E2E_OK) return rc;
   hipLaunchKernelGGL(wide_loss_fix_kernel, dim3(a.B), dim3(64), 0, a.stream, p);

@@ -33,10 +33,15 @@ class CTCLossEngine:
         self.blank_idx = int(blank_idx)
         self.algo = algo
 
-    def compute(self, logits, targets, logits_lengths, targets_lengths, input_is_logprobs=True):
+    def compute(self, logits, targets, logits_lengths, targets_lengths, input_is_logprobs=True,
+                grad_scale=1.0, reduction=None):
         """`logits` is batch-major (B,T,V) (any strides).  With input_is_logprobs=True this is the
         reference engine: log-probabilities in, grads = exp(lp) - posterior.  With False the
-        log-softmax is fused in and grads are d loss / d logits."""
+        log-softmax is fused in and grads are d loss / d logits.
+
+        Extensions (e2e_ctc_loss_opts): `grad_scale` multiplies every gradient element as the kernel writes it;
+        `reduction` = "sum" / "mean" makes the call also return the reduced loss, written by the tail of its last
+        kernel: the result is then (losses, grads, reduced)."""
         if logits.dim() != 3:
             raise ValueError("logits must be (batch, time, alphabet)")
         src_device, src_dtype = logits.device, logits.dtype
@@ -56,8 +61,12 @@ class CTCLossEngine:
         Smax = targets.shape[1]
         losses = torch.empty(B, dtype=x.dtype, device=dev)
         grads = torch.empty((B, T, V), dtype=x.dtype, device=dev)
+        if reduction not in (None, "sum", "mean"):
+            raise ValueError("reduction must be None, 'sum' or 'mean'")
         if B == 0:
-            return losses.to(src_device, src_dtype), grads.to(src_device, src_dtype)
+            out = (losses.to(src_device, src_dtype), grads.to(src_device, src_dtype))
+            return out if reduction is None else out + (getattr(out[0], reduction)(),)
+        reduced = torch.empty((), dtype=x.dtype, device=dev) if reduction else None
         code = R.dtype_code(x.dtype)
         with torch.cuda.device(dev):
             nbytes = _C.ctc_loss_workspace_bytes(B, T, V, Smax, code, self.algo)
@@ -67,22 +76,27 @@ class CTCLossEngine:
                                 targets.data_ptr(), targets.stride(0), xl.data_ptr(), tl.data_ptr(),
                                 B, T, V, Smax, self.blank_idx,
                                 losses.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(),
-                                self.algo, R.stream_handle(dev))
+                                self.algo, R.stream_handle(dev), float(grad_scale),
+                                reduced.data_ptr() if reduction else 0,
+                                {None: _C.REDUCE_NONE, "sum": _C.REDUCE_SUM, "mean": _C.REDUCE_MEAN}[reduction])
         if src_device != dev or src_dtype != x.dtype:
             losses = losses.to(src_device, src_dtype)
             grads = grads.to(src_device, src_dtype)
-        return losses, grads
+            if reduction:
+                reduced = reduced.to(src_device, src_dtype)
+        return (losses, grads) if reduction is None else (losses, grads, reduced)
 
     @staticmethod
     def scale_grads_(grads, scale):
         """grads[b] *= scale[b] in place on the GPU (the multiply of functions/forward_backward.py:33 upstream,
-        without a second (B,T,V) tensor).  `grads` must be a contiguous CUDA tensor, `scale` a (B,) tensor."""
+        without a second (B,T,V) tensor; rows whose factor is exactly 1 are not touched).  `grads` must be a contiguous
+        CUDA tensor, `scale` a (B,) tensor -- or a single element, which then scales the whole tensor."""
         if not (grads.is_cuda and grads.is_contiguous()):
             raise ValueError("scale_grads_ needs a contiguous GPU tensor")
-        B = grads.shape[0]
         scale = scale.detach().to(device=grads.device, dtype=grads.dtype).contiguous().view(-1)
+        B = grads.shape[0] if scale.numel() != 1 else 1
         if scale.numel() != B:
-            raise ValueError("scale must have one entry per utterance")
+            raise ValueError("scale must have one entry per utterance (or a single one)")
         if grads.numel():
             with torch.cuda.device(grads.device):
                 _C.ctc_scale_grads(grads.data_ptr(), R.dtype_code(grads.dtype), scale.data_ptr(), B,

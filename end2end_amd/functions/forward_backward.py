@@ -3,8 +3,12 @@
 Same surface as the reference's ForwardBackwardLossFunction
 (pytorch_end2end/functions/forward_backward.py:4-35): forward asks the engine for
 (loss, grads) in one pass and keeps the gradient; backward scales it by grad_output.
-The extra `fused_logits` flag selects the engine mode in which log-softmax is fused into
-the kernel and the stored gradient is already d loss / d logits.
+Two optional trailing arguments extend it:
+  fused_logits  the engine fuses log-softmax into the kernel; the kept gradient is d loss / d logits;
+  reduction     "sum" / "mean": the Function returns the reduced loss itself (what the module's
+                `loss.sum()` / `loss.mean()` gives, pytorch_end2end/modules/ctc_loss.py:52-56), computed by
+                the tail of the engine's last kernel, and the kept gradient is already scaled by 1/B for
+                the mean -- the backward of the usual `loss.backward()` then has nothing left to multiply.
 
 The backward does not build a second (B,T,V) tensor: the kept gradient is scaled in place by the
 library (e2e_ctc_scale_grads; rows whose factor is exactly 1 are not touched) and handed to autograd,
@@ -17,29 +21,37 @@ from torch.autograd import Function
 
 class ForwardBackwardLossFunction(Function):
     @staticmethod
-    def forward(ctx, engine, logits, targets, logits_lengths, targets_lengths, fused_logits=False):
-        if fused_logits:
-            loss, grads = engine.compute(logits, targets, logits_lengths, targets_lengths, input_is_logprobs=False)
-        else:
-            loss, grads = engine.compute(logits, targets, logits_lengths, targets_lengths)
-        ctx.engine = engine
-        ctx.fused_logits = fused_logits
+    def _compute(engine, args, fused_logits, reduction):
+        logits, targets, logits_lengths, targets_lengths = args
+        if reduction is None and not fused_logits:         # exactly the reference's call
+            return engine.compute(logits, targets, logits_lengths, targets_lengths) + (None,)
+        kw = {"input_is_logprobs": not fused_logits}
+        if reduction is not None:
+            kw["reduction"] = reduction
+            kw["grad_scale"] = 1.0 / max(logits.shape[0], 1) if reduction == "mean" else 1.0
+            return engine.compute(logits, targets, logits_lengths, targets_lengths, **kw)
+        return engine.compute(logits, targets, logits_lengths, targets_lengths, **kw) + (None,)
+
+    @staticmethod
+    def forward(ctx, engine, logits, targets, logits_lengths, targets_lengths, fused_logits=False, reduction=None):
+        args = (logits.detach(), targets, logits_lengths, targets_lengths)
+        loss, grads, reduced = ForwardBackwardLossFunction._compute(engine, args, fused_logits, reduction)
+        ctx.engine, ctx.args = engine, args
+        ctx.fused_logits, ctx.reduction = fused_logits, reduction
         ctx.grads = grads          # plain attribute, as in the reference (no double backward)
-        ctx.args = (logits.detach(), targets, logits_lengths, targets_lengths)
-        return loss
+        return loss if reduction is None else reduced
 
     @staticmethod
     def backward(ctx, grad_output):
         grads = ctx.grads
         if grads is None:          # a retained graph walked again: the first walk gave the buffer to autograd
-            x, tg, xl, tl = ctx.args
-            grads = (ctx.engine.compute(x, tg, xl, tl, input_is_logprobs=False) if ctx.fused_logits
-                     else ctx.engine.compute(x, tg, xl, tl))[1]
+            grads = ForwardBackwardLossFunction._compute(ctx.engine, ctx.args, ctx.fused_logits, ctx.reduction)[1]
         ctx.grads = None
         if grads.is_cuda and grads.is_contiguous() and hasattr(ctx.engine, "scale_grads_"):
             ctx.engine.scale_grads_(grads, grad_output)
         else:                      # results that were moved back to a CPU source tensor
-            grads = grads * grad_output.contiguous().to(device=grads.device, dtype=grads.dtype).view(-1, 1, 1)
+            go = grad_output.contiguous().to(device=grads.device, dtype=grads.dtype)
+            grads = grads * (go.view(-1, 1, 1) if go.numel() > 1 else go)
         if grads.device != grad_output.device:
             grads = grads.to(grad_output.device)
-        return None, grads, None, None, None, None
+        return None, grads, None, None, None, None, None

@@ -39,10 +39,11 @@ class ForwardBackwardLossBase(nn.Module):
             x = F.log_softmax(x, dim=2)
         if self._time_major:
             x = x.permute(1, 0, 2)          # a strided view; the kernel reads through the strides
-        loss = ForwardBackwardLossFunction.apply(self._engine, x, targets, logits_lengths, targets_lengths, fuse)
-        if self._reduce:
-            return loss.mean() if self._size_average else loss.sum()
-        return loss
+        # reduce: the sum / mean is written by the tail of the engine's last kernel (no separate reduction) and the
+        # kept gradient is already scaled, so `loss.backward()` finds nothing left to multiply
+        reduction = ("mean" if self._size_average else "sum") if self._reduce else None
+        return ForwardBackwardLossFunction.apply(self._engine, x, targets, logits_lengths, targets_lengths, fuse,
+                                                 reduction)
 
 
 class CTCLoss(ForwardBackwardLossBase):

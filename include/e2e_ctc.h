@@ -84,7 +84,33 @@ int e2e_ctc_loss_fwd_bwd(const void* x, int dtype, int input_is_logprobs,
                          void* workspace, size_t workspace_bytes,
                          int algo, void* stream);
 
-/* grads[b,:,:] *= scale[b]  in place: the multiply of the autograd backward
+/* The same call with options (NULL = the plain call):
+ *   grad_scale  every gradient element is multiplied by it as it is written (NaN slabs stay NaN).  The module passes
+ *               1/B for reduce=True, size_average=True, so that the autograd backward of the mean
+ *               (pytorch_end2end/modules/ctc_loss.py:52-56 + functions/forward_backward.py:33) has nothing left to do.
+ *   reduced     NULL, or one element of x's dtype that receives the sum (E2E_REDUCE_SUM) or mean (E2E_REDUCE_MEAN) of
+ *               the B losses (+inf / NaN propagate as they would through torch.sum), in a fixed order (deterministic).
+ *               On the f32 small-alphabet path it is written by the launch that also looks for flagged utterances, so
+ *               the call has no launch more than without it. */
+#define E2E_REDUCE_NONE 0
+#define E2E_REDUCE_SUM 1
+#define E2E_REDUCE_MEAN 2
+typedef struct e2e_ctc_loss_opts {
+  double grad_scale;
+  void* reduced;
+  int reduction;
+} e2e_ctc_loss_opts;
+
+int e2e_ctc_loss_fwd_bwd_opt(const void* x, int dtype, int input_is_logprobs,
+                             int64_t sB, int64_t sT, int64_t sV,
+                             const int64_t* targets, int64_t tgt_stride,
+                             const int64_t* x_len, const int64_t* t_len,
+                             int B, int T, int V, int Smax, int blank,
+                             void* losses, void* grads,
+                             void* workspace, size_t workspace_bytes,
+                             int algo, void* stream, const e2e_ctc_loss_opts* opts);
+
+/* grads[b,:,:] *= scale[b]  in place (rows whose factor is exactly 1 are not touched): the multiply of the autograd backward
  * (pytorch_end2end/functions/forward_backward.py:33) without a second (B,T,V) tensor. */
 int e2e_ctc_scale_grads(void* grads, int dtype, const void* scale /* (B) same dtype */,
                         int B, int64_t row_elems /* T*V */, void* stream);

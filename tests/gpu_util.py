@@ -9,8 +9,9 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_AUTO, keep=None):
-    """x: torch tensor (B,T,V) on any device with any strides (moved to the GPU keeping its layout)."""
+def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_AUTO, keep=None, opts=None):
+    """x: torch tensor (B,T,V) on any device with any strides (moved to the GPU keeping its layout).
+    opts = (grad_scale, reduction): call e2e_ctc_loss_fwd_bwd_opt and return (losses, grads, reduced)."""
     L = _lib.load()
     d = dev()
     if not x.is_cuda:
@@ -31,13 +32,22 @@ def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_
     n = L.e2e_ctc_loss_workspace_bytes(B, T, V, Smax, code, algo)
     ws = torch.empty(n, dtype=torch.uint8, device=d)
     sB, sT, sV = x.stride()
-    _lib.check(L.e2e_ctc_loss_fwd_bwd(x.data_ptr(), code, 1 if logprobs else 0, sB, sT, sV,
-                                      targets.data_ptr(), targets.stride(0), xl.data_ptr(), tl.data_ptr(),
-                                      B, T, V, Smax, blank, losses.data_ptr(), grads.data_ptr(),
-                                      ws.data_ptr(), ws.numel(), algo, _lib.stream_ptr(d)))
+    args = (x.data_ptr(), code, 1 if logprobs else 0, sB, sT, sV,
+            targets.data_ptr(), targets.stride(0), xl.data_ptr(), tl.data_ptr(),
+            B, T, V, Smax, blank, losses.data_ptr(), grads.data_ptr(),
+            ws.data_ptr(), ws.numel(), algo, _lib.stream_ptr(d))
+    if opts is None:
+        _lib.check(L.e2e_ctc_loss_fwd_bwd(*args))
+    else:
+        reduced = torch.full((1,), 7.0, dtype=x.dtype, device=d)
+        o = _lib.LossOpts(float(opts[0]), reduced.data_ptr() if opts[1] else None, int(opts[1]))
+        import ctypes
+        _lib.check(L.e2e_ctc_loss_fwd_bwd_opt(*args, ctypes.byref(o)))
     torch.cuda.synchronize()
     if keep is not None:
         keep["workspace"] = ws              # (diagnostics read the fast path's flag words out of it)
+    if opts is not None:
+        return losses.cpu().numpy(), grads.cpu().numpy(), reduced.cpu().numpy()[0]
     return losses.cpu().numpy(), grads.cpu().numpy()
 
 

@@ -188,6 +188,48 @@ def test_scale_grads_in_place_both_dtypes():
     assert L.e2e_ctc_scale_grads(None, 9, None, 1, 1, None) == -1
 
 
+@pytest.mark.parametrize("algo", ALGOS, ids=lambda a: ALGO_IDS[a])
+@pytest.mark.parametrize("shape", ["small", "wide", "f64"])
+def test_options_grad_scale_and_fused_reduction(algo, shape):
+    """e2e_ctc_loss_fwd_bwd_opt: the gradient comes out multiplied by grad_scale (NaN slabs stay NaN) and the sum / mean of
+    the losses is written by the call itself -- on every path: fast (nothing flagged: the segment kernel's last wave;
+    something flagged: the fallback's last workgroup), exact, wide."""
+    g = torch.Generator().manual_seed(21)
+    V = 300 if shape == "wide" else 7
+    dt = torch.float64 if shape == "f64" else torch.float32
+    if algo == _lib.ALGO_FAST and shape != "small":
+        pytest.skip("E2E_ALGO_FAST proper: f32, V <= 96")
+    B, T = 6, 40
+    x = torch.randn(B, T, V, generator=g, dtype=dt)
+    tg = torch.randint(1, V, (B, 9), generator=g)
+    xl = [40, 31, 40, 12, 40, 25]
+    tl = [9, 5, 0, 9, 3, 7]
+    for feasible in (True, False):
+        if not feasible:
+            tl = [9, 5, 0, 9, 3, 7]
+            xl = [40, 31, 40, 5, 40, 25]              # utterance 3: T < S -> +inf / NaN slab (flagged on the fast path)
+        base_l, base_g = U.c_abi_loss(x, tg, xl, tl, 0, False, algo)
+        for scale, red in ((0.125, _lib.REDUCE_MEAN), (-3.0, _lib.REDUCE_SUM), (1.0, _lib.REDUCE_NONE)):
+            l2, g2, r = U.c_abi_loss(x, tg, xl, tl, 0, False, algo, opts=(scale, red))
+            assert np.array_equal(l2, base_l, equal_nan=True)
+            # (the wide path forms the label columns as softmax*s - (posterior part)*s: one more rounding of a difference)
+            U.assert_same(g2, base_g * scale, 2e-5 if dt == torch.float32 else 1e-13, 1e-8 if dt == torch.float32 else 1e-30,
+                          "scaled grads")
+            if red == _lib.REDUCE_NONE:
+                assert r == 7.0                       # untouched
+            else:
+                want = base_l.astype(np.float64).sum() / (B if red == _lib.REDUCE_MEAN else 1)
+                if np.isfinite(want):
+                    assert abs(r - want) <= (1e-6 if dt == torch.float32 else 1e-13) * abs(want)
+                else:
+                    assert (np.isnan(r) and np.isnan(want)) or r == want      # (FAST poisons what it flags: NaN)
+    # log-prob mode: padded rows are exp(lp) * scale (quirk Q1 keeps its shape)
+    lp = torch.log_softmax(x, -1)
+    l0, g0 = U.c_abi_loss(lp, tg, xl, tl, 0, True, algo)
+    l1, g1, _ = U.c_abi_loss(lp, tg, xl, tl, 0, True, algo, opts=(0.5, _lib.REDUCE_NONE))
+    U.assert_same(g1, g0 * 0.5, 2e-5 if dt == torch.float32 else 1e-13, 1e-8, "scaled grads, log-prob mode")
+
+
 def test_argument_errors_are_reported():
     L = _lib.load()
     rc = L.e2e_ctc_loss_fwd_bwd(None, 5, 1, 1, 1, 1, None, 0, None, None, 1, 1, 1, 0, 0, None, None, None, 0, 0, None)

@@ -177,6 +177,23 @@ def test_backward_scales_in_place_and_a_retained_graph_can_be_walked_again():
     assert (g1[1] == 0).all()
 
 
+@pytest.mark.parametrize("size_average", [True, False])
+def test_reduced_module_path_matches_unreduced_and_scaled_backward(size_average):
+    g = torch.Generator().manual_seed(8)
+    x0 = torch.randn(5, 30, 9, generator=g)
+    tg = torch.randint(1, 9, (5, 6), generator=g)
+    xl, tl = torch.tensor([30, 22, 30, 17, 30]), torch.tensor([6, 3, 0, 6, 5])
+    xa = x0.clone().cuda().requires_grad_()
+    xb = x0.clone().cuda().requires_grad_()
+    red = CTCLoss(reduce=True, size_average=size_average)(xa, tg, xl, tl)
+    vec = CTCLoss()(xb, tg, xl, tl)
+    want = vec.mean() if size_average else vec.sum()
+    assert red.shape == want.shape and abs(red.item() - want.item()) <= 1e-6 * abs(want.item())
+    (red * 3.0).backward()
+    (want * 3.0).backward()
+    U.assert_same(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), 1e-6, 1e-12, "input grad")
+
+
 def test_decoder_rejects_an_alphabet_that_does_not_match_the_labels():
     dec = CTCDecoder(beam_width=4, labels=["_", "a", "b"])
     with pytest.raises(ValueError, match="labels"):
