@@ -24,6 +24,7 @@
 //     checkpoints first), alpha/beta log Z mismatch, targets that contain the blank id.
 //
 // Reference semantics restated: src/losses/ctc_loss.cpp:33-117 (recurrences, loss, gradient).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -52,6 +53,9 @@ struct FastParams {
   short* ckE;      // [B][NS][2][64]  per-lane exponent of checkpoint row k (0: alpha, 1: beta); -30000 = all zero
   int* cumA;       // [B][NB]   cumA[m]: sum of the exponents the alpha chain removed at steps 8i+7, i < m (cumA[0] = 0)
   int* cumB;       // [B][NB]   cumB[m]: sum of the exponents the beta chain removed at steps 8i, i >= m (0 past the end)
+  int* trkA;       // [B][NB]   like cumA / cumB, but of a frame that follows the row's maximum block by block: the segment
+  int* trkB;       //           kernel takes the exponents it replays INSIDE a segment from these differences (the multi-wave
+                   //           chains' own frame lags by kMwLag blocks; the single-wave chains' frame is such a frame itself)
   double* zt2;     // [B]       log2 of the TILTED partition sum in the alpha chain's final units + what it removed:
                    //           what sum_j alpha_t[j]*beta_t[j] * 2^(cumA + cumB) must equal at every t
   double* logz;    // [B][2]    alpha-side / beta-side log Z
@@ -244,6 +248,7 @@ __shared__ unsigned long long s_prof_acc[8];
 #define F2_STAMP(i)
 #define F2_FLUSH
 #endif
+__host__ __device__ inline size_t align_up_dev(size_t x, size_t a) { return (x + a - 1) / a * a; }
 typedef __attribute__((address_space(3))) int lds_int;
 // (the flags must be addressed as LDS: through a generic pointer the poll becomes a flat load with sc0 sc1 and
 // an s_waitcnt vmcnt(0) that again drains the global stores)
@@ -338,7 +343,7 @@ struct F1Lds {
     took = filled + 2 * kRingBlks;
     sortcnt = took + 2;
   }
-  static size_t bytes(int V) { return sizeof(double) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * (kSyncInts + 130); }
+  __host__ __device__ static size_t bytes(int V) { return sizeof(double) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * (kSyncInts + 130); }
 };
 
 // Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
@@ -749,6 +754,387 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
 }
 
 // ============================================================================================
+// F1, multi-wave form: each chain is SPLIT OVER UP TO FOUR WAVES that run as a pipeline
+// ============================================================================================
+// A chain's speed is its instruction count per step (a lone wave issues one instruction per ~4.5 cycles), and one wave
+// carrying 8 cells per lane needs ~47 of them.  Here slice wave w of a direction holds the label pairs [64w, 64w+64)
+// -- ONE pair per lane: 5 multiply-adds, the neighbour move and its share of the bookkeeping per step -- and the
+// slices run as a systolic pipeline in the direction mass flows: alpha moves up, so slice w+1 only ever needs the
+// label cell of slice w's last lane, one value per step; beta moves down and needs the first lane's two cells of the
+// slice above.  A slice publishes those edge values a BLOCK (8 steps) at a time in an LDS ring and the consumer runs a
+// block or two behind; nothing else couples the waves:
+//   * the probability rows come from the same producer waves and ring as in the single-wave form (every slice polls
+//     the block it is about to read; the direction's LAST slice releases ring slots);
+//   * the power-of-two rescale stays COMMON to the whole row (one frame per direction, so that edge values need no
+//     conversion and the segment kernel sees the same cumA / cumB / zt2 as before).  The HEAD slice (no slice upstream:
+//     the one that runs first) decides the exponent removed at position 7 of block n and publishes it; the others,
+//     which run behind it, read it.  It takes the maximum of its own cells' exponent measured at position 6 of the same
+//     block -- at the start of an utterance all the mass is in the head, and the rescale is as immediate as in the
+//     single-wave form -- and of what the other slices measured in block n - kMwLag less what has been removed since
+//     (a dead-beat correction: plain delayed feedback oscillates).  f64 state has the range for the lag.
+// Waves of a workgroup land on the SIMDs in the order 0,2,1,3,...: waves 0-3 = alpha slices, 4-7 = beta slices, 8-11 =
+// probability rows (8,10 alpha side, 9,11 beta side), 12 = lattice description: every SIMD carries one slice of each
+// direction and one producer.
+constexpr int kMwLag = 8;        // blocks between a follower's measurement and its use (> the pipeline's skew, ~1.5 blocks per hop)
+constexpr int kMwRing = 32;      // ring depth (blocks) of the measurements and decided exponents (head <= ~kMwLag + 1 blocks ahead)
+struct MwLds {
+  double* bnd;       // [2][3][kRingBlks][2*kBlk]  dir, edge (between slices e and e+1), block slot, values
+                     //   alpha: [tt] = label cell of slice e's lane 63 BEFORE step tt of the block
+                     //   beta:  [2*tt], [2*tt+1] = blank, label cell of slice e+1's lane 0 before step tt
+  double* zfin;      // [4] alpha: label cell of each slice's lane 63 after the last step
+  int* bdone;        // [2][4]  blocks a slice has finished and published (nblk + 1: also its final values)
+  int* meas;         // [2][kMwRing][4]  exponent of the slice's largest cell, measured in block n (slot n % kMwRing)
+  int* edec;         // [2][kMwRing]     exponent the head removed at position 7 of block n
+  static constexpr int kEdgeBlk = 2 * kBlk;
+  __device__ MwLds(unsigned char* base) {
+    bnd = reinterpret_cast<double*>(base);
+    zfin = bnd + 2 * 3 * kRingBlks * kEdgeBlk;
+    bdone = reinterpret_cast<int*>(zfin + 4);
+    meas = bdone + 8;
+    edec = meas + 2 * kMwRing * 4;
+  }
+  __host__ __device__ static size_t bytes() {
+    return sizeof(double) * (2 * 3 * kRingBlks * kEdgeBlk + 4) + sizeof(int) * (8 + 2 * kMwRing * 4 + 2 * kMwRing);
+  }
+};
+constexpr int kNoMeas = -0x40000000;
+
+// F2PPL: label pairs per lane of the SEGMENT kernel, which fixes the checkpoint rows' width (128*F2PPL cells) and the
+// granularity of their block-floating-point exponents (one per segment-kernel lane = F2PPL lanes here).
+// ROLE: what is upstream / downstream of this slice is fixed at compile time -- a lone wave pays ~4.5 cycles for every
+// instruction it issues, scalar tests and branches included.
+enum { kSolo = 0, kHead = 1, kMid = 2, kTail = 3 };
+// Hand-off waits of the slices are bounded: a protocol error flags the utterance (bit 128 -> the exact kernel redoes it)
+// instead of hanging the GPU.  (~2^22 polls of >= 64 cycles: far beyond any legitimate wait.)
+#define MW_WAIT(cond)                                                                            \
+  do {                                                                                           \
+    int _spins = 0;                                                                              \
+    while (!(cond)) { __builtin_amdgcn_s_sleep(1); if (++_spins > (1 << 22)) { atomicOr(&p.flags[b], 128); break; } } \
+    asm volatile("" ::: "memory");                                                               \
+  } while (0)
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef double mw_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) mw_d2 lds_d2;     // (every LDS access of the slices is a DS operation: a wave's DS
+typedef __attribute__((address_space(3))) double lds_f64;    //  operations execute in order, which the hand-off words rely on)
+
+template <int DIR, int F2PPL, int ROLE>
+__device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int T, int S, lds_u8* L0, int ring_bytes_dir,
+                                                 int blk_bytes, int mw_off, int lane, int w, int NW) {
+  constexpr bool HEAD = ROLE == kSolo || ROLE == kHead;     // no slice upstream: polls the producers, decides exponents
+  constexpr bool TAIL = ROLE == kSolo || ROLE == kTail;     // runs last: releases ring slots, writes the tracking exponents
+  constexpr bool W0 = DIR == 0 ? HEAD : TAIL;               // slice 0
+  constexpr int NE = DIR == 0 ? 1 : 2;                      // edge values per step
+  const int V = p.V, blank = p.blank, L = 2 * S + 1;
+  const int nblk = (T + kBlk - 1) / kBlk;
+  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
+  short* cke = p.ckE + (size_t)b * p.NS * 2 * 64;
+  const int up = DIR == 0 ? w - 1 : w + 1;                 // upstream slice
+  const int tailw = DIR == 0 ? NW - 1 : 0;
+  // byte offsets into the workgroup's LDS
+  const int y_off = DIR * ring_bytes_dir;                                              // probability ring of this direction
+  const int sync_off = 2 * ring_bytes_dir;                                             // F1Lds::filled, took
+  volatile lds_int* filled = (volatile lds_int*)(L0 + sync_off) + DIR * kRingBlks;
+  volatile lds_int* took = (volatile lds_int*)(L0 + sync_off) + 2 * kRingBlks + DIR;
+  const int edge_bytes = kRingBlks * MwLds::kEdgeBlk * 8;
+  const int edge_in_off = mw_off + (DIR * 3 + (DIR == 0 ? w - 1 : w)) * edge_bytes;    // (unused by a head)
+  const int edge_out_off = mw_off + (DIR * 3 + (DIR == 0 ? w : w - 1)) * edge_bytes;   // (unused by a tail)
+  const int zfin_off = mw_off + 6 * edge_bytes;
+  volatile lds_int* bdone = (volatile lds_int*)(L0 + zfin_off + 32) + DIR * 4;
+  volatile lds_int* meas = (volatile lds_int*)(L0 + zfin_off + 32) + 8 + DIR * kMwRing * 4;
+  volatile lds_int* edec = (volatile lds_int*)(L0 + zfin_off + 32) + 8 + 2 * kMwRing * 4 + DIR * kMwRing;
+  __builtin_amdgcn_s_setprio(3);
+
+  // this lane's pair
+  const int i = 64 * w + lane;
+  const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
+  const float r = fast_tilt(S, T);
+  const double rr = (double)r, rr2 = rr * rr, inv_rr = 1.0 / rr;
+  int lab; double sk; bool bad_label = false;
+  {
+    const int li = i < S ? (int)tg[i] : -1;
+    const int lp = (i >= 1 && i - 1 < S) ? (int)tg[i - 1] : -1;
+    const int ln = (i + 1 < S) ? (int)tg[i + 1] : -1;
+    lab = (i < S && li >= 0 && li < V) ? li : V;
+    if (i < S && (li == blank || li < 0 || li >= V)) bad_label = true;
+    const bool skp = i < S && i >= 1 && li != blank && lp != li;          // ctc_loss.cpp:53-57
+    const bool skn = i + 1 < S && li != blank && ln != li;                // ctc_loss.cpp:91-96
+    sk = (DIR == 0 ? skp : skn) ? rr2 : 0.0;
+  }
+  if (DIR == 0 && __any(bad_label)) { if (lane == 0) atomicOr(&p.flags[b], 2); }
+  const bool cond = (T > 1 || L == 1);            // ctc_loss.cpp:39,76
+  const int lab_off = lab * (kRow * 8), blank_off = blank * (kRow * 8);
+
+  double c0 = 0.0, c1 = 0.0;                       // B~ of blank cell 2i, L^ of label cell 2i+1 (see chain_wave)
+  double yb_prev = 0.0;
+  int e_total = 0, e_hist[kMwLag], my_meas = kNoMeas, gabs = 0;
+#pragma unroll
+  for (int k = 0; k < kMwLag; k++) e_hist[k] = 0;
+  int* cum = (DIR == 0 ? p.cumA : p.cumB) + (size_t)b * p.NB;
+  int* trk = (DIR == 0 ? p.trkA : p.trkB) + (size_t)b * p.NB;
+  if (lane == 0) {
+    if (W0) { if (DIR == 0) cum[0] = 0; else { cum[((T - 1) >> 3) + 1] = 0; cum[((T - 1) >> 3) + 2] = 0; } }
+    if (TAIL) { if (DIR == 0) trk[0] = 0; else { trk[((T - 1) >> 3) + 1] = 0; trk[((T - 1) >> 3) + 2] = 0; } }
+  }
+
+  mw_d2 eraw[4], braw[4];                          // probabilities of this lane's label / of the blank, 2 steps each
+  mw_d2 xraw[4 * NE];                              // upstream edge values: alpha 2 steps per d2, beta 1 step (blank, label)
+#pragma unroll
+  for (int q = 0; q < 4 * NE; q++) xraw[q] = mw_d2{0.0, 0.0};
+  auto load_half = [&](int n, auto half_tag) {
+    constexpr int H = decltype(half_tag)::value;
+    const int yo = y_off + (n & (kRingBlks - 1)) * blk_bytes + 32 * H;
+    eraw[2 * H] = *(lds_d2*)(L0 + yo + lab_off); eraw[2 * H + 1] = *(lds_d2*)(L0 + yo + lab_off + 16);
+    braw[2 * H] = *(lds_d2*)(L0 + yo + blank_off); braw[2 * H + 1] = *(lds_d2*)(L0 + yo + blank_off + 16);
+    if (!HEAD) {
+      const int xo = edge_in_off + (n & (kRingBlks - 1)) * (MwLds::kEdgeBlk * 8) + 32 * NE * H;
+#pragma unroll
+      for (int q = 0; q < 2 * NE; q++) xraw[2 * NE * H + q] = *(lds_d2*)(L0 + xo + 16 * q);
+    }
+  };
+
+  auto run_block = [&](int n, auto steady_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    load_half(n, std::integral_constant<int, 1>{});
+    if (TAIL) *took = n + 1;                             // (in order behind this wave's reads above)
+    const bool want_next = n + 1 < nblk;
+    // what the first half of block n+1 waits for: the producers' block (head) or the upstream slice (which has read it)
+    int next_ready = 0, lag_done = 0;
+    if (want_next) next_ready = HEAD ? filled[(n + 1) & (kRingBlks - 1)] : bdone[up];
+    if (ROLE == kHead && n >= kMwLag) lag_done = bdone[tailw];
+    double h0[kBlk], h1[kBlk];                            // what this slice's edge lane publishes
+    const int tbase = block_time(DIR, n, 0, T);
+#pragma unroll
+    for (int tt = 0; tt < kBlk; tt++) {
+      const int t = DIR == 0 ? tbase + tt : tbase - tt;
+      const double yb = braw[tt >> 1][tt & 1], e = eraw[tt >> 1][tt & 1];
+      double x0, x1 = 0.0;                                // upstream edge values for this step
+      if (DIR == 0) x0 = xraw[tt >> 1][tt & 1]; else { x0 = xraw[tt][0]; x1 = xraw[tt][1]; }
+      if (tt == 4) {
+        if (want_next) {
+          if (HEAD) { if (__builtin_amdgcn_readfirstlane(next_ready) != n + 2) MW_WAIT(filled[(n + 1) & (kRingBlks - 1)] == n + 2); }
+          else { if (__builtin_amdgcn_readfirstlane(next_ready) < n + 2) MW_WAIT(bdone[up] >= n + 2); }
+        }
+        load_half(n + 1, std::integral_constant<int, 0>{});
+      }
+      h0[tt] = c0; h1[tt] = c1;
+      const bool live = STEADY || t < T;
+      if (live) {
+        const bool first = !STEADY && (DIR == 0 ? t == 0 : t == T - 1);
+        if (DIR == 0) {
+          if (first) {
+            if (i == 0) { c0 = cond ? 1.0 : 0.0; c1 = rr2 * e; }                  // ctc_loss.cpp:39-42
+          } else {
+            // label cell of the pair below: lane n-1's, lane 0 takes the upstream slice's edge value
+            const int lo = __builtin_amdgcn_update_dpp(__double2loint(x0), __double2loint(c1), 0x138, 0xf, 0xf, false);
+            const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x0), __double2hiint(c1), 0x138, 0xf, 0xf, false);
+            const double pl = __hiloint2double(hi, lo);
+            const double wgt = rr2 * yb_prev;
+            const double ob = c0, ol = c1;
+            c0 = ob * yb_prev + pl;
+            c1 = (ol + wgt * ob + sk * pl) * e;
+          }
+        } else {
+          if (first) {
+            if (2 * i == L - 1 && cond) c0 = 1.0;                                 // ctc_loss.cpp:76
+            if (2 * i + 1 == L - 2) c1 = rr2 * e;                                 // ctc_loss.cpp:78
+          } else {
+            const int blo = __builtin_amdgcn_update_dpp(__double2loint(x0), __double2loint(c0), 0x130, 0xf, 0xf, false);
+            const int bhi = __builtin_amdgcn_update_dpp(__double2hiint(x0), __double2hiint(c0), 0x130, 0xf, 0xf, false);
+            const int llo = __builtin_amdgcn_update_dpp(__double2loint(x1), __double2loint(c1), 0x130, 0xf, 0xf, false);
+            const int lhi = __builtin_amdgcn_update_dpp(__double2hiint(x1), __double2hiint(c1), 0x130, 0xf, 0xf, false);
+            const double nb = __hiloint2double(bhi, blo), nl = __hiloint2double(lhi, llo);
+            const double wgt = rr2 * yb_prev;
+            const double ob = c0, ol = c1;
+            c1 = (ol + wgt * nb + sk * nl) * e;
+            c0 = ob * yb_prev + ol;
+          }
+        }
+        yb_prev = yb;
+      }
+      if (tt == 6) {
+        // (dead steps too: the words below are read by the other slices whatever this block held)
+        const int hi = wave_max(max(__double2hiint(c0), __double2hiint(c1)));     // positive doubles order like ints
+        my_meas = hi > 0 ? ((hi >> 20) & 0x7ff) - 1023 : kNoMeas;
+        if (ROLE != kSolo) meas[(n & (kMwRing - 1)) * 4 + w] = my_meas;
+      } else if (tt == 7) {
+        // the common exponent of this block (decided by the head, see the header comment)
+        int e_now = 0;
+        if (HEAD) {
+          int m = my_meas;
+          if (ROLE == kHead && n >= kMwLag) {
+            if (__builtin_amdgcn_readfirstlane(lag_done) < n - kMwLag + 1) MW_WAIT(bdone[tailw] >= n - kMwLag + 1);
+            int since = 0;
+#pragma unroll
+            for (int k = 0; k < kMwLag; k++) since += e_hist[k];
+            for (int q = 0; q < NW; q++) {
+              if (q == w) continue;
+              const int mq = __builtin_amdgcn_readfirstlane(meas[((n - kMwLag) & (kMwRing - 1)) * 4 + q]);
+              if (mq > kNoMeas) m = max(m, mq - since);
+            }
+          }
+          if (m > kNoMeas) e_now = min(max(m, -1000), 1000);
+          if (ROLE == kHead) {
+            edec[n & (kMwRing - 1)] = e_now;
+#pragma unroll
+            for (int k = 0; k + 1 < kMwLag; k++) e_hist[k] = e_hist[k + 1];
+            e_hist[kMwLag - 1] = e_now;
+          }
+        } else {
+          e_now = __builtin_amdgcn_readfirstlane(edec[n & (kMwRing - 1)]);     // (the head is blocks ahead)
+        }
+        if (TAIL) {
+          // tracking exponent for the segment kernel: the row's true maximum at position 6 of this block (every slice
+          // upstream has published its own), as an absolute exponent -- what the single-wave form's frame IS
+          int g = my_meas;
+          if (ROLE == kTail)
+            for (int q = 0; q < NW; q++) { if (q != w) g = max(g, __builtin_amdgcn_readfirstlane(meas[(n & (kMwRing - 1)) * 4 + q])); }
+          if (g > kNoMeas) gabs = g + e_total;
+        }
+        if (e_now != 0) { c0 = ldexp(c0, -e_now); c1 = ldexp(c1, -e_now); }
+        e_total += e_now;
+        if (live) {
+          if (W0) cum[(t >> 3) + (DIR == 0 ? 1 : 0)] = e_total;          // (every lane the same word: no divergence)
+          if (TAIL) trk[(t >> 3) + (DIR == 0 ? 1 : 0)] = gabs;
+          const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
+          if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
+            const double cell0 = c0 * yb_prev, cell1 = c1 * inv_rr;     // blank with its emission, label without the tilt
+            int m = max(__double2hiint(cell0), __double2hiint(cell1));
+            if (F2PPL >= 2) m = max(m, dpp_i<0xB1>(0, m));                // the segment kernel's lane = F2PPL lanes here
+            if (F2PPL >= 4) m = max(m, dpp_i<0x4E>(0, m));
+            const int own = m > 0 ? ((m >> 20) & 0x7ff) - 1023 : -30000;
+            float2* dst = reinterpret_cast<float2*>(ck + (size_t)(kk / kSeg) * p.CELLS + 128 * w);
+            dst[lane] = m > 0 ? make_float2((float)ldexp(cell0, -own), (float)ldexp(cell1, -own)) : make_float2(0.f, 0.f);
+            if ((lane & (F2PPL - 1)) == 0)
+              cke[((size_t)(kk / kSeg) * 2 + DIR) * 64 + (64 / F2PPL) * w + lane / F2PPL] = (short)own;
+          }
+        }
+      }
+    }
+    // publish this block's edge values (the cells BEFORE each step) and the block itself
+    if (!TAIL) {
+      if (lane == (DIR == 0 ? 63 : 0)) {
+        lds_d2* dst = (lds_d2*)(L0 + edge_out_off + (n & (kRingBlks - 1)) * (MwLds::kEdgeBlk * 8));
+        if (DIR == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) dst[q] = mw_d2{h1[2 * q], h1[2 * q + 1]};
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; q++) dst[q] = mw_d2{h0[q], h1[q]};
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+    bdone[w] = n + 1;                                     // (the tail's count is what the head's lagged exponents wait for)
+  };
+  {
+    if (HEAD) MW_WAIT(filled[0] == 1); else MW_WAIT(bdone[up] >= 1);
+    load_half(0, std::integral_constant<int, 0>{});
+    const int steady_end = DIR == 0 ? T / kBlk : nblk;         // blocks [1, steady_end) are steady
+    run_block(0, std::false_type{});
+    int n = 1;
+    for (; n < steady_end; n++) run_block(n, std::true_type{});
+    for (; n < nblk; n++) run_block(n, std::false_type{});
+  }
+
+  // ---- log Z from this side ----
+  if (DIR == 0) {
+    // cells L-1 (blank of pair S) and L-2 (label of pair S-1): the last slice holds the first, the second may be the
+    // last lane of the slice below
+    if (!TAIL) {
+      if (lane == 63) *(lds_f64*)(L0 + zfin_off + 8 * w) = c1;
+      asm volatile("" ::: "memory");
+      bdone[w] = nblk + 1;
+      return;
+    }
+    double z = 0.0;
+    if (i == S) z += c0 * yb_prev;                         // ctc_loss.cpp:63-70, un-tilted relative to cell L-1
+    if (i == S - 1) z += c1;                               // (= r * the label cell)
+    if (ROLE == kTail && (S & 63) == 0) {                  // pair S-1 is lane 63 of slice w-1
+      MW_WAIT(bdone[w - 1] >= nblk + 1);
+      if (lane == 0) z += *(lds_f64*)(L0 + zfin_off + 8 * (w - 1));
+    }
+    for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+    if (lane == 0) {
+      const double lz = log(z) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log(rr);
+      p.logz[2 * b] = lz;
+      p.zt2[b] = log2(z) + (double)e_total;
+      p.losses[b] = (float)(-lz);
+      if (!(z > 0.0) || !(z < __builtin_huge_val())) atomicOr(&p.flags[b], 4);     // infeasible or out of range
+    }
+  } else if (W0 && lane == 0) {
+    const double z = (cond ? c0 * yb_prev : 0.0) + c1;     // sum_j alpha_0[j]*beta_0[j]
+    p.logz[2 * b + 1] = log(z) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log(rr);
+  }
+}
+
+// a slice that holds no cell of this utterance: the segment kernel still reads the full row width -- leave zeros
+template <int DIR, int F2PPL>
+__device__ __forceinline__ void empty_slice_wave(const FastParams& p, int b, int lane, int w) {
+  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
+  short* cke = p.ckE + (size_t)b * p.NS * 2 * 64;
+  for (int k = 1; k < p.NS; k++) {
+    float2* dst = reinterpret_cast<float2*>(ck + (size_t)k * p.CELLS + 128 * w);
+    dst[lane] = make_float2(0.f, 0.f);
+    if (lane < 64 / F2PPL) cke[((size_t)k * 2 + DIR) * 64 + (64 / F2PPL) * w + lane] = (short)-30000;
+  }
+}
+
+template <int DIR, int F2PPL>
+__device__ __forceinline__ void slice_dispatch(const FastParams& p, int b, int T, int S, lds_u8* L0, int ring_bytes_dir,
+                                               int blk_bytes, int mw_off, int lane, int w, int NW) {
+  if (w >= NW) { empty_slice_wave<DIR, F2PPL>(p, b, lane, w); return; }
+  const bool head = DIR == 0 ? w == 0 : w == NW - 1, tail = DIR == 0 ? w == NW - 1 : w == 0;
+  if (head && tail) chain_slice_wave<DIR, F2PPL, kSolo>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
+  else if (F2PPL == 1) return;                                       // (one slice at most: only the solo form exists)
+  else if (head) chain_slice_wave<DIR, F2PPL, kHead>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
+  else if (tail) chain_slice_wave<DIR, F2PPL, kTail>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
+  else if (F2PPL == 2) return;                                       // (two slices at most: no middle)
+  else chain_slice_wave<DIR, F2PPL, kMid>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
+}
+
+template <int PPL>
+__global__ __launch_bounds__(832) void ctc_fast_chain_mw_kernel(FastParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int V = p.V;
+  const F1Lds lds(smem, V);
+  const MwLds mw(smem + align_up_dev(F1Lds::bytes(V), 16));
+
+  if (b == 0 && tid < 4) p.ctl[tid] = 0;
+  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
+  const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
+  if (bad) {                       // the exact kernel poisons this utterance
+    if (tid == 0) { p.flags[b] = 1; p.losses[b] = __builtin_nanf(""); }   // reason bit 0: bad lengths
+    return;
+  }
+  const int T = (int)Tq, S = (int)Sq;
+  if (tid == 0) p.flags[b] = 0;
+  if (tid < F1Lds::kSyncInts) lds.filled[tid] = 0;
+  if (tid < 8) mw.bdone[tid] = 0;
+  for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
+    lds.ring[(size_t)(i / kBlk) * lds.blk_elems + V * kRow + (i % kBlk)] = 0.0;
+  __syncthreads();
+
+  const int wave = __builtin_amdgcn_readfirstlane(wid);
+  const int NW = min(S / 64 + 1, PPL);                  // slices that hold a cell: pairs 0..S (pair S = the last blank)
+  lds_u8* L0 = (lds_u8*)smem;
+  const int blk_bytes = lds.blk_elems * 8, ring_bytes_dir = kRingBlks * blk_bytes;
+  const int mw_off = (int)align_up_dev(F1Lds::bytes(V), 16);
+  if (wave < 4) { if (wave < PPL) slice_dispatch<0, PPL>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, wave, NW); }
+  else if (wave < 8) { if (wave - 4 < PPL) slice_dispatch<1, PPL>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, wave - 4, NW); }
+  else if (wave == 12) cellinfo_wave<PPL>(p, b, T, S, lds.sortcnt, lane);
+  else {
+    const int d = (wave - 8) & 1;                        // waves 8,10 -> alpha rows, 9,11 -> beta rows
+    const int first = (wave - 8) >> 1;                   // the two producers of a direction take alternate blocks
+    if (V <= 16) prep_wave<1>(p, b, T, d, first, 2, lds, lane);
+    else if (V <= 32) prep_wave<2>(p, b, T, d, first, 2, lds, lane);
+    else if (V <= 48) prep_wave<3>(p, b, T, d, first, 2, lds, lane);
+    else if (V <= 64) prep_wave<4>(p, b, T, d, first, 2, lds, lane);
+    else prep_wave<6>(p, b, T, d, first, 2, lds, lane);
+  }
+}
+
+// ============================================================================================
 // F2: one wave per (utterance, 16-step segment)
 // ============================================================================================
 constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before they are summed and written out
@@ -894,8 +1280,11 @@ struct SegIn {
     const int t0 = seg * kSeg;
     const int* cA = p.cumA + (size_t)b * p.NB + (t0 >> 3);
     const int* cB = p.cumB + (size_t)b * p.NB + (t0 >> 3);
-    const int a0 = cA[0], a1 = cA[1], a2 = cA[2], b0 = cB[0], b1 = cB[1], b2 = cB[2];
-    eA7 = a1 - a0; eA15 = a2 - a1; eB0 = b0 - b1; eB8 = b1 - b2;
+    const int* tA = p.trkA + (size_t)b * p.NB + (t0 >> 3);
+    const int* tB = p.trkB + (size_t)b * p.NB + (t0 >> 3);
+    const int a0 = cA[0], b2 = cB[2];
+    const int ta0 = tA[0], ta1 = tA[1], ta2 = tA[2], tb0 = tB[0], tb1 = tB[1], tb2 = tB[2];
+    eA7 = ta1 - ta0; eA15 = ta2 - ta1; eB0 = tb0 - tb1; eB8 = tb1 - tb2;
     EA0 = a0; EB16 = b2;
     { const double z = p.zt2[b]; const double zi = floor(z); zfrac = (float)(z - zi);
       zint = (int)fmax(fmin(zi, 1e9), -1e9); if (!(z == z)) zfrac = z; }      // (infeasible: -inf; never passes the check)
@@ -1248,7 +1637,24 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute");
   const size_t lds2 = F2Lds<PPL>::bytes(p.V);
-  hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
+  // The multi-wave chains (ctc_fast_chain_mw_kernel) are parity-green but SLOWER on MI355X (B=256, T=1000, S<=200: chain
+  // kernel 152 us against 95 us): per 8-step block a slice wave executes 250-300 instructions (56 of them the steps) against
+  // 340 for a whole single-wave chain, and with two slices and a producer on every SIMD the CU is issue-bound -- what
+  // counts is the TOTAL instruction count per utterance step (2740 per block against 1180), not the longest wave.  Kept
+  // selectable for A/B (E2E_F1_MULTI=1); see DESIGN.md section 4.1.
+  static const bool single_wave = getenv("E2E_F1_MULTI") == nullptr;
+  if (single_wave) {
+    hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
+    FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB;          // (its frame follows the maximum itself)
+    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
+    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
+    return E2E_OK;
+  } else {
+    const size_t ldsm = align_up(lds1, 16) + MwLds::bytes();
+    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_mw_kernel<PPL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm), "hipFuncSetAttribute");
+    hipLaunchKernelGGL(ctc_fast_chain_mw_kernel<PPL>, dim3(p.B), dim3(832), ldsm, stream, p);
+  }
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
   hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
@@ -1264,7 +1670,7 @@ int ppl_for(int Smax) {
 }
 
 struct FastLayout {
-  size_t ytab, ckA, ckQ, ckE, cumA, cumB, logz, zt2, flags, cinfo, lstart, ctl, total;
+  size_t ytab, ckA, ckQ, ckE, cumA, cumB, trkA, trkB, logz, zt2, flags, cinfo, lstart, ctl, total;
   int NS, NB, CELLS;
 };
 
@@ -1281,6 +1687,8 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
   l.ckE = o; o += align_up((size_t)B * l.NS * 2 * 64 * sizeof(short), 256);
   l.cumA = o; o += align_up((size_t)B * l.NB * sizeof(int), 256);
   l.cumB = o; o += align_up((size_t)B * l.NB * sizeof(int), 256);
+  l.trkA = o; o += align_up((size_t)B * l.NB * sizeof(int), 256);
+  l.trkB = o; o += align_up((size_t)B * l.NB * sizeof(int), 256);
   l.zt2 = o; o += align_up((size_t)B * sizeof(double), 256);
   l.logz = o; o += align_up((size_t)B * 2 * sizeof(double), 256);
   l.flags = o; o += align_up((size_t)B * sizeof(int), 256);
@@ -1320,6 +1728,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.ckA = reinterpret_cast<float*>(ws + l.ckA); p.ckQ = reinterpret_cast<float*>(ws + l.ckQ);
   p.ckE = reinterpret_cast<short*>(ws + l.ckE);
   p.cumA = reinterpret_cast<int*>(ws + l.cumA); p.cumB = reinterpret_cast<int*>(ws + l.cumB);
+  p.trkA = reinterpret_cast<int*>(ws + l.trkA); p.trkB = reinterpret_cast<int*>(ws + l.trkB);
   p.zt2 = reinterpret_cast<double*>(ws + l.zt2);
   p.logz = reinterpret_cast<double*>(ws + l.logz); p.flags = reinterpret_cast<int*>(ws + l.flags);
   p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart);

@@ -65,3 +65,33 @@ def test_sharp_unrelated_emissions_are_taken_or_handed_over_but_never_wrong():
     kernel's partition-sum self-check decides what the fast path may keep.  Whatever it keeps must be right, and what the
     caller gets by default (ALGO_AUTO) must be right for every utterance."""
     assert _sweep(105, 40, "sharp") > 0
+
+
+def test_multi_wave_chains_variant_matches_exact(monkeypatch):
+    """The experimental multi-wave form of the chain kernel (E2E_F1_MULTI=1, read once per process: run in a child)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os
+sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import gpu_util as U
+from end2end_amd import _lib
+g = torch.Generator().manual_seed(77)
+for (B, T, V, S) in ((6, 300, 29, 100), (4, 1000, 29, 200), (5, 137, 20, 60), (3, 64, 9, 31), (3, 520, 40, 128)):
+    x = torch.randn(B, T, V, generator=g) * 1.5
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl = torch.randint(max(2 * S + 1, T // 2), T + 1, (B,), generator=g); xl[0] = T
+    tl = torch.randint(S // 2, S + 1, (B,), generator=g); tl[0] = S
+    le, ge = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_EXACT)
+    lf, gf = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    assert np.isfinite(lf).all(), lf
+    U.assert_same(lf, le, 1e-6, 1e-6, "losses")
+    U.assert_same(gf, ge, 1e-4, 2e-6, "grads")
+print("ok")
+'''
+    import os
+    env = dict(os.environ, E2E_F1_MULTI="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
