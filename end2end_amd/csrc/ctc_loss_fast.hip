@@ -824,6 +824,8 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
   constexpr bool TAIL = ROLE == kSolo || ROLE == kTail;     // runs last: releases ring slots, writes the tracking exponents
   constexpr bool W0 = DIR == 0 ? HEAD : TAIL;               // slice 0
   constexpr int NE = DIR == 0 ? 1 : 2;                      // edge values per step
+  constexpr int PS = F2PPL == 1 ? 1 : F2PPL / 2;            // label pairs per lane of a slice (a slice = 64*PS pairs)
+  constexpr int NC = 2 * PS;
   const int V = p.V, blank = p.blank, L = 2 * S + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
   float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
@@ -844,27 +846,32 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
   volatile lds_int* edec = (volatile lds_int*)(L0 + zfin_off + 32) + 8 + 2 * kMwRing * 4 + DIR * kMwRing;
   __builtin_amdgcn_s_setprio(3);
 
-  // this lane's pair
-  const int i = 64 * w + lane;
+  // this lane's pairs i = PS*(64w + lane) + r
+  const int i0 = PS * (64 * w + lane);
   const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
-  const float r = fast_tilt(S, T);
-  const double rr = (double)r, rr2 = rr * rr, inv_rr = 1.0 / rr;
-  int lab; double sk; bool bad_label = false;
-  {
+  const float r_tilt = fast_tilt(S, T);
+  const double rr = (double)r_tilt, rr2 = rr * rr, inv_rr = 1.0 / rr;
+  int lab_off[PS]; double sk[PS]; bool bad_label = false;
+#pragma unroll
+  for (int r = 0; r < PS; r++) {
+    const int i = i0 + r;
     const int li = i < S ? (int)tg[i] : -1;
     const int lp = (i >= 1 && i - 1 < S) ? (int)tg[i - 1] : -1;
     const int ln = (i + 1 < S) ? (int)tg[i + 1] : -1;
-    lab = (i < S && li >= 0 && li < V) ? li : V;
+    const int lab = (i < S && li >= 0 && li < V) ? li : V;
     if (i < S && (li == blank || li < 0 || li >= V)) bad_label = true;
     const bool skp = i < S && i >= 1 && li != blank && lp != li;          // ctc_loss.cpp:53-57
     const bool skn = i + 1 < S && li != blank && ln != li;                // ctc_loss.cpp:91-96
-    sk = (DIR == 0 ? skp : skn) ? rr2 : 0.0;
+    sk[r] = (DIR == 0 ? skp : skn) ? rr2 : 0.0;
+    lab_off[r] = lab * (kRow * 8);
   }
   if (DIR == 0 && __any(bad_label)) { if (lane == 0) atomicOr(&p.flags[b], 2); }
   const bool cond = (T > 1 || L == 1);            // ctc_loss.cpp:39,76
-  const int lab_off = lab * (kRow * 8), blank_off = blank * (kRow * 8);
+  const int blank_off = blank * (kRow * 8);
 
-  double c0 = 0.0, c1 = 0.0;                       // B~ of blank cell 2i, L^ of label cell 2i+1 (see chain_wave)
+  double c[NC];                                    // c[2r] = B~ of blank cell 2i, c[2r+1] = L^ of label cell 2i+1 (see chain_wave)
+#pragma unroll
+  for (int k = 0; k < NC; k++) c[k] = 0.0;
   double yb_prev = 0.0;
   int e_total = 0, e_hist[kMwLag], my_meas = kNoMeas, gabs = 0;
 #pragma unroll
@@ -876,14 +883,17 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
     if (TAIL) { if (DIR == 0) trk[0] = 0; else { trk[((T - 1) >> 3) + 1] = 0; trk[((T - 1) >> 3) + 2] = 0; } }
   }
 
-  mw_d2 eraw[4], braw[4];                          // probabilities of this lane's label / of the blank, 2 steps each
+  mw_d2 eraw[PS][4], braw[4];                      // probabilities of this lane's labels / of the blank, 2 steps each
   mw_d2 xraw[4 * NE];                              // upstream edge values: alpha 2 steps per d2, beta 1 step (blank, label)
 #pragma unroll
   for (int q = 0; q < 4 * NE; q++) xraw[q] = mw_d2{0.0, 0.0};
   auto load_half = [&](int n, auto half_tag) {
     constexpr int H = decltype(half_tag)::value;
     const int yo = y_off + (n & (kRingBlks - 1)) * blk_bytes + 32 * H;
-    eraw[2 * H] = *(lds_d2*)(L0 + yo + lab_off); eraw[2 * H + 1] = *(lds_d2*)(L0 + yo + lab_off + 16);
+#pragma unroll
+    for (int r = 0; r < PS; r++) {
+      eraw[r][2 * H] = *(lds_d2*)(L0 + yo + lab_off[r]); eraw[r][2 * H + 1] = *(lds_d2*)(L0 + yo + lab_off[r] + 16);
+    }
     braw[2 * H] = *(lds_d2*)(L0 + yo + blank_off); braw[2 * H + 1] = *(lds_d2*)(L0 + yo + blank_off + 16);
     if (!HEAD) {
       const int xo = edge_in_off + (n & (kRingBlks - 1)) * (MwLds::kEdgeBlk * 8) + 32 * NE * H;
@@ -906,7 +916,10 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
 #pragma unroll
     for (int tt = 0; tt < kBlk; tt++) {
       const int t = DIR == 0 ? tbase + tt : tbase - tt;
-      const double yb = braw[tt >> 1][tt & 1], e = eraw[tt >> 1][tt & 1];
+      const double yb = braw[tt >> 1][tt & 1];
+      double e[PS];
+#pragma unroll
+      for (int r = 0; r < PS; r++) e[r] = eraw[r][tt >> 1][tt & 1];
       double x0, x1 = 0.0;                                // upstream edge values for this step
       if (DIR == 0) x0 = xraw[tt >> 1][tt & 1]; else { x0 = xraw[tt][0]; x1 = xraw[tt][1]; }
       if (tt == 4) {
@@ -916,44 +929,58 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
         }
         load_half(n + 1, std::integral_constant<int, 0>{});
       }
-      h0[tt] = c0; h1[tt] = c1;
+      if (DIR == 0) h1[tt] = c[NC - 1]; else { h0[tt] = c[0]; h1[tt] = c[1]; }
       const bool live = STEADY || t < T;
       if (live) {
         const bool first = !STEADY && (DIR == 0 ? t == 0 : t == T - 1);
         if (DIR == 0) {
           if (first) {
-            if (i == 0) { c0 = cond ? 1.0 : 0.0; c1 = rr2 * e; }                  // ctc_loss.cpp:39-42
+            if (i0 == 0) { c[0] = cond ? 1.0 : 0.0; c[1] = rr2 * e[0]; }          // ctc_loss.cpp:39-42
           } else {
-            // label cell of the pair below: lane n-1's, lane 0 takes the upstream slice's edge value
-            const int lo = __builtin_amdgcn_update_dpp(__double2loint(x0), __double2loint(c1), 0x138, 0xf, 0xf, false);
-            const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x0), __double2hiint(c1), 0x138, 0xf, 0xf, false);
-            const double pl = __hiloint2double(hi, lo);
+            // label cell of the pair below this lane's first: lane n-1's last, lane 0 takes the upstream slice's edge value
+            const int lo = __builtin_amdgcn_update_dpp(__double2loint(x0), __double2loint(c[NC - 1]), 0x138, 0xf, 0xf, false);
+            const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x0), __double2hiint(c[NC - 1]), 0x138, 0xf, 0xf, false);
+            double pl = __hiloint2double(hi, lo);
             const double wgt = rr2 * yb_prev;
-            const double ob = c0, ol = c1;
-            c0 = ob * yb_prev + pl;
-            c1 = (ol + wgt * ob + sk * pl) * e;
+#pragma unroll
+            for (int r = 0; r < PS; r++) {
+              const double ob = c[2 * r], ol = c[2 * r + 1];
+              c[2 * r] = ob * yb_prev + pl;
+              c[2 * r + 1] = (ol + wgt * ob + sk[r] * pl) * e[r];
+              pl = ol;
+            }
           }
         } else {
           if (first) {
-            if (2 * i == L - 1 && cond) c0 = 1.0;                                 // ctc_loss.cpp:76
-            if (2 * i + 1 == L - 2) c1 = rr2 * e;                                 // ctc_loss.cpp:78
+#pragma unroll
+            for (int r = 0; r < PS; r++) {
+              if (2 * (i0 + r) == L - 1 && cond) c[2 * r] = 1.0;                  // ctc_loss.cpp:76
+              if (2 * (i0 + r) + 1 == L - 2) c[2 * r + 1] = rr2 * e[r];           // ctc_loss.cpp:78
+            }
           } else {
-            const int blo = __builtin_amdgcn_update_dpp(__double2loint(x0), __double2loint(c0), 0x130, 0xf, 0xf, false);
-            const int bhi = __builtin_amdgcn_update_dpp(__double2hiint(x0), __double2hiint(c0), 0x130, 0xf, 0xf, false);
-            const int llo = __builtin_amdgcn_update_dpp(__double2loint(x1), __double2loint(c1), 0x130, 0xf, 0xf, false);
-            const int lhi = __builtin_amdgcn_update_dpp(__double2hiint(x1), __double2hiint(c1), 0x130, 0xf, 0xf, false);
-            const double nb = __hiloint2double(bhi, blo), nl = __hiloint2double(lhi, llo);
+            const int blo = __builtin_amdgcn_update_dpp(__double2loint(x0), __double2loint(c[0]), 0x130, 0xf, 0xf, false);
+            const int bhi = __builtin_amdgcn_update_dpp(__double2hiint(x0), __double2hiint(c[0]), 0x130, 0xf, 0xf, false);
+            const int llo = __builtin_amdgcn_update_dpp(__double2loint(x1), __double2loint(c[1]), 0x130, 0xf, 0xf, false);
+            const int lhi = __builtin_amdgcn_update_dpp(__double2hiint(x1), __double2hiint(c[1]), 0x130, 0xf, 0xf, false);
+            double nb = __hiloint2double(bhi, blo), nl = __hiloint2double(lhi, llo);
             const double wgt = rr2 * yb_prev;
-            const double ob = c0, ol = c1;
-            c1 = (ol + wgt * nb + sk * nl) * e;
-            c0 = ob * yb_prev + ol;
+#pragma unroll
+            for (int r = PS - 1; r >= 0; r--) {
+              const double ob = c[2 * r], ol = c[2 * r + 1];
+              c[2 * r + 1] = (ol + wgt * nb + sk[r] * nl) * e[r];
+              c[2 * r] = ob * yb_prev + ol;
+              nb = ob; nl = ol;
+            }
           }
         }
         yb_prev = yb;
       }
       if (tt == 6) {
         // (dead steps too: the words below are read by the other slices whatever this block held)
-        const int hi = wave_max(max(__double2hiint(c0), __double2hiint(c1)));     // positive doubles order like ints
+        int hi = 0;
+#pragma unroll
+        for (int k = 0; k < NC; k++) hi = max(hi, __double2hiint(c[k]));              // positive doubles order like ints
+        hi = wave_max(hi);
         my_meas = hi > 0 ? ((hi >> 20) & 0x7ff) - 1023 : kNoMeas;
         if (ROLE != kSolo) meas[(n & (kMwRing - 1)) * 4 + w] = my_meas;
       } else if (tt == 7) {
@@ -990,22 +1017,27 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
             for (int q = 0; q < NW; q++) { if (q != w) g = max(g, __builtin_amdgcn_readfirstlane(meas[(n & (kMwRing - 1)) * 4 + q])); }
           if (g > kNoMeas) gabs = g + e_total;
         }
-        if (e_now != 0) { c0 = ldexp(c0, -e_now); c1 = ldexp(c1, -e_now); }
+#pragma unroll
+        for (int k = 0; k < NC; k++) c[k] = ldexp(c[k], -e_now);
         e_total += e_now;
         if (live) {
           if (W0) cum[(t >> 3) + (DIR == 0 ? 1 : 0)] = e_total;          // (every lane the same word: no divergence)
           if (TAIL) trk[(t >> 3) + (DIR == 0 ? 1 : 0)] = gabs;
           const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
           if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
-            const double cell0 = c0 * yb_prev, cell1 = c1 * inv_rr;     // blank with its emission, label without the tilt
-            int m = max(__double2hiint(cell0), __double2hiint(cell1));
-            if (F2PPL >= 2) m = max(m, dpp_i<0xB1>(0, m));                // the segment kernel's lane = F2PPL lanes here
-            if (F2PPL >= 4) m = max(m, dpp_i<0x4E>(0, m));
+            double cell[NC];                                // blank with its emission, label without the tilt
+#pragma unroll
+            for (int r = 0; r < PS; r++) { cell[2 * r] = c[2 * r] * yb_prev; cell[2 * r + 1] = c[2 * r + 1] * inv_rr; }
+            int m = 0;
+#pragma unroll
+            for (int k = 0; k < NC; k++) m = max(m, __double2hiint(cell[k]));
+            if (F2PPL >= 2) m = max(m, dpp_i<0xB1>(0, m));                // the segment kernel's lane = 2 lanes here
             const int own = m > 0 ? ((m >> 20) & 0x7ff) - 1023 : -30000;
-            float2* dst = reinterpret_cast<float2*>(ck + (size_t)(kk / kSeg) * p.CELLS + 128 * w);
-            dst[lane] = m > 0 ? make_float2((float)ldexp(cell0, -own), (float)ldexp(cell1, -own)) : make_float2(0.f, 0.f);
-            if ((lane & (F2PPL - 1)) == 0)
-              cke[((size_t)(kk / kSeg) * 2 + DIR) * 64 + (64 / F2PPL) * w + lane / F2PPL] = (short)own;
+            float* dst = ck + (size_t)(kk / kSeg) * p.CELLS + 128 * PS * w + NC * lane;
+#pragma unroll
+            for (int k = 0; k < NC; k++) dst[k] = m > 0 ? (float)ldexp(cell[k], -own) : 0.f;
+            if (F2PPL == 1) cke[((size_t)(kk / kSeg) * 2 + DIR) * 64 + lane] = (short)own;
+            else if ((lane & 1) == 0) cke[((size_t)(kk / kSeg) * 2 + DIR) * 64 + 32 * w + (lane >> 1)] = (short)own;
           }
         }
       }
@@ -1013,18 +1045,18 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
     // publish this block's edge values (the cells BEFORE each step) and the block itself
     if (!TAIL) {
       if (lane == (DIR == 0 ? 63 : 0)) {
-        lds_d2* dst = (lds_d2*)(L0 + edge_out_off + (n & (kRingBlks - 1)) * (MwLds::kEdgeBlk * 8));
+        lds_f64* dst = (lds_f64*)(L0 + edge_out_off + (n & (kRingBlks - 1)) * (MwLds::kEdgeBlk * 8));
         if (DIR == 0) {
 #pragma unroll
-          for (int q = 0; q < 4; q++) dst[q] = mw_d2{h1[2 * q], h1[2 * q + 1]};
+          for (int q = 0; q < 8; q++) dst[q] = h1[q];
         } else {
 #pragma unroll
-          for (int q = 0; q < 8; q++) dst[q] = mw_d2{h0[q], h1[q]};
+          for (int q = 0; q < 8; q++) { dst[2 * q] = h0[q]; dst[2 * q + 1] = h1[q]; }
         }
       }
     }
     asm volatile("" ::: "memory");
-    bdone[w] = n + 1;                                     // (the tail's count is what the head's lagged exponents wait for)
+    if (ROLE != kSolo) bdone[w] = n + 1;                  // (the tail's count is what the head's lagged exponents wait for)
   };
   {
     if (HEAD) MW_WAIT(filled[0] == 1); else MW_WAIT(bdone[up] >= 1);
@@ -1039,17 +1071,20 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
   // ---- log Z from this side ----
   if (DIR == 0) {
     // cells L-1 (blank of pair S) and L-2 (label of pair S-1): the last slice holds the first, the second may be the
-    // last lane of the slice below
+    // last cell of the slice below
     if (!TAIL) {
-      if (lane == 63) *(lds_f64*)(L0 + zfin_off + 8 * w) = c1;
+      if (lane == 63) *(lds_f64*)(L0 + zfin_off + 8 * w) = c[NC - 1];
       asm volatile("" ::: "memory");
       bdone[w] = nblk + 1;
       return;
     }
     double z = 0.0;
-    if (i == S) z += c0 * yb_prev;                         // ctc_loss.cpp:63-70, un-tilted relative to cell L-1
-    if (i == S - 1) z += c1;                               // (= r * the label cell)
-    if (ROLE == kTail && (S & 63) == 0) {                  // pair S-1 is lane 63 of slice w-1
+#pragma unroll
+    for (int r = 0; r < PS; r++) {
+      if (i0 + r == S) z += c[2 * r] * yb_prev;            // ctc_loss.cpp:63-70, un-tilted relative to cell L-1
+      if (i0 + r == S - 1) z += c[2 * r + 1];              // (= r * the label cell)
+    }
+    if (ROLE == kTail && S == 64 * PS * w) {               // pair S-1 is the last pair of slice w-1
       MW_WAIT(bdone[w - 1] >= nblk + 1);
       if (lane == 0) z += *(lds_f64*)(L0 + zfin_off + 8 * (w - 1));
     }
@@ -1062,7 +1097,7 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
       if (!(z > 0.0) || !(z < __builtin_huge_val())) atomicOr(&p.flags[b], 4);     // infeasible or out of range
     }
   } else if (W0 && lane == 0) {
-    const double z = (cond ? c0 * yb_prev : 0.0) + c1;     // sum_j alpha_0[j]*beta_0[j]
+    const double z = (cond ? c[0] * yb_prev : 0.0) + c[1];     // sum_j alpha_0[j]*beta_0[j]
     p.logz[2 * b + 1] = log(z) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log(rr);
   }
 }
@@ -1070,12 +1105,14 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
 // a slice that holds no cell of this utterance: the segment kernel still reads the full row width -- leave zeros
 template <int DIR, int F2PPL>
 __device__ __forceinline__ void empty_slice_wave(const FastParams& p, int b, int lane, int w) {
+  constexpr int PS = F2PPL == 1 ? 1 : F2PPL / 2;
   float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
   short* cke = p.ckE + (size_t)b * p.NS * 2 * 64;
   for (int k = 1; k < p.NS; k++) {
-    float2* dst = reinterpret_cast<float2*>(ck + (size_t)k * p.CELLS + 128 * w);
-    dst[lane] = make_float2(0.f, 0.f);
-    if (lane < 64 / F2PPL) cke[((size_t)k * 2 + DIR) * 64 + (64 / F2PPL) * w + lane] = (short)-30000;
+    float* dst = ck + (size_t)k * p.CELLS + 128 * PS * w + 2 * PS * lane;
+#pragma unroll
+    for (int q = 0; q < 2 * PS; q++) dst[q] = 0.f;
+    if (lane < 32) cke[((size_t)k * 2 + DIR) * 64 + 32 * w + lane] = (short)-30000;
   }
 }
 
@@ -1087,13 +1124,11 @@ __device__ __forceinline__ void slice_dispatch(const FastParams& p, int b, int T
   if (head && tail) chain_slice_wave<DIR, F2PPL, kSolo>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
   else if (F2PPL == 1) return;                                       // (one slice at most: only the solo form exists)
   else if (head) chain_slice_wave<DIR, F2PPL, kHead>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
-  else if (tail) chain_slice_wave<DIR, F2PPL, kTail>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
-  else if (F2PPL == 2) return;                                       // (two slices at most: no middle)
-  else chain_slice_wave<DIR, F2PPL, kMid>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
+  else chain_slice_wave<DIR, F2PPL, kTail>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
 }
 
 template <int PPL>
-__global__ __launch_bounds__(832) void ctc_fast_chain_mw_kernel(FastParams p) {
+__global__ __launch_bounds__(576) void ctc_fast_chain_mw_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V;
@@ -1115,17 +1150,20 @@ __global__ __launch_bounds__(832) void ctc_fast_chain_mw_kernel(FastParams p) {
     lds.ring[(size_t)(i / kBlk) * lds.blk_elems + V * kRow + (i % kBlk)] = 0.0;
   __syncthreads();
 
+  // waves 0,1 = alpha slices 0,1 (SIMDs 0,2); waves 2,3 = beta slices 0,1 (SIMDs 1,3); waves 4-7 = probability rows, one per
+  // SIMD (4,6 alpha side, 5,7 beta side); wave 8 = lattice description.  A slice = 64*PS label pairs, PS = PPL/2.
+  constexpr int PS = PPL == 1 ? 1 : PPL / 2, MAXW = PPL == 1 ? 1 : 2;
   const int wave = __builtin_amdgcn_readfirstlane(wid);
-  const int NW = min(S / 64 + 1, PPL);                  // slices that hold a cell: pairs 0..S (pair S = the last blank)
+  const int NW = min(S / (64 * PS) + 1, MAXW);          // slices that hold a cell: pairs 0..S (pair S = the last blank)
   lds_u8* L0 = (lds_u8*)smem;
   const int blk_bytes = lds.blk_elems * 8, ring_bytes_dir = kRingBlks * blk_bytes;
   const int mw_off = (int)align_up_dev(F1Lds::bytes(V), 16);
-  if (wave < 4) { if (wave < PPL) slice_dispatch<0, PPL>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, wave, NW); }
-  else if (wave < 8) { if (wave - 4 < PPL) slice_dispatch<1, PPL>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, wave - 4, NW); }
-  else if (wave == 12) cellinfo_wave<PPL>(p, b, T, S, lds.sortcnt, lane);
+  if (wave < 2) { if (wave < MAXW) slice_dispatch<0, PPL>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, wave, NW); }
+  else if (wave < 4) { if (wave - 2 < MAXW) slice_dispatch<1, PPL>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, wave - 2, NW); }
+  else if (wave == 8) cellinfo_wave<PPL>(p, b, T, S, lds.sortcnt, lane);
   else {
-    const int d = (wave - 8) & 1;                        // waves 8,10 -> alpha rows, 9,11 -> beta rows
-    const int first = (wave - 8) >> 1;                   // the two producers of a direction take alternate blocks
+    const int d = (wave - 4) & 1;                        // waves 4,6 -> alpha rows, 5,7 -> beta rows
+    const int first = (wave - 4) >> 1;                   // the two producers of a direction take alternate blocks
     if (V <= 16) prep_wave<1>(p, b, T, d, first, 2, lds, lane);
     else if (V <= 32) prep_wave<2>(p, b, T, d, first, 2, lds, lane);
     else if (V <= 48) prep_wave<3>(p, b, T, d, first, 2, lds, lane);
@@ -1637,11 +1675,17 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute");
   const size_t lds2 = F2Lds<PPL>::bytes(p.V);
-  // The multi-wave chains (ctc_fast_chain_mw_kernel) are parity-green but SLOWER on MI355X (B=256, T=1000, S<=200: chain
-  // kernel 152 us against 95 us): per 8-step block a slice wave executes 250-300 instructions (56 of them the steps) against
-  // 340 for a whole single-wave chain, and with two slices and a producer on every SIMD the CU is issue-bound -- what
-  // counts is the TOTAL instruction count per utterance step (2740 per block against 1180), not the longest wave.  Kept
-  // selectable for A/B (E2E_F1_MULTI=1); see DESIGN.md section 4.1.
+  // The multi-wave chains (ctc_fast_chain_mw_kernel) are parity-green but SLOWER on MI355X (B=256, T=1000, S<=200; the
+  // single-wave chain kernel takes 95 us = 215 cycles per step):
+  //   4 slices per direction (1 pair per lane, two slices + a producer per SIMD)   chain kernel 152 us
+  //   2 slices per direction (2 pairs per lane, one slice + a producer per SIMD)   chain kernel 120 us   <- this code
+  // Per 8-step block a slice wave executes ~300-340 instructions (170-200 VALU, of which 88 are the f64 steps) against 340
+  // (220 VALU) for a WHOLE single-wave chain: halving the cells per lane removes 80 f64 operations and adds the hand-off,
+  // edge, exponent-exchange and per-slice checkpoint code, most of it moves / selects / address arithmetic that the
+  // compiler emits per block.  A lone wave pays ~4.5 cycles for every instruction of any kind, and a slice that shares
+  // its SIMD with a producer wave (~200 VALU per block) is VALU-bound instead.  What would pay is fewer instructions in
+  // total: softmax rows computed once instead of once per direction, and an f32 lattice that carries alpha and beta in
+  // the two halves of packed instructions -- see DESIGN.md section 4.1.  Kept selectable for A/B (E2E_F1_MULTI=1).
   static const bool single_wave = getenv("E2E_F1_MULTI") == nullptr;
   if (single_wave) {
     hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
@@ -1653,7 +1697,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
     const size_t ldsm = align_up(lds1, 16) + MwLds::bytes();
     E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_mw_kernel<PPL>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_fast_chain_mw_kernel<PPL>, dim3(p.B), dim3(832), ldsm, stream, p);
+    hipLaunchKernelGGL(ctc_fast_chain_mw_kernel<PPL>, dim3(p.B), dim3(576), ldsm, stream, p);
   }
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
   hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);
