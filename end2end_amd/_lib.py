@@ -80,6 +80,11 @@ def load():
         L.e2e_ctc_beam.argtypes = [vp, C.c_int, i64, i64, i64, i64p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_double,
                                    i64p, i64, i64p, vp, C.c_size_t, vp]
+        L.e2e_ctc_align_workspace_bytes.restype = C.c_size_t
+        L.e2e_ctc_align_workspace_bytes.argtypes = [C.c_int] * 5
+        L.e2e_ctc_align.restype = C.c_int
+        L.e2e_ctc_align.argtypes = [vp, C.c_int, i64, i64, i64, i64p, i64, i64p, i64p,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i64p, i64, vp, C.c_size_t, vp]
         L.e2e_debug_stream_copy.restype = C.c_int
         L.e2e_debug_stream_copy.argtypes = [vp, vp, C.c_size_t, vp]
         if L.e2e_ctc_abi_version() != ABI_VERSION:

@@ -127,6 +127,23 @@ PYBIND11_MODULE(_C, m) {
         py::arg("lmwt"), py::arg("wip"), py::arg("oov_penalty"), py::arg("out"), py::arg("max_out"),
         py::arg("out_len"), py::arg("workspace"), py::arg("workspace_bytes"), py::arg("stream"));
 
+  m.def("ctc_align_workspace_bytes",
+        [](int B, int T, int V, int Smax, bool is_ctc) { return e2e_ctc_align_workspace_bytes(B, T, V, Smax, is_ctc ? 1 : 0); });
+
+  m.def("ctc_align",
+        [](uintptr_t lp, int dtype, int64_t sB, int64_t sT, int64_t sV, uintptr_t targets, int64_t tgt_stride,
+           uintptr_t x_len, uintptr_t t_len, int B, int T, int V, int Smax, int blank, bool is_ctc, uintptr_t out,
+           int64_t pad_value, uintptr_t workspace, size_t workspace_bytes, uintptr_t stream) {
+          check(e2e_ctc_align(ptr<const void>(lp), dtype, sB, sT, sV, ptr<const int64_t>(targets), tgt_stride,
+                              ptr<const int64_t>(x_len), ptr<const int64_t>(t_len), B, T, V, Smax, blank,
+                              is_ctc ? 1 : 0, ptr<int64_t>(out), pad_value, ptr<void>(workspace), workspace_bytes,
+                              ptr<void>(stream)));
+        },
+        py::arg("lp"), py::arg("dtype"), py::arg("sB"), py::arg("sT"), py::arg("sV"), py::arg("targets"),
+        py::arg("tgt_stride"), py::arg("x_len"), py::arg("t_len"), py::arg("B"), py::arg("T"), py::arg("V"),
+        py::arg("Smax"), py::arg("blank"), py::arg("is_ctc"), py::arg("out"), py::arg("pad_value"),
+        py::arg("workspace"), py::arg("workspace_bytes"), py::arg("stream"));
+
   py::class_<LanguageModel>(m, "LanguageModel")
       .def(py::init<const std::string&, const std::vector<std::string>&, bool>(), py::arg("path"), py::arg("labels"),
            py::arg("case_sensitive"))

@@ -179,6 +179,30 @@ int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, int64_t sV,
                  int64_t* out, int64_t max_out, int64_t* out_len,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Viterbi forced alignment on the same lattice (max-plus instead of sum).
+ * Replaces pytorch_end2end/utils/alignment.py:50-106 (_get_alignment_ctc_1d), :10-47
+ * (_get_alignment_asg_1d, is_ctc = 0: no blanks) and the batch driver :109-138
+ * (get_alignment_3d), which run as numba-jitted Python on the host upstream.
+ *   lp        (B,T,V) LOG-PROBABILITIES, strides sB,sT,sV, f32/f64 (alpha is f64 either way, as upstream)
+ *   targets   (B,*) int64, first t_len[b] entries used; x_len, t_len (B) int64
+ *   blank     the blank id (upstream hard-codes 0, :57); ignored when is_ctc = 0
+ *   out       (B,T) int64: out[b, t] = the label (or blank) frame t is aligned to for t < x_len[b], pad_value beyond
+ *             (upstream fills -100, :132).  Ties keep the earlier candidate in the order stay, previous cell, skip, as
+ *             upstream's strict ">" does.  Too few frames for the labelling is not an error upstream and is not one
+ *             here (same walk over -inf cells).  An utterance with invalid lengths or a target outside [0,V) gets a
+ *             row of pad_value.
+ *   workspace >= e2e_ctc_align_workspace_bytes(...): one back-pointer byte per lattice cell and frame
+ */
+size_t e2e_ctc_align_workspace_bytes(int B, int T, int V, int Smax, int is_ctc);
+
+int e2e_ctc_align(const void* lp, int dtype, int64_t sB, int64_t sT, int64_t sV,
+                  const int64_t* targets, int64_t tgt_stride,
+                  const int64_t* x_len, const int64_t* t_len,
+                  int B, int T, int V, int Smax, int blank, int is_ctc,
+                  int64_t* out, int64_t pad_value,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

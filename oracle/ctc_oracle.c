@@ -605,3 +605,96 @@ int oracle_ctc_beam(const double* lp, int64_t sB, int64_t sT, int64_t sV,
   run_pool(beam_one, &c, B, n_threads);
   return c.status;
 }
+
+/* ------------------------------------------------------------------ */
+/* Viterbi forced alignment                                            */
+/* pytorch_end2end/utils/alignment.py:50-106 (_get_alignment_ctc_1d), :10-47
+ * (_get_alignment_asg_1d), batch driver :109-138 (get_alignment_3d).
+ * Restated statement by statement, including what the Python leaves implicit:
+ * path_alpha is zero-initialised (cells outside the band point at cell 0),
+ * comparisons are strict ">" in the order stay, i-1, i-2, the skip needs
+ * "i - 2 > 0" (:86), alpha is float64 whatever the input, the blank id is the
+ * argument here (upstream hard-codes 0, :57). */
+typedef struct {
+  const double* lp; int64_t sB, sT, sV; const int64_t* targets; int64_t tgt_stride;
+  const int64_t* x_len; const int64_t* t_len; int B, T, V, blank, is_ctc; int64_t* out;
+} align_ctx;
+
+static void align_one(void* vctx, int b) {
+  align_ctx* c = (align_ctx*)vctx;
+  const int T = (int)c->x_len[b], S = (int)c->t_len[b];
+  const double* lp = c->lp + b * c->sB;
+  const int64_t* tg = c->targets + (int64_t)b * c->tgt_stride;
+  int64_t* best = c->out + (int64_t)b * c->T;
+  if (T < 1) return;
+#define LP(t, v) lp[(int64_t)(t) * c->sT + (int64_t)(v) * c->sV]
+  if (c->is_ctc) {
+    const int L = 2 * S + 1;
+    for (int k = 0; k < T; k++) best[k] = 0;                        /* np.zeros, :63 */
+    if (L == 1 || T == 1) {                                         /* :65-70 */
+      if (L == 1) return;
+      best[0] = tg[0];
+      return;
+    }
+    int64_t* ext = (int64_t*)malloc(sizeof(int64_t) * (size_t)L);
+    for (int i = 0; i < L; i++) ext[i] = (i & 1) ? tg[i >> 1] : c->blank;
+    double* alpha = (double*)malloc(sizeof(double) * (size_t)L * (size_t)T);
+    int* path = (int*)calloc((size_t)L * (size_t)T, sizeof(int));
+    for (size_t q = 0; q < (size_t)L * (size_t)T; q++) alpha[q] = NEG_INF;
+#define A(i, k) alpha[(size_t)(i) * (size_t)T + (size_t)(k)]
+#define P(i, k) path[(size_t)(i) * (size_t)T + (size_t)(k)]
+    A(0, 0) = LP(0, ext[0]);
+    A(1, 0) = LP(0, ext[1]);
+    for (int k = 1; k < T; k++) {
+      int start = L - 2 * (T - k); if (start < 0) start = 0;
+      int end = k * 2 + 2; if (end > L) end = L;
+      for (int i = start; i < end; i++) { A(i, k) = A(i, k - 1); P(i, k) = i; }
+      for (int i = start; i < end; i++) {
+        const int64_t lab = ext[i];
+        if (i > 0) {
+          if (A(i - 1, k - 1) > A(i, k)) { A(i, k) = A(i - 1, k - 1); P(i, k) = i - 1; }
+          if (lab != c->blank && i - 2 > 0 && ext[i - 2] != lab && A(i - 2, k - 1) > A(i, k)) {
+            A(i, k) = A(i - 2, k - 1); P(i, k) = i - 2;
+          }
+        }
+        A(i, k) += LP(k, lab);
+      }
+    }
+    int i = L - 1;
+    if (A(i - 1, T - 1) > A(i, T - 1)) i = i - 1;
+    for (int k = T - 1; k >= 0; k--) { best[k] = ext[i]; i = P(i, k); }
+    free(ext); free(alpha); free(path);
+  } else {
+    for (int k = 0; k < T; k++) best[k] = 0;
+    if (S < 1) return;                                              /* (upstream would index targets[0]) */
+    if (T == 1) { best[0] = tg[0]; return; }                        /* :22-24 */
+    double* alpha = (double*)malloc(sizeof(double) * (size_t)S * (size_t)T);
+    int* path = (int*)calloc((size_t)S * (size_t)T, sizeof(int));
+    for (size_t q = 0; q < (size_t)S * (size_t)T; q++) alpha[q] = NEG_INF;
+#define A2(i, k) alpha[(size_t)(i) * (size_t)T + (size_t)(k)]
+#define P2(i, k) path[(size_t)(i) * (size_t)T + (size_t)(k)]
+    A2(0, 0) = LP(0, tg[0]);
+    for (int k = 1; k < T; k++) {
+      int start = S - (T - k); if (start < 0) start = 0;
+      int end = k + 1; if (end > S) end = S;
+      for (int i = start; i < end; i++) { A2(i, k) = A2(i, k - 1); P2(i, k) = i; }
+      for (int i = start; i < end; i++) {
+        if (i > 0 && A2(i - 1, k - 1) > A2(i, k)) { A2(i, k) = A2(i - 1, k - 1); P2(i, k) = i - 1; }
+        A2(i, k) += LP(k, tg[i]);
+      }
+    }
+    int i = S - 1;
+    for (int k = T - 1; k >= 0; k--) { best[k] = tg[i]; i = P2(i, k); }
+    free(alpha); free(path);
+  }
+}
+
+/* out: (B,T) int64, pre-filled by the caller (upstream: -100, :132); rows b get out[b, :x_len[b]] */
+int oracle_ctc_align(const double* lp, int64_t sB, int64_t sT, int64_t sV,
+                     const int64_t* targets, int64_t tgt_stride, const int64_t* x_len, const int64_t* t_len,
+                     int B, int T, int V, int blank, int is_ctc, int64_t* out, int n_threads) {
+  if (!lp || !x_len || !t_len || !out || B < 0 || T < 1 || V < 1) return -1;
+  align_ctx c = {lp, sB, sT, sV, targets, tgt_stride, x_len, t_len, B, T, V, blank, is_ctc, out};
+  run_pool(align_one, &c, B, n_threads);
+  return 0;
+}

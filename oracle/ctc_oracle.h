@@ -89,6 +89,13 @@ int oracle_ctc_beam(const double* lp, int64_t sB, int64_t sT, int64_t sV,
                     int64_t* out, int64_t max_out, int64_t* out_len,
                     int n_threads);
 
+/* Viterbi forced alignment, pytorch_end2end/utils/alignment.py:50-106 (CTC), :10-47 (ASG, is_ctc = 0),
+ * driver :109-138.  lp: (B,T,V) log-probs; out: (B,T) int64 pre-filled by the caller (upstream: -100);
+ * row b receives its labelling in out[b, :x_len[b]]. */
+int oracle_ctc_align(const double* lp, int64_t sB, int64_t sT, int64_t sV,
+                     const int64_t* targets, int64_t tgt_stride, const int64_t* x_len, const int64_t* t_len,
+                     int B, int T, int V, int blank, int is_ctc, int64_t* out, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

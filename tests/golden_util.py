@@ -56,6 +56,13 @@ def module_case(name):
     return {k: z[name + "/" + k] for k in ("input", "targets", "x_len", "t_len", "loss", "input_grad")}
 
 
+def align_cases():
+    """Forced alignments computed by the reference's own functions (tests/golden/make_align_golden.py)."""
+    z = npz("align.npz")
+    names = sorted({k.split("/")[0] for k in z.files})
+    return [dict(name=n, **{k: z[n + "/" + k] for k in ("lp", "targets", "x_len", "t_len", "is_ctc", "out")}) for n in names]
+
+
 def known_loss_inputs(case):
     """-> (lp float64 [B,T,V], targets, x_len, t_len, blank, cost) for a known-answer loss case."""
     p = np.array(case["probs"], dtype=np.float32)

@@ -56,6 +56,9 @@ def lib():
                                       C.POINTER(C.c_char_p), C.c_int, C.c_void_p, C.c_int,
                                       C.c_double, C.c_double, C.c_double,
                                       i64p, C.c_int64, i64p, C.c_int]
+        L.oracle_ctc_align.restype = C.c_int
+        L.oracle_ctc_align.argtypes = [dp, C.c_int64, C.c_int64, C.c_int64, i64p, C.c_int64, i64p, i64p,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i64p, C.c_int]
         _lib = L
     return _lib
 
@@ -102,6 +105,25 @@ def ctc_greedy(x, x_len=None, blank=0, n_threads=8):
     if rc != 0:
         raise ValueError("oracle_ctc_greedy rc=%d" % rc)
     return out, out_len
+
+
+def ctc_align(lp, targets, x_len, t_len, blank=0, is_ctc=True, pad=-100, n_threads=8):
+    """Viterbi forced alignment -> (B,T) int64, rows beyond x_len keep `pad` (get_alignment_3d upstream)."""
+    lp = np.asarray(lp, dtype=np.float64)
+    B, T, V = lp.shape
+    targets = np.ascontiguousarray(np.asarray(targets, dtype=np.int64).reshape(B, -1))
+    if targets.shape[1] == 0:
+        targets = np.zeros((B, 1), dtype=np.int64)
+    x_len = np.ascontiguousarray(np.asarray(x_len, dtype=np.int64))
+    t_len = np.ascontiguousarray(np.asarray(t_len, dtype=np.int64))
+    out = np.full((B, T), pad, dtype=np.int64)
+    es = lp.itemsize
+    rc = lib().oracle_ctc_align(_dptr(lp), lp.strides[0] // es, lp.strides[1] // es, lp.strides[2] // es,
+                                _iptr(targets), targets.shape[1], _iptr(x_len), _iptr(t_len), B, T, V, blank,
+                                int(is_ctc), _iptr(out), n_threads)
+    if rc != 0:
+        raise ValueError("oracle_ctc_align rc=%d" % rc)
+    return out
 
 
 class OracleLM:

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     from end2end_amd import _lib
     L = _lib.load()
     names = _declared()
-    assert {"e2e_ctc_loss_fwd_bwd", "e2e_ctc_greedy", "e2e_ctc_beam", "e2e_lm_load_arpa"} <= names
+    assert {"e2e_ctc_loss_fwd_bwd", "e2e_ctc_greedy", "e2e_ctc_beam", "e2e_lm_load_arpa", "e2e_ctc_align"} <= names
     for n in sorted(names):
         assert hasattr(L, n), n
     assert L.e2e_ctc_abi_version() == _lib.ABI_VERSION

@@ -89,3 +89,11 @@ def test_beam_against_exhaustive_enumeration(case):
     for W in (case["beam_width"], case["beam_width"] + 37):
         ids, lens, _ = O.ctc_beam(lp, None, case["blank"], W, case["labels"], wip=case["wip"])
         assert ids[0, : lens[0]].tolist() == case["want_ids"]
+
+
+@pytest.mark.parametrize("case", G.align_cases(), ids=lambda c: c["name"])
+def test_forced_alignment_against_the_reference_functions(case):
+    """oracle_ctc_align vs the outputs of the reference's own _get_alignment_ctc_1d / _asg_1d / get_alignment_3d
+    (pytorch_end2end/utils/alignment.py, run by tests/golden/make_align_golden.py)."""
+    out = O.ctc_align(case["lp"], case["targets"], case["x_len"], case["t_len"], 0, bool(case["is_ctc"]))
+    assert out.tolist() == case["out"].tolist()
