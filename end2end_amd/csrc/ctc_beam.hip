@@ -180,6 +180,19 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
   if (!path || !out || V < 0 || (V > 0 && !labels)) { set_error("e2e_lm_load_arpa: bad argument"); return E2E_ERR_ARG; }
   gzFile f = gzopen(path, "rb");
   if (!f) { set_error("cannot open language model %s", path); return E2E_ERR_IO; }
+  {
+    // KenLM's own binary format (what `build_binary` writes; upstream's LoadVirtual, ctc_decoder.cpp:64, takes it too)
+    // is not read here: say so instead of failing to find ARPA sections
+    char magic[64] = {0};
+    const int got = gzread(f, magic, sizeof(magic) - 1);
+    if (got > 0 && strncmp(magic, "mmap lm http://kheafield.com/code", 33) == 0) {
+      gzclose(f);
+      set_error("%s is a KenLM binary model; this library reads ARPA (plain or .gz) -- convert it back with KenLM, or "
+                "load the ARPA file it was built from", path);
+      return E2E_ERR_UNSUPPORTED;
+    }
+    gzrewind(f);
+  }
   e2e_lm* lm = new e2e_lm();
   lm->fold_case = case_sensitive ? 0 : 1;
   std::vector<std::string> words;                          // id -> word; id 0 is <unk>
@@ -1171,6 +1184,25 @@ BeamLayout beam_layout(int B, int T, int V, int W, bool lm = false) {
 
 }  // namespace
 }  // namespace e2e
+
+// does one workgroup's LDS hold the beam of this width over this alphabet? (same tests as e2e_ctc_beam)
+static bool beam_fits(int V, int W, bool lm) {
+  if (V < 1 || W < 1) return false;
+  if ((long long)W * V + W + 8 > kMaxCand || W > kSelBins) return false;
+  if (lm && 2 * W > kStateSlots) return false;
+  const BeamLayout l = beam_layout(1, 1, V, W, lm);
+  return l.lds <= (size_t)kLdsBudget;
+}
+
+extern "C" int e2e_ctc_beam_max_width(int V, int with_lm) {
+  if (V < 1) return 0;
+  int lo = 0, hi = kSelBins;                    // the largest supported width (the tests are monotone in the width)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) / 2;
+    if (beam_fits(V, mid, with_lm != 0)) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
 
 extern "C" size_t e2e_ctc_beam_workspace_bytes(int B, int T, int V, int beam_width) {
   if (B < 0 || T < 1 || V < 1 || beam_width < 1) return 0;

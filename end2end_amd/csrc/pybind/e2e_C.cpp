@@ -114,6 +114,8 @@ PYBIND11_MODULE(_C, m) {
   m.def("ctc_beam_workspace_bytes",
         [](int B, int T, int V, int beam_width) { return e2e_ctc_beam_workspace_bytes(B, T, V, beam_width); });
 
+  m.def("ctc_beam_max_width", [](int V, bool with_lm) { return e2e_ctc_beam_max_width(V, with_lm ? 1 : 0); });
+
   m.def("ctc_beam",
         [](uintptr_t lp, int dtype, int64_t sB, int64_t sT, int64_t sV, uintptr_t x_len, int B, int T, int V, int blank,
            int beam_width, int space_id, uintptr_t lm, double lmwt, double wip, double oov_penalty, uintptr_t out,

@@ -155,6 +155,13 @@ class CTCDecoderEngine:
         # index of " " among the labels, else -1 (src/decoders/ctc_decoder.cpp:55-59)
         self.space_id = self.labels.index(" ") if " " in self.labels else -1
         self.lm = None
+        if self.labels and self.beam_width > 1:
+            # the beam lives in one workgroup's LDS: a width / alphabet it cannot hold is reported now, not at the first
+            # decode (upstream has no such limit, ctc_decoder.cpp:353-441; see include/e2e_ctc.h)
+            cap = _C.ctc_beam_max_width(len(self.labels), bool(lm_path))
+            if self.beam_width > cap:
+                raise ValueError("beam_width %d is not supported for an alphabet of %d labels%s: at most %d"
+                                 % (self.beam_width, len(self.labels), " with a language model" if lm_path else "", cap))
         if lm_path:
             R.require_gpu()
             self.lm = LanguageModel(lm_path, self.labels, self.case_sensitive)

@@ -171,6 +171,10 @@ double e2e_lm_score(const e2e_lm* lm, const uint32_t* ctx /* host */, int ctx_le
  * also live there: e.g. beam 100 at V = 29 with an LM of any order up to 6).
  */
 size_t e2e_ctc_beam_workspace_bytes(int B, int T, int V, int beam_width);
+/* The largest beam_width e2e_ctc_beam accepts for an alphabet of V columns, with or without a language model (0: none).
+ * E.g. V = 29: 150 without / 103 with an LM; V = 80: 81 / 47; V = 1000: 7 / 3 -- word-piece alphabets are out of reach
+ * of the one-workgroup design (host callers check this at construction instead of failing at the first decode). */
+int e2e_ctc_beam_max_width(int V, int with_lm);
 
 int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, int64_t sV,
                  const int64_t* x_len, int B, int T, int V, int blank,

@@ -122,3 +122,25 @@ def test_decoder_wrapper_parameter_checks(tmp_path):
     from end2end_amd.engines import CTCDecoderEngine
     e = CTCDecoderEngine(0)
     assert (e.beam_width, e.wip, e.oov_penalty, e.case_sensitive) == (100, 0.0, -1000.0, False)  # engine defaults
+
+
+def test_beam_width_limits_are_queryable_and_enforced_at_construction():
+    from end2end_amd import _C
+    from end2end_amd.engines import CTCDecoderEngine
+    assert _C.ctc_beam_max_width(29, False) >= 100 and _C.ctc_beam_max_width(29, True) >= 100     # the reference default
+    assert _C.ctc_beam_max_width(8000, False) == 0
+    labels = ["_"] + ["l%d" % i for i in range(199)]
+    cap = _C.ctc_beam_max_width(200, False)
+    CTCDecoderEngine(0, cap, labels)
+    with pytest.raises(ValueError, match="beam_width"):
+        CTCDecoderEngine(0, cap + 1, labels)
+    CTCDecoderEngine(0, 1, labels)           # greedy has no such limit
+
+
+def test_kenlm_binary_models_are_refused_with_a_clear_message(tmp_path):
+    from end2end_amd.engines import LanguageModel
+    from end2end_amd._runtime import E2EError
+    p = tmp_path / "model.binary"
+    p.write_bytes(b"mmap lm http://kheafield.com/code format version 5\n\x00" + bytes(200))
+    with pytest.raises(E2EError, match="KenLM binary"):
+        LanguageModel(str(p), ["_", "a"], True)
