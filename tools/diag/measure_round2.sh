@@ -1,14 +1,16 @@
 # usage (on the GPU box, from the repo root): bash tools/diag/measure_round2.sh TAG
-# bench line + rocprofv3 kernel stats (+ optional PMC passes with PMC=1) of the default bench command
+# bench line + rocprofv3 kernel stats (+ PMC passes with PMC=1) of the default bench command
 TAG=${1:-x}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 bench.py --steps 20 --warmup 5 ${BENCH_FLAGS} > gpurun_out/bench_r02_$TAG.json 2> gpurun_out/bench_r02_$TAG.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o c2 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-decode --no-wide > gpurun_out/prof_$TAG.log 2>&1
 if [ -n "$PMC" ]; then
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${TAG}_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-wide > gpurun_out/pmc_${TAG}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${TAG}_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-wide > gpurun_out/pmc_${TAG}_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${TAG}_fetch -o pmc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-wide > gpurun_out/pmc_${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${TAG}_write -o pmc -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-wide > gpurun_out/pmc_${TAG}_write.log 2>&1
+python3 tools/diag/pmc_summary.py gpurun_out/pmc_${TAG}_fetch
+python3 tools/diag/pmc_summary.py gpurun_out/pmc_${TAG}_write
 fi
-find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs head -12
+find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs head -8 | cut -c1-180
 python3 -c "
 import json
 d=json.loads(open('gpurun_out/bench_r02_$TAG.json').read().strip().splitlines()[-1])
