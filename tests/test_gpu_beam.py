@@ -325,3 +325,29 @@ def test_device_lm_tables_with_the_definition_pinned_models(name):
     lp = torch.log_softmax(x, -1)
     for W, kw in ((30, dict(lmwt=1.0, wip=0.0, oov_penalty=-5.0)), (100, dict(lmwt=2.0, wip=1.0, oov_penalty=-1000.0))):
         same_as_oracle(lp, [90, 71, 33, 5], 0, W, labels, lm, olm, case_sensitive=True, **kw)
+
+
+def test_language_model_follows_the_logits_device():
+    """the LM's tables live on one GPU; a decoder built while cuda:0 is current must still decode tensors that
+    live on cuda:1 (a per-device copy is loaded on first use), and the raw C ABI refuses a model of another device."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from end2end_amd import CTCDecoder
+    from end2end_amd._runtime import E2EError
+    labels = ["_", "a", "b", " "]
+    dec = CTCDecoder(beam_width=8, labels=labels, lm_path=ARPA, after_logsoftmax=True)
+    lp = rand_lp(3, 2, 20, 4).float()
+    r0 = dec.decode(lp.to("cuda:0"))
+    r1 = dec.decode(lp.to("cuda:1"))
+    assert r0.decoded_sentences == r1.decoded_sentences
+    lm = LanguageModel(ARPA, labels, True)
+    with torch.cuda.device(1):
+        with pytest.raises(E2EError, match="device"):
+            from end2end_amd import _C, _runtime as R
+            x = lp.to("cuda:1")
+            out = torch.empty((2, 21), dtype=torch.long, device="cuda:1")
+            ol = torch.empty(2, dtype=torch.long, device="cuda:1")
+            xl = torch.full((2,), 20, dtype=torch.long, device="cuda:1")
+            ws = torch.empty(_C.ctc_beam_workspace_bytes(2, 20, 4, 8), dtype=torch.uint8, device="cuda:1")
+            _C.ctc_beam(x.data_ptr(), R.F32, *x.stride(), xl.data_ptr(), 2, 20, 4, 0, 8, 3, lm.on(torch.device("cuda", 0)).handle,
+                        1.0, 0.0, -10.0, out.data_ptr(), 21, ol.data_ptr(), ws.data_ptr(), ws.numel(), 0)
