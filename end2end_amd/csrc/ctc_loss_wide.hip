@@ -430,37 +430,65 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
   p.gc = reinterpret_cast<const float*>(ws + l.gc);
   const bool vec4 = a.sV == 1 && (a.sT % 4 == 0) && (a.sB % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0) &&
                     (a.V % 4 == 0) && (reinterpret_cast<uintptr_t>(a.grads) % 16 == 0);
-  const int64_t rows = (int64_t)a.B * a.T;
-  const dim3 grid_rows((unsigned)((rows + kWaves - 1) / kWaves));
+  const bool dense = vec4 && a.V <= 8192;          // the row fits a wave's registers: logits read once
   hipLaunchKernelGGL(wide_compact_kernel, dim3(a.B), dim3(256), sizeof(int) * 3 * (a.Smax > 0 ? a.Smax : 1), a.stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "wide_compact_kernel launch");
-  const bool dense = vec4 && a.V <= 8192;          // the row fits a wave's registers: logits read once
-  if (dense) {
-    if (a.V <= 2048) hipLaunchKernelGGL(wide_rows_dense_kernel<8>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
-    else if (a.V <= 4096) hipLaunchKernelGGL(wide_rows_dense_kernel<16>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
-    else hipLaunchKernelGGL(wide_rows_dense_kernel<32>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
-  } else if (vec4) hipLaunchKernelGGL(wide_rows_kernel<true>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
-  else hipLaunchKernelGGL(wide_rows_kernel<false>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
-  E2E_HIP_CHECK(hipGetLastError(), "wide rows kernel launch");
-  // the lattice on the compact alphabet: log-probabilities in, (prob - posterior) out
-  LossArgs c = a;
-  c.x = p.xc; c.dtype = E2E_F32; c.logprobs = 1;
-  c.sB = (int64_t)a.T * l.VC; c.sT = l.VC; c.sV = 1;
-  c.targets = p.targets_c; c.tgt_stride = a.Smax > 0 ? a.Smax : 1;
-  c.V = l.VC; c.blank = l.VC - 1;
-  c.grads = ws + l.gc;
-  c.ws = ws + l.inner; c.ws_bytes = a.ws_bytes - l.inner;
-  c.grad_scale = 1.0; c.reduced = nullptr; c.reduction = 0;      // (the compact gradient stays unscaled; the losses
-                                                                  //  are corrected below, the caller reduces them after)
-  const int rc = launch_fast(c, fallback_to_exact);
+
+  // utterances [b0, b0 + nb): the row kernel on stream `s_rows`; the lattice on the compact alphabet, the loss
+  // correction and the label-column fix-up on stream `s_lat`
+  auto rows_part = [&](int b0, int nb, hipStream_t s_rows) -> int {
+    WideParams q = p;
+    q.B = nb; q.x = p.x + (int64_t)b0 * a.sB; q.x_len = a.x_len + b0; q.t_len = a.t_len + b0;
+    q.grads = p.grads + (size_t)b0 * a.T * a.V; q.losses = p.losses + b0;
+    q.clabel = p.clabel + (size_t)b0 * l.VC; q.lse = p.lse + (size_t)b0 * a.T; q.shift = p.shift + (size_t)b0 * a.T;
+    q.xc = p.xc + (size_t)b0 * a.T * l.VC; q.gc = p.gc + (size_t)b0 * a.T * l.VC;
+    const dim3 grid_rows((unsigned)(((int64_t)nb * a.T + kWaves - 1) / kWaves));
+    if (dense) {
+      if (a.V <= 2048) hipLaunchKernelGGL(wide_rows_dense_kernel<8>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+      else if (a.V <= 4096) hipLaunchKernelGGL(wide_rows_dense_kernel<16>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+      else hipLaunchKernelGGL(wide_rows_dense_kernel<32>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+    } else if (vec4) hipLaunchKernelGGL(wide_rows_kernel<true>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+    else hipLaunchKernelGGL(wide_rows_kernel<false>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+    E2E_HIP_CHECK(hipGetLastError(), "wide rows kernel launch");
+    return E2E_OK;
+  };
+  auto lattice_part = [&](int b0, int nb, hipStream_t s_lat) -> int {
+    WideParams q = p;
+    q.B = nb; q.x = p.x + (int64_t)b0 * a.sB; q.x_len = a.x_len + b0; q.t_len = a.t_len + b0;
+    q.grads = p.grads + (size_t)b0 * a.T * a.V; q.losses = p.losses + b0;
+    q.clabel = p.clabel + (size_t)b0 * l.VC; q.lse = p.lse + (size_t)b0 * a.T; q.shift = p.shift + (size_t)b0 * a.T;
+    q.xc = p.xc + (size_t)b0 * a.T * l.VC; q.gc = p.gc + (size_t)b0 * a.T * l.VC;
+    const dim3 grid_rows((unsigned)(((int64_t)nb * a.T + kWaves - 1) / kWaves));
+    // the lattice on the compact alphabet: log-probabilities in, (prob - posterior) out
+    LossArgs c = a;
+    c.B = nb; c.stream = s_lat;
+    c.x = q.xc; c.dtype = E2E_F32; c.logprobs = 1;
+    c.sB = (int64_t)a.T * l.VC; c.sT = l.VC; c.sV = 1;
+    c.targets = p.targets_c + (size_t)b0 * (a.Smax > 0 ? a.Smax : 1); c.tgt_stride = a.Smax > 0 ? a.Smax : 1;
+    c.x_len = q.x_len; c.t_len = q.t_len; c.losses = q.losses;
+    c.V = l.VC; c.blank = l.VC - 1;
+    c.grads = const_cast<float*>(q.gc);
+    c.ws = ws + l.inner; c.ws_bytes = a.ws_bytes - l.inner;
+    c.grad_scale = 1.0; c.reduced = nullptr; c.reduction = 0;      // (the compact gradient stays unscaled; the losses
+                                                                    //  are corrected below, the caller reduces them after)
+    const int rc = launch_fast(c, fallback_to_exact);
+    if (rc != E2E_OK) return rc;
+    hipLaunchKernelGGL(wide_loss_fix_kernel, dim3(nb), dim3(64), 0, s_lat, q);
+    E2E_HIP_CHECK(hipGetLastError(), "wide_loss_fix_kernel launch");
+    if (dense) hipLaunchKernelGGL(wide_fix_kernel, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
+    else if (vec4) hipLaunchKernelGGL(wide_emit_kernel<true>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
+    else hipLaunchKernelGGL(wide_emit_kernel<false>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
+    E2E_HIP_CHECK(hipGetLastError(), "wide emit kernel launch");
+    return E2E_OK;
+  };
+
+  // (Chunking the batch -- lattice + fix-up of chunk k on an internal second stream under the row kernel of chunk k+1, so
+  // that the fix-up would find its gradient lines in the Infinity Cache -- was built and measured at B=512, T=256, V=8000:
+  // 16 utterances per chunk 3.37 ms, 32: 2.29, 64: 2.09, 128: 2.05 against 2.00 ms unchunked.  A chunk's lattice is
+  // latency-bound (~100 us of launches and serial steps whatever its size) and the fix-up is no faster behind it.)
+  int rc = rows_part(0, a.B, a.stream);
   if (rc != E2E_OK) return rc;
-  hipLaunchKernelGGL(wide_loss_fix_kernel, dim3(a.B), dim3(64), 0, a.stream, p);
-  E2E_HIP_CHECK(hipGetLastError(), "wide_loss_fix_kernel launch");
-  if (dense) hipLaunchKernelGGL(wide_fix_kernel, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
-  else if (vec4) hipLaunchKernelGGL(wide_emit_kernel<true>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
-  else hipLaunchKernelGGL(wide_emit_kernel<false>, grid_rows, dim3(64 * kWaves), 0, a.stream, p);
-  E2E_HIP_CHECK(hipGetLastError(), "wide emit kernel launch");
-  return E2E_OK;
+  return lattice_part(0, a.B, a.stream);
 }
 
 }  // namespace e2e
