@@ -371,15 +371,16 @@ __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
     return;
   }
   if (t >= Tq) return;
-  // prob - posterior, the posterior in the shifted compact space: exp(xc) - gc.  The probability is what the dense
-  // kernel left in the column (the line has to come in for the 4-byte write anyway); the compact log-prob is read from
-  // the workspace row instead of gathering the logits a second time.
+  // prob - posterior, the posterior in the shifted compact space: exp(xc) - gc.  Everything comes from the compact
+  // workspace row -- the probability is exp(xc + shift) again -- so the column is WRITTEN, not read-modified: a 4-byte
+  // store into a line that left the caches long ago needs no fill (the read half of the fix-up's traffic).
   const float* gc = p.gc + (size_t)row * p.VC;
   const float* xc = p.xc + (size_t)row * p.VC;
   const int* cl = p.clabel + (size_t)b * p.VC;
+  const float sh = p.shift[row];
   for (int k = lane; k < p.VC; k += 64) {
     const int l = cl[k];
-    if (l >= 0) gr[l] -= (exp_acc(xc[k]) - gc[k]) * p.gscale;
+    if (l >= 0) gr[l] = (exp_acc(xc[k] + sh) - (exp_acc(xc[k]) - gc[k])) * p.gscale;
   }
 }
 
