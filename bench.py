@@ -298,6 +298,14 @@ def decode_numbers(dev, with_cpu):
             out["beam100_lm"]["cpu_baseline"] = cpu_timed(
                 lambda: O.ctc_beam(xbh, None, 0, 100, labels, olm, lmwt=1.0, wip=1.0, oov_penalty=-10.0, n_threads=0),
                 64, "the full 64-utterance batch, same ARPA")
+    # a word-piece-sized alphabet: the general beam kernel (candidate keys in HBM); the reference's default width
+    gw = torch.Generator().manual_seed(3)
+    xw = torch.log_softmax(torch.randn(16, 256, 8000, generator=gw) * 3, -1).to(dev)
+    xlw = torch.full((16,), 256, dtype=torch.long, device=dev)
+    eng = CTCDecoder(beam_width=100, blank_idx=0, after_logsoftmax=True)._decoder
+    dt = timed(lambda: eng.decode(xw, xlw), 1)
+    out["beam100_wide_alphabet"] = {"workload": "B=16 T=256 V=8000 beam=100, no LM (general kernel)",
+                                    "utterances_per_s": 16 / dt, "ms": dt * 1e3}
     return out
 
 

@@ -37,6 +37,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace e2e {
@@ -1166,6 +1168,382 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The general form: any alphabet width
+// ------------------------------------------------------------------------------------------------------
+// The kernel above keeps everything that scales with beam_width * alphabet in LDS -- candidate keys, the members' child
+// tables, the LM's answers -- which bounds the width by the alphabet (81 at V = 80, 7 at V = 1000).  This one is the same
+// algorithm, phase by phase, with those three in HBM (L2-resident: 16-24 bytes per (member, character)):
+//   * candidate keys: an array in the workspace, streamed by the pair loop (written) and by the radix select and the
+//     gather (read); the select starts below the leading bits that the best score and the worst old member share, like
+//     above, and runs on to the last bit (no small-bin finish);
+//   * child tables: at most one alive child per member is ever recorded (its guard), so a step's table is a hash map
+//     of <= W entries keyed by (member position, character) in LDS instead of W*V words;
+//   * the LM's answers: rows in the workspace, copied with a member that stays, asked for a member that is new (every
+//     new member asks for itself: no sharing between members of equal LM state);
+//   * the frame's log-probabilities are read from the input where they are needed (no staging).
+// Barriers are full (__syncthreads after a workgroup fence): data crosses threads through global memory here.
+// Not tuned: it exists so that an alphabet the fast kernel cannot hold is decoded at all, on the device, with
+// the same result (tests run the whole beam suite through it: E2E_BEAM_GENERAL=1).  beam_width <= kGenMaxW.
+constexpr int kGenMaxW = 256;
+constexpr int kGenThreads = 1024;
+
+struct GenParams {
+  unsigned long long* gkey;      // [B][W + W*V]
+  LmAnswer* lmc;                 // [B][2][W][V]   (null without a language model)
+  int CH;                        // child map slots (power of two >= 4W)
+};
+
+struct ChildMap {                // (member position * V + character) -> node id of the alive child
+  int* key; int* val; int mask;
+  __device__ static unsigned hash(int k) { return (unsigned)k * 2654435761u; }
+  __device__ void insert(int k, int v) const {
+    unsigned h = (hash(k) >> 7) & mask;
+    while (atomicCAS(&key[h], -1, k) != -1) h = (h + 1) & mask;
+    val[h] = v;
+  }
+  __device__ int find(int k) const {
+    unsigned h = (hash(k) >> 7) & mask;
+    for (;;) {
+      const int kk = key[h];
+      if (kk == k) return val[h];
+      if (kk == -1) return -1;
+      h = (h + 1) & mask;
+    }
+  }
+};
+
+__device__ __forceinline__ void gsync() { __threadfence_block(); __syncthreads(); }
+
+template <typename IO, int LMK>
+__global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParams p, GenParams g) {
+  constexpr int kThreads = kGenThreads;
+  constexpr bool LM = LMK != 0;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int V = p.V, W = p.W, blank = p.blank;
+  // ---- LDS carve-up ----
+  unsigned char* q8 = smem;
+  unsigned char* const mem0 = q8;
+  const size_t mbytes = Members::bytes(W);
+  q8 += 2 * mbytes;
+  unsigned long long* uskey = (unsigned long long*)q8; q8 += sizeof(unsigned long long) * (p.WP2 + 8);
+  double* fkey = (double*)q8; q8 += sizeof(double) * (p.WP2 + 8);          // final scores
+  int* sidx = (int*)q8; q8 += sizeof(int) * (p.WP2 + 8);
+  int* hist = (int*)q8; q8 += sizeof(int) * kSelBins;
+  int* s_part = (int*)q8; q8 += sizeof(int) * 64;
+  int* const sm0 = (int*)q8; q8 += sizeof(int) * 4 * p.HS;                  // [set][key | val][HS]  node -> position
+  int* const cm0 = (int*)q8; q8 += sizeof(int) * 4 * g.CH;                  // [set][key | val][CH]  (position, char) -> child node
+  auto slot_map = [&](int set) { SlotMap m; m.key = sm0 + set * 2 * p.HS; m.val = m.key + p.HS; m.mask = p.HS - 1; return m; };
+  auto child_map = [&](int set) { ChildMap m; m.key = cm0 + set * 2 * g.CH; m.val = m.key + g.CH; m.mask = g.CH - 1; return m; };
+  __shared__ int s_next_node, s_err, s_krem, s_done, s_total_new;
+  __shared__ unsigned s_hi, s_lo;
+  __shared__ unsigned long long s_prefix;
+  LabelTab lt; lt.off = p.lm.label_off; lt.bytes = p.lm.label_bytes;
+
+  BeamNode* nodes = p.nodes + (size_t)b * p.NCAP;
+  const IO* lp = reinterpret_cast<const IO*>(p.lp) + (int64_t)b * p.sB;
+  unsigned long long* const gkey = g.gkey + (size_t)b * ((size_t)W + (size_t)W * V);
+  LmAnswer* const lmc0 = LM ? g.lmc + (size_t)b * 2 * (size_t)W * V : nullptr;
+  int64_t Tq = p.x_len[b];
+  const int T = Tq < 0 ? 0 : (Tq > p.T ? p.T : (int)Tq);
+  Members M0; M0.carve(mem0, W);
+
+  for (int h = tid; h < 2 * p.HS; h += kThreads) { sm0[h] = -1; sm0[2 * p.HS + h] = -1; }
+  for (int h = tid; h < 2 * g.CH; h += kThreads) { cm0[h] = -1; cm0[2 * g.CH + h] = -1; }
+  if (tid == 0) {
+    s_next_node = 1; s_err = 0;                                                     // node 0 is taken
+    BeamNode& r = nodes[0];
+    r.parent = -1; r.last_char = -1;
+    LmFields l;
+    l.lm_score = 0.0; l.lm_before = 0.0; l.num_words = 0; l.num_oov = 0; l.num_oov_before = 0; l.word_len = 0;
+    l.word_hash = kFnvInit; l.st_n = 0; l.stb_n = 0;
+    if (p.has_lm) { l.st[0] = p.lm.bos; l.st_n = 1; l.stb[0] = p.lm.bos; l.stb_n = 1; }
+    M0.ppb[0] = 0.0; M0.ppnb[0] = ninf(); M0.full[0] = lse2(ninf(), 0.0); M0.inc[0] = ninf(); M0.kept[0] = 0; M0.node[0] = 0; M0.last[0] = -1; M0.gown[0] = -1; M0.gchar[0] = 0; M0.gnode[0] = 0;
+    M0.lm[0] = l;
+  }
+  gsync();
+  if (tid == 0) slot_map(0).insert(0, 0);
+  if (LM) for (int c = tid; c < V; c += kThreads) if (c != blank && c != p.space_id) lmc0[c] = lm_query<LMK == 2>(p, lt, M0.lm[0], -1, c);
+  gsync();
+  int n = 1, cur = 0;
+
+  for (int t = 0; t < T; t++) {
+    Members A, Bm;
+    A.carve(mem0 + (size_t)cur * mbytes, W);
+    Bm.carve(mem0 + (size_t)(cur ^ 1) * mbytes, W);
+    const SlotMap mapA = slot_map(cur), mapB = slot_map(cur ^ 1);
+    const ChildMap cmA = child_map(cur), cmB = child_map(cur ^ 1);
+    const LmAnswer* const lmcA = LM ? lmc0 + (size_t)cur * W * V : nullptr;
+    LmAnswer* const lmcB = LM ? lmc0 + (size_t)(cur ^ 1) * W * V : nullptr;
+    const IO* const row = lp + (int64_t)t * p.sT;
+    auto LP = [&](int c) -> double { return (double)row[(int64_t)c * p.sV]; };
+    if (tid == 0) { s_hi = 0u; s_lo = 0xffffffffu; s_total_new = 0; }
+    for (int h = tid; h < kSelBins; h += kThreads) hist[h] = 0;
+    __syncthreads();
+    // ---- pairs: candidate q = c*n + i is the reference's order (character outer, prefix inner, :370-395) ----
+    const int npairs = n * V;
+    int my_new = 0;
+    unsigned key_hi = 0u, key_lo = 0xffffffffu;
+    for (int e = tid; e < npairs; e += kThreads) {
+      const int ii = e / V, ci = e - ii * V;
+      const double full = A.full[ii], ppb = A.ppb[ii];
+      const int last = A.last[ii];
+      const double curp = LP(ci);
+      unsigned long long* const slot = gkey + n + (size_t)ci * n + ii;
+      if (ci == blank) { *slot = kNoCandKey; A.npb[ii] = curp + full; continue; }   // :374-376 (prob_blank was -inf)
+      const double val = curp + (ci == last ? ppb : full);                     // :383-385 / :389-391
+      const int k = cmA.find(ii * V + ci);
+      unsigned long long uk = kNoCandKey;
+      if (k >= 0) {
+        const int j = mapA.find(k);
+        if (j >= 0) A.inc[j] = val;            // the child is a beam member: its share from this parent
+        // else: alive but pruned (Q7) -- the probability is lost and the slot stays taken
+      } else {
+        LmFields pr, nl;
+        pr.num_words = A.lm[ii].num_words;
+        if (LM) { pr.lm_score = A.lm[ii].lm_score; pr.lm_before = A.lm[ii].lm_before; pr.num_oov = A.lm[ii].num_oov; pr.num_oov_before = A.lm[ii].num_oov_before; }
+        LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
+        if (LM) ans = lmcA[(size_t)ii * V + ci];
+        child_score_fields<LM>(p, pr, last, ci, ans, nl);
+        const double sc = beam_score<LM>(p, val, ninf(), nl);                  // after next_step: prev_pnb = val, prev_pb = -inf
+        uk = okey(sc);
+        key_hi = max(key_hi, (unsigned)(uk >> 32));
+        my_new++;
+      }
+      *slot = uk;
+    }
+    {
+      const int incl = wave_scan_i(my_new);
+      if (lane == 63 && incl) atomicAdd(&s_total_new, incl);
+    }
+    gsync();
+    // ---- members: repeated-character share (:386-387), next_step (:337-342), score ----
+    for (int i = tid; i < n; i += kThreads) {
+      const int lc = A.last[i];
+      double pnb = A.inc[i];
+      if (lc >= 0 && lc != blank) pnb = lse2(pnb, LP(lc) + A.ppnb[i]);
+      A.npnb[i] = pnb;
+      const double nf = lse2(pnb, A.npb[i]);
+      A.nfull[i] = nf;
+      const double sc = beam_score_full<LM>(p, nf, A.lm[i]);
+      const unsigned long long uk = okey(sc);
+      gkey[i] = uk;
+      const unsigned h32 = (unsigned)(uk >> 32);
+      key_hi = max(key_hi, h32); key_lo = min(key_lo, h32);
+    }
+    key_hi = (unsigned)wave_max_i((int)(key_hi ^ 0x80000000u)) ^ 0x80000000u;
+    key_lo = ~((unsigned)wave_max_i((int)((~key_lo) ^ 0x80000000u)) ^ 0x80000000u);
+    if (lane == 0) { atomicMax(&s_hi, key_hi); atomicMin(&s_lo, key_lo); }
+    for (int h = tid; h < p.HS; h += kThreads) mapB.key[h] = -1;
+    for (int h = tid; h < g.CH; h += kThreads) cmB.key[h] = -1;
+    gsync();
+    const int total_new = s_total_new;
+    const int nreal = n + total_new;                // candidates that exist
+    const size_t ntot = (size_t)n + (size_t)npairs; // entries of gkey[]
+    const int nsel = nreal > W ? W : nreal;
+    // candidate d takes place j of the new beam (see the fast kernel's `place`)
+    auto place = [&](int j, int d) {
+      if (d < n) {
+        const int i = d;
+        A.kept[i] = 1; A.newpos[i] = j; Bm.from[j] = i;
+        Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i]; Bm.full[j] = A.nfull[i];
+        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; copy_lm<LM>(Bm.lm[j], A.lm[i]);
+        Bm.gown[j] = A.gown[i]; Bm.gchar[j] = A.gchar[i]; Bm.gnode[j] = A.gnode[i];
+        mapB.insert(A.node[i], j);
+      } else {
+        const int q = d - n;
+        const int c = q / n, i = q - c * n;
+        const double val = LP(c) + (c == A.last[i] ? A.ppb[i] : A.full[i]);
+        LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
+        if (LM) ans = lmcA[(size_t)i * V + c];
+        child_lm<LM>(p, lt, A.lm[i], A.last[i], c, ans, Bm.lm[j]);
+        int k = atomicAdd(&s_next_node, 1);                                       // make_shared<Prefix>, :254
+        if (k >= p.NCAP) { s_err = 1; k = 0; }
+        else {
+          BeamNode nn;
+          nn.parent = A.node[i]; nn.last_char = c;
+          nodes[k] = nn;
+          mapB.insert(k, j);
+        }
+        Bm.ppb[j] = ninf(); Bm.ppnb[j] = val; Bm.full[j] = lse2(val, ninf()); Bm.node[j] = k; Bm.last[j] = c;
+        Bm.gown[j] = i; Bm.gchar[j] = c; Bm.gnode[j] = k;
+        Bm.from[j] = -1;
+      }
+    };
+    // this thread's contiguous chunk of candidate positions (ordered passes below)
+    const size_t per = (ntot + kThreads - 1) / kThreads;
+    const size_t d0 = min((size_t)tid * per, ntot), d1 = min(d0 + per, ntot);
+    if (nreal > W) {                                                             // :405-415
+      // ---- radix select of the W-th largest key, 11 bits per pass, from the first bit that can differ ----
+      const unsigned H32 = s_hi, L32 = n == W ? s_lo : 0u;
+      const unsigned xdiff = H32 ^ L32;
+      const int hb = xdiff ? 63 - __builtin_clz(xdiff) : 31;
+      unsigned long long mask = hb == 63 ? 0ULL : ~0ULL << (hb + 1);
+      unsigned long long prefix = ((unsigned long long)H32 << 32) & mask;
+      int krem = W;
+      bool done = false;
+      int shift = hb + 1 - kSelBits;
+      for (;;) {
+        const int nbits = 64 - __builtin_popcountll(mask) - shift;
+        const int width = nbits < kSelBits ? nbits : kSelBits;
+        const unsigned long long dmask = (1ULL << width) - 1ULL;
+        for (size_t d = tid; d < ntot; d += kThreads) {
+          const unsigned long long u = gkey[d];
+          if ((u & mask) == prefix && u != kNoCandKey) atomicAdd(&hist[(int)((u >> shift) & dmask)], 1);
+        }
+        __syncthreads();
+        constexpr int kPer = kSelBins / kThreads;
+        const int top = kSelBins - 1 - kPer * tid;
+        int cnt[kPer], mine = 0;
+#pragma unroll
+        for (int jj = 0; jj < kPer; jj++) { cnt[jj] = hist[top - jj]; mine += cnt[jj]; }
+        const int inc = wave_scan_i(mine);
+        if (lane == 63) s_part[wid] = inc;
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < kPer; jj++) hist[top - jj] = 0;
+        int above = inc - mine;
+        {
+          const int wtot = wave_scan_i(lane < kThreads / 64 ? s_part[lane] : 0);
+          if (wid > 0) above += __builtin_amdgcn_readlane(wtot, wid - 1);
+        }
+        const unsigned long long digit_mask = dmask << shift;
+        if (above < krem && above + mine >= krem) {
+#pragma unroll
+          for (int jj = 0; jj < kPer; jj++) {
+            if (above + cnt[jj] >= krem) {
+              s_krem = krem - above;
+              s_prefix = (prefix & ~digit_mask) | ((unsigned long long)(top - jj) << shift);
+              s_done = cnt[jj] == krem - above ? 1 : 0;     // the whole bin survives: no finer threshold needed
+              break;
+            }
+            above += cnt[jj];
+          }
+        }
+        mask |= digit_mask;
+        __syncthreads();
+        krem = s_krem; prefix = s_prefix; done = s_done != 0;
+        if (done || shift == 0) break;
+        shift = shift - kSelBits > 0 ? shift - kSelBits : 0;
+        __syncthreads();
+      }
+      // ---- gather: keys above the threshold, then the first krem of those equal to it, in position order ----
+      const unsigned long long Tk = prefix;
+      int ngt = 0, neq = 0;
+      for (size_t d = d0; d < d1; d++) {
+        const unsigned long long uf = gkey[d], u = uf & mask;
+        ngt += u > Tk; neq += (u == Tk && uf != kNoCandKey);
+      }
+      const int igt = wave_scan_i(ngt), ieq = wave_scan_i(neq);
+      if (lane == 63) { s_part[wid] = igt; s_part[16 + wid] = ieq; }
+      __syncthreads();
+      int og = igt - ngt, oe = ieq - neq, tg = 0;
+      for (int w2 = 0; w2 < kThreads / 64; w2++) { if (w2 < wid) { og += s_part[w2]; oe += s_part[16 + w2]; } tg += s_part[w2]; }
+      for (size_t d = d0; d < d1; d++) {
+        const unsigned long long uf = gkey[d], u = uf & mask;
+        if (u > Tk) { uskey[og] = uf; sidx[og] = (int)d; og++; }
+        else if (u == Tk && uf != kNoCandKey) { if (oe < krem) { uskey[tg + oe] = uf; sidx[tg + oe] = (int)d; } oe++; }
+      }
+      const int M = tg + krem;                      // == W
+      __syncthreads();
+      // ---- rank by (score desc, position asc): eight lanes count for one candidate ----
+      for (int e0 = 0; e0 < M; e0 += kThreads / 8) {
+        const int e = e0 + (tid >> 3), part = tid & 7;
+        int cnt = 0;
+        if (e < M) {
+          const unsigned long long ke = uskey[e];
+          for (int jj = part; jj < M; jj += 8) {
+            const unsigned long long kj = uskey[jj];
+            cnt += (kj > ke || (kj == ke && jj < e)) ? 1 : 0;
+          }
+        }
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);
+        cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);
+        if (e < M && part == 0 && cnt < W) place(cnt, sidx[e]);
+      }
+    } else {
+      // nothing is pruned: old members, then the pairs that exist, in order
+      int mine = 0;
+      for (size_t d = max(d0, (size_t)n); d < d1; d++) mine += gkey[d] != kNoCandKey;
+      const int incl = wave_scan_i(mine);
+      if (lane == 63) s_part[wid] = incl;
+      __syncthreads();
+      int pos = n + incl - mine;
+      for (int w2 = 0; w2 < wid; w2++) pos += s_part[w2];
+      for (size_t d = max(d0, (size_t)n); d < d1; d++)
+        if (gkey[d] != kNoCandKey) sidx[pos++] = (int)d;
+      for (int j = tid; j < n; j += kThreads) sidx[j] = j;
+      __syncthreads();
+      for (int j = tid; j < nsel; j += kThreads) place(j, sidx[j]);
+    }
+    gsync();
+    // ---- guards and child map of the new beam (see the fast kernel) ----
+    for (int j = tid; j < nsel; j += kThreads) {
+      Bm.inc[j] = ninf(); Bm.kept[j] = 0;
+      int go = Bm.gown[j], gc = Bm.gchar[j], gn = Bm.gnode[j];
+      while (go >= 0 && !A.kept[go]) { const int o = go; go = A.gown[o]; gc = A.gchar[o]; gn = A.gnode[o]; }
+      if (go >= 0) {
+        const int o = A.newpos[go];
+        Bm.gown[j] = o; Bm.gchar[j] = gc; Bm.gnode[j] = gn;
+        cmB.insert(o * V + gc, gn);
+      } else {
+        Bm.gown[j] = -1;
+      }
+    }
+    if (LM) {
+      // the LM's answers for the new beam: rows copied with members that stay, asked for members that are new
+      for (size_t e = tid; e < (size_t)nsel * V; e += kThreads) {
+        const int j2 = (int)(e / V), c = (int)(e - (size_t)j2 * V);
+        const int f = Bm.from[j2];
+        if (f >= 0) lmcB[e] = lmcA[(size_t)f * V + c];
+        else if (c != blank && c != p.space_id) lmcB[e] = lm_query<LMK == 2>(p, lt, Bm.lm[j2], Bm.last[j2], c);
+      }
+    }
+    gsync();
+    n = nsel; cur ^= 1;
+    if (s_err) break;
+  }
+
+  // ---- final sort (:418-424) reduces to the best prefix; its sentence (:232-245) ----
+  {
+    Members A;
+    A.carve(mem0 + (size_t)cur * mbytes, W);
+    for (int i = tid; i < n; i += kThreads) fkey[i] = beam_score<LM>(p, A.ppnb[i], A.ppb[i], A.lm[i]);
+    __syncthreads();
+  }
+  int64_t* out = p.out + (int64_t)b * p.max_out;
+  for (int64_t i = tid; i < p.max_out; i += kThreads) out[i] = 0;
+  gsync();
+  if (tid == 0) {
+    int bi = 0;
+    for (int i = 1; i < n; i++) if (fkey[i] > fkey[bi]) bi = i;            // first maximum = (score desc, position asc)
+    Members A;
+    A.carve(mem0 + (size_t)cur * mbytes, W);
+    const int best = A.node[bi];
+    int64_t m = 0;
+    for (int k = best; k >= 0; k = nodes[k].parent) if (k == best || nodes[k].parent >= 0) m++;
+    int64_t at = m;
+    for (int k = best; k >= 0; k = nodes[k].parent)
+      if (k == best || nodes[k].parent >= 0) { at--; if (at < p.max_out) out[at] = nodes[k].last_char; }
+    p.out_len[b] = s_err ? (int64_t)-1 : m;
+  }
+}
+
+struct GenLayout { size_t gkey, lmc, total, lds; int CH; };
+GenLayout gen_layout(int B, int V, int W, int WP2, int HS, bool lm) {
+  GenLayout l;
+  l.CH = 256; while (l.CH < 4 * W) l.CH <<= 1;
+  size_t o = 0;
+  l.gkey = o; o += align_up((size_t)B * ((size_t)W + (size_t)W * V) * sizeof(unsigned long long), 256);
+  l.lmc = o; if (lm) o += align_up((size_t)B * 2 * (size_t)W * V * sizeof(LmAnswer), 256);
+  l.total = o;
+  l.lds = 2 * Members::bytes(W) + (sizeof(unsigned long long) + sizeof(double) + sizeof(int)) * (size_t)(WP2 + 8) +
+          sizeof(int) * (kSelBins + 64 + 4 * (size_t)HS + 4 * (size_t)l.CH) + 64;
+  return l;
+}
+
 struct BeamLayout { size_t nodes, total, lds; int NCAP, CMAX, WP2, HS; };
 
 BeamLayout beam_layout(int B, int T, int V, int W, bool lm = false) {
@@ -1185,7 +1563,7 @@ BeamLayout beam_layout(int B, int T, int V, int W, bool lm = false) {
 }  // namespace
 }  // namespace e2e
 
-// does one workgroup's LDS hold the beam of this width over this alphabet? (same tests as e2e_ctc_beam)
+// does one workgroup's LDS hold the beam of this width over this alphabet? (the fast kernel)
 static bool beam_fits(int V, int W, bool lm) {
   if (V < 1 || W < 1) return false;
   if ((long long)W * V + W + 8 > kMaxCand || W > kSelBins) return false;
@@ -1193,20 +1571,29 @@ static bool beam_fits(int V, int W, bool lm) {
   const BeamLayout l = beam_layout(1, 1, V, W, lm);
   return l.lds <= (size_t)kLdsBudget;
 }
+// ... the general kernel (everything that scales with the alphabet is in the workspace)
+static bool gen_fits(int V, int W, bool lm) {
+  if (V < 1 || W < 1 || W > kGenMaxW || (long long)W * V > 0x7fffffffLL / 2) return false;
+  const BeamLayout l = beam_layout(1, 1, V, W, lm);
+  return gen_layout(1, V, W, l.WP2, l.HS, lm).lds <= (size_t)kLdsBudget;
+}
 
 extern "C" int e2e_ctc_beam_max_width(int V, int with_lm) {
   if (V < 1) return 0;
   int lo = 0, hi = kSelBins;                    // the largest supported width (the tests are monotone in the width)
   while (lo < hi) {
     const int mid = (lo + hi + 1) / 2;
-    if (beam_fits(V, mid, with_lm != 0)) lo = mid; else hi = mid - 1;
+    if (beam_fits(V, mid, with_lm != 0) || gen_fits(V, mid, with_lm != 0)) lo = mid; else hi = mid - 1;
   }
   return lo;
 }
 
 extern "C" size_t e2e_ctc_beam_workspace_bytes(int B, int T, int V, int beam_width) {
   if (B < 0 || T < 1 || V < 1 || beam_width < 1) return 0;
-  return beam_layout(B, T, V, beam_width).total + 256;
+  const BeamLayout l = beam_layout(B, T, V, beam_width, true);
+  // (sized for the general kernel with a language model: whether a model is used, and which kernel runs, is decided per call)
+  const size_t gen = gen_fits(V, beam_width, true) ? gen_layout(B, V, beam_width, l.WP2, l.HS, true).total : 0;
+  return l.total + gen + 256;
 }
 
 extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, int64_t sV,
@@ -1236,18 +1623,19 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
     }
   }
   const BeamLayout l = beam_layout(B, T, V, beam_width, lm != nullptr);
-  if (lm && 2 * beam_width > kStateSlots) {
-    set_error("beam_width = %d with a language model: at most %d", beam_width, kStateSlots / 2);
+  static const bool force_general = getenv("E2E_BEAM_GENERAL") != nullptr;      // (tests: the whole suite through the general kernel)
+  const bool fast_ok = beam_fits(V, beam_width, lm != nullptr), gen_ok = gen_fits(V, beam_width, lm != nullptr);
+  const bool general = gen_ok && (!fast_ok || force_general);
+  if (!fast_ok && !gen_ok) {
+    set_error("beam_width = %d over an alphabet of %d%s: at most %d (one workgroup's LDS holds the beam)", beam_width, V,
+              lm ? " with a language model" : "", e2e_ctc_beam_max_width(V, lm != nullptr));
     return E2E_ERR_UNSUPPORTED;
   }
-  if (l.CMAX > kMaxCand || l.lds > (size_t)kLdsBudget || beam_width > kSelBins) {
-    set_error("beam_width*alphabet = %d candidates per step (%zu B of LDS) exceed what one workgroup holds (%d, %d B)",
-              l.CMAX, l.lds, kMaxCand, kLdsBudget);
-    return E2E_ERR_UNSUPPORTED;
-  }
+  const GenLayout gl = gen_layout(B, V, beam_width, l.WP2, l.HS, lm != nullptr);
   uintptr_t base = reinterpret_cast<uintptr_t>(workspace);
   const uintptr_t aligned = (base + 255) & ~(uintptr_t)255;
-  if (!workspace || workspace_bytes < l.total + (aligned - base)) { set_error("workspace too small: need %zu", l.total + 256); return E2E_ERR_WORKSPACE; }
+  const size_t need = l.total + (general ? gl.total : 0);
+  if (!workspace || workspace_bytes < need + (aligned - base)) { set_error("workspace too small: need %zu", need + 256); return E2E_ERR_WORKSPACE; }
   if (B == 0) return E2E_OK;
   char* ws = reinterpret_cast<char*>(aligned);
   BeamParams p;
@@ -1262,6 +1650,24 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
   p.NCAP = l.NCAP; p.CMAX = l.CMAX; p.WP2 = l.WP2; p.HS = l.HS;
   hipStream_t s = (hipStream_t)stream;
   const bool fast_lm = lm && lm->d_ngs && lm->order - 1 <= kParCtx;
+  if (general) {
+    GenParams g;
+    g.gkey = reinterpret_cast<unsigned long long*>(ws + l.total + gl.gkey);
+    g.lmc = lm ? reinterpret_cast<LmAnswer*>(ws + l.total + gl.lmc) : nullptr;
+    g.CH = gl.CH;
+    const void* gfn;
+    if (dtype == E2E_F32)
+      gfn = !lm ? (const void*)&ctc_beam_general_kernel<float, 0>
+                : fast_lm ? (const void*)&ctc_beam_general_kernel<float, 2> : (const void*)&ctc_beam_general_kernel<float, 1>;
+    else
+      gfn = !lm ? (const void*)&ctc_beam_general_kernel<double, 0>
+                : fast_lm ? (const void*)&ctc_beam_general_kernel<double, 2> : (const void*)&ctc_beam_general_kernel<double, 1>;
+    E2E_HIP_CHECK(hipFuncSetAttribute(gfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gl.lds), "hipFuncSetAttribute");
+    void* gargs[] = { &p, &g };
+    E2E_HIP_CHECK(hipLaunchKernel(gfn, dim3(B), dim3(kGenThreads), gargs, gl.lds, s), "ctc_beam_general_kernel launch");
+    E2E_HIP_CHECK(hipGetLastError(), "ctc_beam_general_kernel launch");
+    return E2E_OK;
+  }
   const void* fn;
   if (dtype == E2E_F32)
     fn = !lm ? (const void*)&ctc_beam_kernel<float, 0, kThreadsNoLm>

@@ -109,10 +109,37 @@ def test_lm_changes_the_answer():
     assert s0 == "b a" and s1 == "a b"
 
 
-def test_too_many_candidates_is_reported():
+def test_too_wide_a_beam_is_reported():
     from end2end_amd._lib import E2EError
-    with pytest.raises(E2EError, match="candidates"):
-        U.c_abi_beam(rand_lp(1, 1, 4, 100), None, 0, 100, None)
+    with pytest.raises(E2EError, match="at most 256"):
+        U.c_abi_beam(rand_lp(1, 1, 4, 100), None, 0, 300, None)
+
+
+@pytest.mark.parametrize("V,W,T", [(100, 100, 40), (200, 100, 60), (1000, 50, 30), (8000, 20, 12), (300, 256, 25)])
+def test_wide_alphabets_take_the_general_kernel_and_match_the_oracle(V, W, T):
+    """Alphabets the one-workgroup-LDS kernel cannot hold at this width (the reference has no limit,
+    ctc_decoder.cpp:353-441): the general kernel -- keys, child tables and LM answers in the workspace -- must give the
+    oracle's result.  Includes the reference's default beam_width = 100 at V >= 82."""
+    labels = ["_"] + ["w%d" % i for i in range(V - 2)] + [" "]
+    lp = rand_lp(500 + V, 3, T, V, sharp=3.0)
+    same_as_oracle(lp, [T, T - 3, max(T // 2, 1)], 0, W, labels, wip=0.5)
+    same_as_oracle(lp.float(), None, V - 1, W, None, wip=0.0)          # blank last, no labels, f32
+
+
+def test_general_kernel_with_a_language_model_matches_the_oracle(tmp_path):
+    # 120 single-letter-pair labels: beyond the fast kernel's range with an LM at width 60; words are spelled from them
+    letters = "abcde"
+    labels = ["_", " "] + [a for a in letters] + [a + b2 for a in letters for b2 in letters] + ["x%d" % i for i in range(88)]
+    V = len(labels)
+    path = str(tmp_path / "lm.arpa")
+    _write_arpa(path, letters, 120, 3, seed=9)
+    lm = LanguageModel(path, labels, True)
+    olm = O.OracleLM(path)
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(3, 40, V, generator=g, dtype=torch.float64) * 2.0
+    x[:, :, 1:32] += 3.0
+    lp = torch.log_softmax(x, -1)
+    same_as_oracle(lp, [40, 31, 17], 0, 60, labels, lm, olm, lmwt=1.2, wip=0.3, oov_penalty=-3.0, case_sensitive=True)
 
 
 def test_full_c4_shape_properties():
@@ -351,3 +378,18 @@ def test_language_model_follows_the_logits_device():
             ws = torch.empty(_C.ctc_beam_workspace_bytes(2, 20, 4, 8), dtype=torch.uint8, device="cuda:1")
             _C.ctc_beam(x.data_ptr(), R.F32, *x.stride(), xl.data_ptr(), 2, 20, 4, 0, 8, 3, lm.on(torch.device("cuda", 0)).handle,
                         1.0, 0.0, -10.0, out.data_ptr(), 21, ol.data_ptr(), ws.data_ptr(), ws.numel(), 0)
+
+
+def test_whole_suite_through_the_general_kernel():
+    """Every test of this file again with E2E_BEAM_GENERAL=1 (read once per process: a child pytest), so that the general
+    kernel is held to the same known answers, brute-force goldens, tie cases, LM cases and sweeps as the fast one."""
+    import subprocess
+    import sys
+    if os.environ.get("E2E_BEAM_GENERAL"):
+        pytest.skip("already inside the child run")
+    env = dict(os.environ, E2E_BEAM_GENERAL="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x",
+                          "-k", "not full_c4 and not c4_shape and not whole_suite"],
+                         env=env, capture_output=True, text=True, timeout=1500,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

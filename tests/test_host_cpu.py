@@ -127,14 +127,15 @@ def test_decoder_wrapper_parameter_checks(tmp_path):
 def test_beam_width_limits_are_queryable_and_enforced_at_construction():
     from end2end_amd import _C
     from end2end_amd.engines import CTCDecoderEngine
-    assert _C.ctc_beam_max_width(29, False) >= 100 and _C.ctc_beam_max_width(29, True) >= 100     # the reference default
-    assert _C.ctc_beam_max_width(8000, False) == 0
+    # the fast kernel's range is bounded by the alphabet; beyond it the general kernel takes over, up to width 256
+    for V in (4, 29, 200, 8000):
+        assert _C.ctc_beam_max_width(V, False) == 256 and _C.ctc_beam_max_width(V, True) == 256
     labels = ["_"] + ["l%d" % i for i in range(199)]
-    cap = _C.ctc_beam_max_width(200, False)
-    CTCDecoderEngine(0, cap, labels)
+    CTCDecoderEngine(0, 256, labels)
     with pytest.raises(ValueError, match="beam_width"):
-        CTCDecoderEngine(0, cap + 1, labels)
+        CTCDecoderEngine(0, 257, labels)
     CTCDecoderEngine(0, 1, labels)           # greedy has no such limit
+    assert _C.ctc_beam_workspace_bytes(8, 256, 8000, 100) > 8 * 100 * 8000 * 8
 
 
 def test_kenlm_binary_models_are_refused_with_a_clear_message(tmp_path):
