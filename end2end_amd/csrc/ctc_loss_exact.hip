@@ -511,7 +511,7 @@ size_t retry_lds_bytes(int V) { return sizeof(double) * (kThreads / 64) * kFastS
 
 }  // namespace
 
-constexpr int kFallbackSlabs = 32;     // workgroups (= alpha slabs) of the flagged-utterance fallback launch
+constexpr int kFallbackSlabs = 256;    // workgroups (= alpha slabs, 3.2 MB each at C2) of the flagged-utterance fallback launch
 
 static size_t exact_bytes_for(int slabs, int T, int Smax) {
   const size_t Lmax = 2 * (size_t)Smax + 1;
