@@ -63,6 +63,19 @@ for case in range(n_cases):
                 lb, _ = O.ctc_loss(lp_ref.numpy()[b_:b_ + 1, :n_], sb[None, :], [n_], [len(sb)], blank)
                 if len(sa) == 0 or len(sb) == 0 or abs(la[0] - lb[0]) > 1e-12 * max(1.0, abs(la[0])): tie = False; break
             if tie: print("(mathematical tie between prefixes, decided by the last bit of libm: case %d)" % case); continue
+        # ... or cascade: with rounded emissions scores that are mathematically equal differ in the last bit between the
+        # device's and the host's exp/log, a different candidate is pruned mid-way and the final answers differ without
+        # being ties themselves.  Probe: emissions perturbed by ~1e-11 break the exact ties and change nothing else -- a
+        # logic error survives that, a tie does not.
+        if style == 1 and not with_lm:
+            prng = np.random.default_rng(case)
+            survived = 0
+            for _ in range(8):
+                qn = lp_ref.numpy() + prng.normal(size=tuple(lp_ref.shape)) * 1e-11
+                i2, l2 = U.c_abi_beam(torch.from_numpy(qn), xl, blank, W, labels, lm, **gpu_kw)
+                o2, ol2, _ = O.ctc_beam(qn, xl, blank, W, labels, olm, **kw)
+                survived += (l2.tolist() != ol2.tolist() or i2.tolist() != o2.tolist())
+            if survived == 0: print("(cascade of mathematical ties, gone under a 1e-11 perturbation: case %d)" % case); continue
         bad += 1
         if only is not None:
             for b_ in range(B):
