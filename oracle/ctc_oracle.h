@@ -12,12 +12,21 @@
  *     oracle/Makefile) and against the reference tests' known answers
  *     (tests/test_ctc.py:69-165) -- see tests/test_oracle_*.py.
  *   - greedy / beam (no LM): pinned on the reference tests' known answers
- *     (tests/test_ctc_decoder.py:44-59,86-166).  The reference decoder cannot
- *     be compiled here (needs KenLM's lm/model.hh, absent), so beyond those
- *     vectors the beam search is pinned by restatement only.
- *   - LM-scored beam: PARITY UNPINNED (KenLM and its ARPA fixture are absent
- *     from /root/reference; the reference's only LM tests print or are
- *     skipped, tests/test_ctc_decoder.py:62-83,168-181).
+ *     (tests/test_ctc_decoder.py:44-59,86-166) and on exhaustive enumeration of
+ *     every alignment of 20 short utterances (tests/golden/make_beam_golden.py:
+ *     a beam that never prunes must return argmax log P - wip * num_words).  The
+ *     reference decoder cannot be compiled here (needs KenLM's lm/model.hh,
+ *     absent), so pruned-beam behaviour (quirk Q7, tie order) is pinned by
+ *     restatement only.
+ *   - LM scorer: pinned to the definition of the ARPA format (expected
+ *     BaseScore of every (context, word) of two models of 527 / 427 entries,
+ *     derived in pure Python by tests/golden/make_lm_golden.py, no code shared
+ *     with this file).  Agreement with a KenLM BINARY on a real corpus model is
+ *     unpinned: KenLM and its ARPA fixture are absent from /root/reference and
+ *     the reference's only LM tests print or are skipped
+ *     (tests/test_ctc_decoder.py:62-83,168-181).
+ *   - forced alignment: pinned on outputs of the reference's own functions
+ *     (pytorch_end2end/utils/alignment.py, run by tests/golden/make_align_golden.py).
  *
  * All arithmetic is IEEE double, as in the reference (scalar_t = double,
  * src/losses/ctc_loss.cpp:10; decode: src/decoders/ctc_decoder.cpp:157).

@@ -1,6 +1,7 @@
-"""CPU: the ARPA reader / back-off scorer of the product library (host tables) against hand-computed values and
-against the oracle's independent C implementation.  LM parity with KenLM itself is UNPINNED (KenLM and its ARPA
-fixture are absent from the reference tree); these tests pin the published ARPA back-off semantics."""
+"""CPU: the ARPA reader / back-off scorer of the product library (host tables) and the oracle's C implementation against
+(a) hand-computed values, (b) each other, (c) expected scores derived in pure Python straight from the definition of the
+ARPA format (tests/golden/make_lm_golden.py -- the independent pin).  KenLM itself cannot be run here (absent from the
+reference tree and the image): agreement with a KenLM binary on a real corpus model stays unpinned."""
 import gzip
 import os
 import shutil
