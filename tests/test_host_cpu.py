@@ -145,3 +145,27 @@ def test_kenlm_binary_models_are_refused_with_a_clear_message(tmp_path):
     p.write_bytes(b"mmap lm http://kheafield.com/code format version 5\n\x00" + bytes(200))
     with pytest.raises(E2EError, match="KenLM binary"):
         LanguageModel(str(p), ["_", "a"], True)
+
+
+def test_bench_helpers(tmp_path, monkeypatch):
+    """bench.py's host-side pieces: the recorded PMC traffic is found for the headline workload, the synthetic ARPA is
+    deterministic, and `--gpus N` without a launcher starts N ranks through torch.distributed.run on 127.0.0.1."""
+    import bench
+    t = bench.recorded_traffic(bench.WORKLOAD["name"])
+    assert t is not None and 2.5e8 < t < 3.5e8
+    labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
+    a, b = tmp_path / "a.arpa", tmp_path / "b.arpa"
+    bench.synthetic_arpa(str(a), labels, n_words=200, seed=3)
+    bench.synthetic_arpa(str(b), labels, n_words=200, seed=3)
+    assert a.read_text() == b.read_text() and "\\3-grams:" in a.read_text()
+    seen = {}
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+
+    class A:
+        gpus = 4
+    assert bench.launch_ranks(A) == 0
+    cmd = seen["cmd"]
+    assert "torch.distributed.run" in cmd and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
