@@ -39,7 +39,7 @@ constexpr int kSeg = kFastSeg;  // steps per F2 segment == checkpoint spacing (1
 constexpr int kBlk = 8;         // prep -> chain hand-off block and rescale period
 constexpr int kRingBlks = 8;    // ring depth (blocks)
 constexpr int kRow = 10;        // doubles per label row of a ring block: 8 steps + pad (80 B spreads the 16-byte gathers over the banks)
-constexpr int kMaxSmallV = 96;  // alphabet columns the lattice kernels take (prep: <= 6 columns per lane)
+constexpr int kMaxSmallV = 96;  // alphabet columns the lattice kernels take (prep: <= 12 columns per lane)
 
 struct FastParams {
   const float* x; int64_t sB, sT, sV; int logprobs;
@@ -226,6 +226,20 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// all-reduce inside each group of 8 lanes
+__device__ __forceinline__ float row8_max(float v) {
+  v = fmaxf(v, __int_as_float(dpp_i<0xB1>(0, __float_as_int(v))));
+  v = fmaxf(v, __int_as_float(dpp_i<0x4E>(0, __float_as_int(v))));
+  v = fmaxf(v, __int_as_float(dpp_i<0x141>(0, __float_as_int(v))));     // row_half_mirror: lane i <-> 7-i
+  return v;
+}
+__device__ __forceinline__ float row8_sum(float v) {
+  v += __int_as_float(dpp_i<0xB1>(0, __float_as_int(v)));
+  v += __int_as_float(dpp_i<0x4E>(0, __float_as_int(v)));
+  v += __int_as_float(dpp_i<0x141>(0, __float_as_int(v)));
+  return v;
+}
+
 // Hand-off words live in LDS and guard LDS data only.  The LDS executes one wave's operations in order, so the
 // producer needs no wait between its data writes and the flag write, and the consumer only has to keep the
 // compiler from hoisting its data reads above the flag read.  (A workgroup-scope release fence would also drain
@@ -233,6 +247,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 #ifdef E2E_FAST_PROFILE
 } __device__ unsigned long long g_prof[256 * 4 * 4]; namespace {   // [wg][wave][total, spin, nspin, -]
 } __device__ unsigned long long g_prof2[16384 * 8]; namespace {      // F2 phase cycles per workgroup (first 16384)
+} __device__ unsigned long long g_prof3[256 * 16 * 4]; namespace {  // halo chains: [wg][dir*8 + wave][total, probability-ring wait, neighbour wait, frame wait]
 } __device__ float g_zdev[16384]; namespace {                         // F2 self-check: log2 deviation per workgroup
 __shared__ unsigned long long s_prof_prev;
 __shared__ unsigned long long s_prof_acc[8];
@@ -267,6 +282,22 @@ __device__ __forceinline__ void publish(volatile int* p, int v) {
   *(volatile lds_int*)p = v;
 }
 __device__ __forceinline__ int peek(volatile int* p) { return *(volatile lds_int*)p; }
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef double h_d2 __attribute__((ext_vector_type(2)));
+typedef int h_i4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) h_d2 lds_d2;      // (every LDS access of these waves is a DS operation: a wave's DS
+typedef __attribute__((address_space(3))) double lds_f64;   //  operations execute in order, which the hand-off words rely on)
+typedef __attribute__((address_space(3))) h_i4 lds_i4;
+
+// smallest / largest of the eight words at a 32-byte aligned LDS address (wave-uniform)
+__device__ __forceinline__ int lds_min8(lds_u8* a) {
+  const h_i4 u = *(volatile lds_i4*)a, v = *(volatile lds_i4*)(a + 16);
+  return min(min(min(u.x, u.y), min(u.z, u.w)), min(min(v.x, v.y), min(v.z, v.w)));
+}
+__device__ __forceinline__ int lds_max8(lds_u8* a) {
+  const h_i4 u = *(volatile lds_i4*)a, v = *(volatile lds_i4*)(a + 16);
+  return max(max(max(u.x, u.y), max(u.z, u.w)), max(max(v.x, v.y), max(v.z, v.w)));
+}
 
 // per-lane lattice description shared by F1 and F2: lane holds pairs i = PPL*lane + r
 template <int PPL>
@@ -323,12 +354,14 @@ struct LaneCells {
 // F1 device code
 // ============================================================================================
 // LDS of F1.  Per direction a ring of kRingBlks blocks; a block holds the probabilities of its 8 steps TRANSPOSED:
-// [label v][step] floats (32 B per label), plus an all-zero row V for lattice cells past the utterance's labels.
+// [label v][step] doubles, plus an all-zero row V for lattice cells past the utterance's labels and a row V+1 that holds
+// the blank's probability times the squared tilt (what a label cell takes from the blank below it: one multiplication
+// per step and wave less in the halo chains).
 // What costs on this machine is the number of LDS instructions (a wave pays >= 12 cycles for each, whatever its
 // width), so the per-lane gather is arranged to pull 4 consecutive time steps of the lane's label per instruction:
 // 2 reads per label cell and block instead of 8, and the producers need no gather at all.
 struct F1Lds {
-  double* ring;      // [2][kRingBlks][V+1][kRow]  (f64: saves the chains' conversions, 2.5 % of the step at B = 256.  It
+  double* ring;      // [2][kRingBlks][V+2][kRow]  (f64: saves the chains' conversions, 2.5 % of the step at B = 256.  It
                      //  costs them 30 VGPRs, though: at 146 a second workgroup does not fit on the CU, which an f32 ring
                      //  (114) allows -- measured +7 % at B = 1024 with the second workgroup's roles rotated onto SIMDs 1/3)
   int* filled;       // [2][kRingBlks]   probability block n of a direction is complete (== n+1)
@@ -337,13 +370,13 @@ struct F1Lds {
   int blk_elems;
   static constexpr int kSyncInts = 2 * kRingBlks + 2;
   __device__ F1Lds(unsigned char* smem, int V) {
-    blk_elems = (V + 1) * kRow;
+    blk_elems = (V + 2) * kRow;
     ring = reinterpret_cast<double*>(smem);
     filled = reinterpret_cast<int*>(ring + 2 * kRingBlks * blk_elems);
     took = filled + 2 * kRingBlks;
     sortcnt = took + 2;
   }
-  __host__ __device__ static size_t bytes(int V) { return sizeof(double) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * (kSyncInts + 130); }
+  __host__ __device__ static size_t bytes(int V) { return sizeof(double) * 2 * kRingBlks * (V + 2) * kRow + sizeof(int) * (kSyncInts + 130); }
 };
 
 // Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
@@ -365,11 +398,15 @@ __device__ __forceinline__ float exp_le0(float x) {
   return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 
-// Probability rows for one chain: each 16-lane DPP row of the wave takes one time step (4 steps per pass), a
-// lane holds the columns v = l16 + 16k, k < NV = ceil(V/16); max / sum by row-wide DPP all-reduce.
-template <int NV>
+// Probability rows for one chain: a block is ONE pass -- each group of 8 lanes takes one of the block's 8 time steps,
+// a lane holds the columns v = l8 + 8k, k < NV = ceil(V/8); max / sum by DPP all-reduce inside the group of 8.
+// (Four steps per pass with 16 lanes each was the first form: the reductions, the reciprocal and the address
+// arithmetic are paid per pass, and at V = 29 that was ~300 VALU instructions per block against ~110 here.  The
+// producers share their SIMDs with the chain waves, so their instruction count is the chains' speed too.)
+// HALO: the ring's readers are the waves of ctc_fast_chain_halo_kernel, whose progress words replace `took`.
+template <int NV, bool HALO = false>
 __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int dir, int first, int stride,
-                                          const F1Lds& lds, int lane) {
+                                          const F1Lds& lds, int lane, lds_u8* prog = nullptr, double rr2 = 0.0) {
   const int V = p.V;
   const int nblk = (T + kBlk - 1) / kBlk;
   double* myring = lds.ring + (size_t)dir * kRingBlks * lds.blk_elems;
@@ -377,79 +414,75 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
   volatile int* took = lds.took + dir;
   const float* x = p.x + (int64_t)b * p.sB;
   float* ytab = p.ytab + (size_t)b * p.T * V;
-  const int q = lane >> 4, l16 = lane & 15;
+  const int tt = lane >> 3, l8 = lane & 7;
   const float ninf = -__builtin_huge_valf();
-  constexpr int NP = kBlk / 4;      // passes per block
   bool col_live[NV];
   int64_t col_off[NV];
 #pragma unroll
-  for (int k = 0; k < NV; k++) { col_live[k] = l16 + 16 * k < V; col_off[k] = (int64_t)(l16 + 16 * k) * p.sV; }
+  for (int k = 0; k < NV; k++) { col_live[k] = l8 + 8 * k < V; col_off[k] = (int64_t)(l8 + 8 * k) * p.sV; }
   unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime();
   (void)prof_spin; (void)prof_t0;
   // the logits of block n+stride are requested before block n is worked on: an HBM miss (~1 us) would otherwise
-  // sit in front of every pass
-  auto load_block = [&](int n, float (&out)[NP][NV]) {
+  // sit in front of every block
+  auto load_block = [&](int n, float (&out)[NV]) {
+    const int t = block_time(dir, n, tt, T);
+    const bool row_live = n < nblk && t < T;
+    const float* xr = x + (int64_t)(row_live ? t : 0) * p.sT;
 #pragma unroll
-    for (int pass = 0; pass < NP; pass++) {
-      const int t = block_time(dir, n, pass * 4 + q, T);
-      const bool row_live = n < nblk && t < T;
-      const float* xr = x + (int64_t)(row_live ? t : 0) * p.sT;
-#pragma unroll
-      for (int k = 0; k < NV; k++) out[pass][k] = (row_live && col_live[k]) ? xr[col_off[k]] : ninf;
-    }
+    for (int k = 0; k < NV; k++) out[k] = (row_live && col_live[k]) ? xr[col_off[k]] : ninf;
   };
-  float xv[NP][NV];
+  float xv[NV];
   float lpmin = 0.f;                // smallest FINITE log-probability this wave has seen (alpha-side producers)
   load_block(first, xv);
   for (int n = first; n < nblk; n += stride) {       // this wave fills every `stride`-th block
-    float xn[NP][NV];
+    float xn[NV];
     load_block(n + stride, xn);
     const int slot = n % kRingBlks;
-    if (n >= kRingBlks) { PROF_SPIN_BEGIN spin_until_ge(took, n - kRingBlks + 1); PROF_SPIN_END(prof_spin) }
+    if (n >= kRingBlks) {
+      PROF_SPIN_BEGIN
+      if (HALO) { while (__builtin_amdgcn_readfirstlane(lds_min8(prog)) < n - kRingBlks + 1) __builtin_amdgcn_s_sleep(1); asm volatile("" ::: "memory"); }
+      else spin_until_ge(took, n - kRingBlks + 1);
+      PROF_SPIN_END(prof_spin)
+    }
     double* blk = myring + (size_t)slot * lds.blk_elems;
-#pragma unroll
-    for (int pass = 0; pass < NP; pass++) {
-      const int tt = pass * 4 + q;
-      const int t = block_time(dir, n, tt, T);
-      const bool row_live = t < T;
-      float y[NV];
-      if (p.logprobs) {
-#pragma unroll
-        for (int k = 0; k < NV; k++) {
-          y[k] = exp_le0(xv[pass][k]);
-          if (row_live && xv[pass][k] > ninf) lpmin = fminf(lpmin, xv[pass][k]);      // (-inf: an impossible symbol, exact)
-        }
-      } else {
-        float m = xv[pass][0];
-#pragma unroll
-        for (int k = 1; k < NV; k++) m = fmaxf(m, xv[pass][k]);
-        m = row16_max(m);
-        float ssum = 0.f;
-#pragma unroll
-        for (int k = 0; k < NV; k++) {
-          y[k] = exp_le0(xv[pass][k] - m); ssum += y[k];
-          if (row_live && xv[pass][k] > ninf) lpmin = fminf(lpmin, xv[pass][k] - m);  // (>= the log-probability)
-        }
-        ssum = row16_sum(ssum);
-        float inv = __builtin_amdgcn_rcpf(ssum);
-        inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);        // one Newton step: ~0.5 ulp
-#pragma unroll
-        for (int k = 0; k < NV; k++) y[k] *= inv;
-      }
-      float* yrow = ytab + (size_t)(row_live ? t : 0) * V;
+    const int t = block_time(dir, n, tt, T);
+    const bool row_live = t < T;
+    float y[NV];
+    if (p.logprobs) {
 #pragma unroll
       for (int k = 0; k < NV; k++) {
-        if (col_live[k]) {
-          blk[(l16 + 16 * k) * kRow + tt] = row_live ? (double)y[k] : 0.0;   // transposed: [label][step]
-          if (dir == 0 && row_live) yrow[l16 + 16 * k] = y[k];
-        }
+        y[k] = exp_le0(xv[k]);
+        lpmin = fminf(lpmin, xv[k] > ninf ? xv[k] : 0.f);      // (-inf: an impossible symbol, exact; so are dead rows)
+      }
+    } else {
+      float m = xv[0];
+#pragma unroll
+      for (int k = 1; k < NV; k++) m = fmaxf(m, xv[k]);
+      m = row8_max(m);
+      float ssum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        y[k] = exp_le0(xv[k] - m); ssum += y[k];
+        lpmin = fminf(lpmin, xv[k] > ninf ? xv[k] - m : 0.f);  // (>= the log-probability)
+      }
+      ssum = row8_sum(ssum);
+      float inv = __builtin_amdgcn_rcpf(ssum);
+      inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);        // one Newton step: ~0.5 ulp
+#pragma unroll
+      for (int k = 0; k < NV; k++) y[k] *= inv;
+    }
+    float* yrow = ytab + (size_t)(row_live ? t : 0) * V;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      if (col_live[k]) {
+        blk[(l8 + 8 * k) * kRow + tt] = row_live ? (double)y[k] : 0.0;   // transposed: [label][step]
+        if (HALO && l8 + 8 * k == p.blank) blk[(V + 1) * kRow + tt] = row_live ? rr2 * (double)y[k] : 0.0;
+        if (dir == 0 && row_live) yrow[l8 + 8 * k] = y[k];
       }
     }
     publish(&myfilled[slot], n + 1);     // every lane stores the same word: no divergence, one LDS write
 #pragma unroll
-    for (int pass = 0; pass < NP; pass++)
-#pragma unroll
-      for (int k = 0; k < NV; k++) xv[pass][k] = xn[pass][k];
+    for (int k = 0; k < NV; k++) xv[k] = xn[k];
   }
   // Probabilities are f32: below ~2^-126 they are flushed, and a chain that ran through such frames carries a loss that
   // is off by the flushed amount (a symbol with log-probability -inf is exactly impossible and does not count).  Reason bit 64 ("emissions near the end of f32"): such an utterance is recomputed
@@ -745,321 +778,232 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   else {
     const int d = (wave == 2 || wave == 6) ? 0 : 1;     // waves 2,6 -> alpha rows, waves 3,7 -> beta rows
     const int first = wave >= 6 ? 1 : 0;                 // the two producers of a direction take alternate blocks
-    if (V <= 16) prep_wave<1>(p, b, T, d, first, 2, lds, lane);
-    else if (V <= 32) prep_wave<2>(p, b, T, d, first, 2, lds, lane);
-    else if (V <= 48) prep_wave<3>(p, b, T, d, first, 2, lds, lane);
-    else if (V <= 64) prep_wave<4>(p, b, T, d, first, 2, lds, lane);
-    else prep_wave<6>(p, b, T, d, first, 2, lds, lane);
+    if (V <= 16) prep_wave<2>(p, b, T, d, first, 2, lds, lane);
+    else if (V <= 32) prep_wave<4>(p, b, T, d, first, 2, lds, lane);
+    else if (V <= 48) prep_wave<6>(p, b, T, d, first, 2, lds, lane);
+    else if (V <= 64) prep_wave<8>(p, b, T, d, first, 2, lds, lane);
+    else prep_wave<12>(p, b, T, d, first, 2, lds, lane);
   }
 }
 
 // ============================================================================================
-// F1, multi-wave form: each chain is SPLIT OVER UP TO FOUR WAVES that run as a pipeline
+// F1, halo form: each chain runs on up to FIVE waves that exchange cells once per 8-step block
 // ============================================================================================
 // A chain's speed is its instruction count per step (a lone wave issues one instruction per ~4.5 cycles), and one wave
-// carrying 8 cells per lane needs ~47 of them.  Here slice wave w of a direction holds the label pairs [64w, 64w+64)
-// -- ONE pair per lane: 5 multiply-adds, the neighbour move and its share of the bookkeeping per step -- and the
-// slices run as a systolic pipeline in the direction mass flows: alpha moves up, so slice w+1 only ever needs the
-// label cell of slice w's last lane, one value per step; beta moves down and needs the first lane's two cells of the
-// slice above.  A slice publishes those edge values a BLOCK (8 steps) at a time in an LDS ring and the consumer runs a
-// block or two behind; nothing else couples the waves:
-//   * the probability rows come from the same producer waves and ring as in the single-wave form (every slice polls
-//     the block it is about to read; the direction's LAST slice releases ring slots);
-//   * the power-of-two rescale stays COMMON to the whole row (one frame per direction, so that edge values need no
-//     conversion and the segment kernel sees the same cumA / cumB / zt2 as before).  The HEAD slice (no slice upstream:
-//     the one that runs first) decides the exponent removed at position 7 of block n and publishes it; the others,
-//     which run behind it, read it.  It takes the maximum of its own cells' exponent measured at position 6 of the same
-//     block -- at the start of an utterance all the mass is in the head, and the rescale is as immediate as in the
-//     single-wave form -- and of what the other slices measured in block n - kMwLag less what has been removed since
-//     (a dead-beat correction: plain delayed feedback oscillates).  f64 state has the range for the lag.
-// Waves of a workgroup land on the SIMDs in the order 0,2,1,3,...: waves 0-3 = alpha slices, 4-7 = beta slices, 8-11 =
-// probability rows (8,10 alpha side, 9,11 beta side), 12 = lattice description: every SIMD carries one slice of each
-// direction and one producer.
-constexpr int kMwLag = 8;        // blocks between a follower's measurement and its use (> the pipeline's skew, ~1.5 blocks per hop)
-constexpr int kMwRing = 32;      // ring depth (blocks) of the measurements and decided exponents (head <= ~kMwLag + 1 blocks ahead)
-struct MwLds {
-  double* bnd;       // [2][3][kRingBlks][2*kBlk]  dir, edge (between slices e and e+1), block slot, values
-                     //   alpha: [tt] = label cell of slice e's lane 63 BEFORE step tt of the block
-                     //   beta:  [2*tt], [2*tt+1] = blank, label cell of slice e+1's lane 0 before step tt
-  double* zfin;      // [4] alpha: label cell of each slice's lane 63 after the last step
-  int* bdone;        // [2][4]  blocks a slice has finished and published (nblk + 1: also its final values)
-  int* meas;         // [2][kMwRing][4]  exponent of the slice's largest cell, measured in block n (slot n % kMwRing)
-  int* edec;         // [2][kMwRing]     exponent the head removed at position 7 of block n
-  static constexpr int kEdgeBlk = 2 * kBlk;
-  __device__ MwLds(unsigned char* base) {
-    bnd = reinterpret_cast<double*>(base);
-    zfin = bnd + 2 * 3 * kRingBlks * kEdgeBlk;
-    bdone = reinterpret_cast<int*>(zfin + 4);
-    meas = bdone + 8;
-    edec = meas + 2 * kMwRing * 4;
+// that carries 8 cells per lane needs ~47 of them.  Here a wave carries ONE label pair per lane.  Cell j of row t depends
+// on cells j, j-1, j-2 of row t-1 only: mass moves by at most one label pair per step.  So a wave that OWNS 56 pairs and
+// also carries the 8 pairs next to them on the upstream side (the halo: lanes 0..7 for alpha, 56..63 for beta) can run
+// a whole block of 8 steps without hearing from its neighbour -- each step one more halo lane goes stale, and after the
+// eighth exactly the owned lanes are still right.  Then the halo is refilled from the neighbour's published edge pairs.
+// Nothing is exchanged per step; 8/64 of the arithmetic is redundant.
+//   * hand-over: wave w publishes its 8 edge pairs and `prog[w] = n+1` at the end of block n; its downstream neighbour
+//     waits for that before block n+1.  The same word releases the producers' ring slot.
+//   * the power-of-two rescale stays COMMON to the whole row (one frame per direction: edge pairs need no conversion, and
+//     the segment kernel sees the same cumA / cumB / zt2 as with the single-wave chains).  At the end of block n every
+//     lane leaves the high word of its larger cell in LDS (two instructions); a FRAME WAVE per direction reduces the words
+//     of block n once all chain waves have passed it and publishes the exponent to remove at the end of block n+2:
+//     the absolute exponent of the row's maximum at block n less what has been removed since (absolute: a delayed
+//     RELATIVE correction oscillates).  A chain wave reads one tagged word per block.  Two blocks of slack keep the
+//     waves from running in lock-step; f64 cells have the range for 16 steps of lag.
+//   * multiplying by powers of two is exact: checkpoints and the cum exponents differ from the single-wave form's only
+//     in where the frame sits.
+//   * beta hands ONE value down per step, like alpha hands one up: a lane prepares what the label cell of the pair below
+//     takes from its pair (blank * tilted blank probability + label * skip), instead of shipping both cells.
+// Waves of a workgroup land on the SIMDs in the order 0,2,1,3,...: waves 0-7 = alpha/beta waves 0..3 interleaved,
+// 8-11 = probability rows (8,10 alpha side, 9,11 beta side), 12,13 = alpha/beta wave 4, 14 = lattice description, then
+// beta's frame wave, 15 = alpha's frame wave.
+constexpr int kHaloLanes = kBlk;              // pairs a wave recomputes (one goes stale per step)
+constexpr int kHaloOwn = 64 - kHaloLanes;     // pairs a wave owns
+constexpr int kHaloMaxW = 5;                  // ceil(256 / 56)
+constexpr int kHaloSlots = 8;                 // ring depth (blocks) of the published exponents and edge pairs
+constexpr int kHaloLag = 2;                   // blocks between measuring the row's exponent and removing it
+constexpr int kHaloIdle = 0x3fffffff;         // prog[] of a wave that holds no cell of the utterance
+
+struct HaloLds {
+  // byte offsets from the start of the workgroup's LDS
+  int bnd;         // [2][kHaloMaxW][kHaloSlots][kHaloLanes] pairs of doubles: wave w's edge pairs after block n
+  int zacc;        // [8] doubles: each alpha wave's share of the partition sum (cells L-1 and L-2 may sit in two waves)
+  int prog;        // [2][8] ints: blocks a wave has finished and published
+  int exw;         // [2][kHaloSlots] ints: (n << 12 | exponent + 2048) the frame wave decided for the end of block n
+  int mxl;         // [2][kHaloSlots][kHaloMaxW][64] ints: high word of every lane's larger cell at the end of block n
+  __host__ __device__ explicit HaloLds(int base) {
+    bnd = base;
+    zacc = bnd + 2 * kHaloMaxW * kHaloSlots * kHaloLanes * 16;
+    prog = zacc + 64;
+    exw = prog + 2 * 8 * 4;
+    mxl = exw + 2 * kHaloSlots * 4;
   }
   __host__ __device__ static size_t bytes() {
-    return sizeof(double) * (2 * 3 * kRingBlks * kEdgeBlk + 4) + sizeof(int) * (8 + 2 * kMwRing * 4 + 2 * kMwRing);
+    return 2 * kHaloMaxW * kHaloSlots * kHaloLanes * 16 + 64 + 2 * 8 * 4 + 2 * kHaloSlots * 4 + 2 * kHaloSlots * kHaloMaxW * 64 * 4;
   }
 };
-constexpr int kNoMeas = -0x40000000;
 
-// F2PPL: label pairs per lane of the SEGMENT kernel, which fixes the checkpoint rows' width (128*F2PPL cells) and the
-// granularity of their block-floating-point exponents (one per segment-kernel lane = F2PPL lanes here).
-// ROLE: what is upstream / downstream of this slice is fixed at compile time -- a lone wave pays ~4.5 cycles for every
-// instruction it issues, scalar tests and branches included.
-enum { kSolo = 0, kHead = 1, kMid = 2, kTail = 3 };
-// Hand-off waits of the slices are bounded: a protocol error flags the utterance (bit 128 -> the exact kernel redoes it)
-// instead of hanging the GPU.  (~2^22 polls of >= 64 cycles: far beyond any legitimate wait.)
-#define MW_WAIT(cond)                                                                            \
+// Hand-off waits are bounded: a protocol error flags the utterance (bit 128 -> the exact kernel redoes it) instead of
+// hanging the GPU.  (~2^20 polls of >= 64 cycles: far beyond any legitimate wait.)
+#define HALO_WAIT(cond)                                                                          \
   do {                                                                                           \
-    int _spins = 0;                                                                              \
-    while (!(cond)) { __builtin_amdgcn_s_sleep(1); if (++_spins > (1 << 22)) { atomicOr(&p.flags[b], 128); break; } } \
+    if (!(cond)) {                                                                               \
+      int _spins = 0;                                                                            \
+      do { __builtin_amdgcn_s_sleep(1); if (++_spins > (1 << 20)) { atomicOr(&p.flags[b], 128); break; } } while (!(cond)); \
+    }                                                                                            \
     asm volatile("" ::: "memory");                                                               \
   } while (0)
-typedef __attribute__((address_space(3))) unsigned char lds_u8;
-typedef double mw_d2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) mw_d2 lds_d2;     // (every LDS access of the slices is a DS operation: a wave's DS
-typedef __attribute__((address_space(3))) double lds_f64;    //  operations execute in order, which the hand-off words rely on)
 
-template <int DIR, int F2PPL, int ROLE>
-__device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int T, int S, lds_u8* L0, int ring_bytes_dir,
-                                                 int blk_bytes, int mw_off, int lane, int w, int NW) {
-  constexpr bool HEAD = ROLE == kSolo || ROLE == kHead;     // no slice upstream: polls the producers, decides exponents
-  constexpr bool TAIL = ROLE == kSolo || ROLE == kTail;     // runs last: releases ring slots, writes the tracking exponents
-  constexpr bool W0 = DIR == 0 ? HEAD : TAIL;               // slice 0
-  constexpr int NE = DIR == 0 ? 1 : 2;                      // edge values per step
-  constexpr int PS = F2PPL == 1 ? 1 : F2PPL / 2;            // label pairs per lane of a slice (a slice = 64*PS pairs)
-  constexpr int NC = 2 * PS;
+// F2PPL: label pairs per lane of the SEGMENT kernel, which fixes the checkpoint rows' width (128*F2PPL cells) and the
+// granularity of their block-floating-point exponents (one per segment-kernel lane = F2PPL lanes here; 56 and 8 are
+// multiples of 4, so such a group never straddles two waves or a wave's halo).
+template <int DIR, int F2PPL>
+__device__ __forceinline__ void halo_chain_wave(const FastParams& p, int b, int T, int S, const F1Lds& lds, lds_u8* L0,
+                                                int ring_bytes_dir, int blk_bytes, const HaloLds hl, int lane, int w, int W) {
   const int V = p.V, blank = p.blank, L = 2 * S + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
-  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
-  short* cke = p.ckE + (size_t)b * p.NS * 2 * 64;
-  const int up = DIR == 0 ? w - 1 : w + 1;                 // upstream slice
-  const int tailw = DIR == 0 ? NW - 1 : 0;
-  // byte offsets into the workgroup's LDS
-  const int y_off = DIR * ring_bytes_dir;                                              // probability ring of this direction
-  const int sync_off = 2 * ring_bytes_dir;                                             // F1Lds::filled, took
-  volatile lds_int* filled = (volatile lds_int*)(L0 + sync_off) + DIR * kRingBlks;
-  volatile lds_int* took = (volatile lds_int*)(L0 + sync_off) + 2 * kRingBlks + DIR;
-  const int edge_bytes = kRingBlks * MwLds::kEdgeBlk * 8;
-  const int edge_in_off = mw_off + (DIR * 3 + (DIR == 0 ? w - 1 : w)) * edge_bytes;    // (unused by a head)
-  const int edge_out_off = mw_off + (DIR * 3 + (DIR == 0 ? w : w - 1)) * edge_bytes;   // (unused by a tail)
-  const int zfin_off = mw_off + 6 * edge_bytes;
-  volatile lds_int* bdone = (volatile lds_int*)(L0 + zfin_off + 32) + DIR * 4;
-  volatile lds_int* meas = (volatile lds_int*)(L0 + zfin_off + 32) + 8 + DIR * kMwRing * 4;
-  volatile lds_int* edec = (volatile lds_int*)(L0 + zfin_off + 32) + 8 + 2 * kMwRing * 4 + DIR * kMwRing;
+  const int ring_off = DIR * ring_bytes_dir;
+  volatile int* myfilled = lds.filled + DIR * kRingBlks;
+  lds_u8* prog = L0 + hl.prog + DIR * 32;
+  lds_u8* exw = L0 + hl.exw + DIR * (kHaloSlots * 4);
+  lds_u8* mxl = L0 + hl.mxl + ((DIR * kHaloSlots * kHaloMaxW + w) * 64 + lane) * 4;      // + slot * kHaloMaxW * 256
   __builtin_amdgcn_s_setprio(3);
+  unsigned long long prof_fill = 0, prof_nb = 0, prof_lag = 0, prof_t0 = __builtin_amdgcn_s_memtime();
+  (void)prof_fill; (void)prof_nb; (void)prof_lag; (void)prof_t0;
 
-  // this lane's pairs i = PS*(64w + lane) + r
-  const int i0 = PS * (64 * w + lane);
+  // this lane's label pair: blank cell 2*pair, label cell 2*pair + 1
+  const int pair = DIR == 0 ? kHaloOwn * w + lane - kHaloLanes : kHaloOwn * w + lane;
+  const bool owned = (DIR == 0 ? lane >= kHaloLanes : lane < kHaloOwn) && pair < 64 * F2PPL;
+  const bool halo = DIR == 0 ? lane < kHaloLanes : lane >= kHaloOwn;
+  const bool has_up = DIR == 0 ? w > 0 : w < W - 1;             // a wave whose edge pairs this one needs
+  const bool has_down = DIR == 0 ? w < W - 1 : w > 0;
+  const int up = DIR == 0 ? w - 1 : w + 1;
   const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
+  const bool in = pair >= 0 && pair < S;
+  const int li = in ? (int)tg[pair] : -1;
+  const int lpv = (pair >= 1 && pair - 1 < S) ? (int)tg[pair - 1] : -1;
+  const int lnx = (pair >= -1 && pair + 1 < S) ? (int)tg[pair + 1] : -1;
+  const int lab = (in && li >= 0 && li < V) ? li : V;           // V: the always-zero column
   const float r_tilt = fast_tilt(S, T);
   const double rr = (double)r_tilt, rr2 = rr * rr, inv_rr = 1.0 / rr;
-  int lab_off[PS]; double sk[PS]; bool bad_label = false;
-#pragma unroll
-  for (int r = 0; r < PS; r++) {
-    const int i = i0 + r;
-    const int li = i < S ? (int)tg[i] : -1;
-    const int lp = (i >= 1 && i - 1 < S) ? (int)tg[i - 1] : -1;
-    const int ln = (i + 1 < S) ? (int)tg[i + 1] : -1;
-    const int lab = (i < S && li >= 0 && li < V) ? li : V;
-    if (i < S && (li == blank || li < 0 || li >= V)) bad_label = true;
-    const bool skp = i < S && i >= 1 && li != blank && lp != li;          // ctc_loss.cpp:53-57
-    const bool skn = i + 1 < S && li != blank && ln != li;                // ctc_loss.cpp:91-96
-    sk[r] = (DIR == 0 ? skp : skn) ? rr2 : 0.0;
-    lab_off[r] = lab * (kRow * 8);
-  }
-  if (DIR == 0 && __any(bad_label)) { if (lane == 0) atomicOr(&p.flags[b], 2); }
+  // alpha: the skip (pair-1) -> pair as this pair sees it; beta: the same skip as the pair BELOW sees it -- a beta lane
+  // prepares what that pair takes from it, so that one value crosses the lanes per step instead of two
+  const float skf = DIR == 0 ? ((in && pair >= 1 && li != blank && lpv != li) ? r_tilt * r_tilt : 0.f)      // ctc_loss.cpp:53-57
+                             : ((in && pair >= 1 && lpv != blank && li != lpv) ? r_tilt * r_tilt : 0.f);     // ctc_loss.cpp:91-96
+  const double sk = (double)skf;
+  (void)lnx;
+  if (DIR == 0 && __any(owned && in && (li == blank || li < 0 || li >= V))) { if (lane == 0) atomicOr(&p.flags[b], 2); }
   const bool cond = (T > 1 || L == 1);            // ctc_loss.cpp:39,76
-  const int blank_off = blank * (kRow * 8);
 
-  double c[NC];                                    // c[2r] = B~ of blank cell 2i, c[2r+1] = L^ of label cell 2i+1 (see chain_wave)
-#pragma unroll
-  for (int k = 0; k < NC; k++) c[k] = 0.0;
-  double yb_prev = 0.0;
-  int e_total = 0, e_hist[kMwLag], my_meas = kNoMeas, gabs = 0;
-#pragma unroll
-  for (int k = 0; k < kMwLag; k++) e_hist[k] = 0;
-  int* cum = (DIR == 0 ? p.cumA : p.cumB) + (size_t)b * p.NB;
-  int* trk = (DIR == 0 ? p.trkA : p.trkB) + (size_t)b * p.NB;
-  if (lane == 0) {
-    if (W0) { if (DIR == 0) cum[0] = 0; else { cum[((T - 1) >> 3) + 1] = 0; cum[((T - 1) >> 3) + 2] = 0; } }
-    if (TAIL) { if (DIR == 0) trk[0] = 0; else { trk[((T - 1) >> 3) + 1] = 0; trk[((T - 1) >> 3) + 2] = 0; } }
-  }
+  double c0 = 0.0, c1 = 0.0;                       // the pair: c0 = B~ (blank cell before its emission), c1 = L^ (label cell, tilted)
+  double yb_prev = 0.0, wb_prev = 0.0;             // blank probability of the frame processed last, and r^2 times it
+  int e_total = 0;                                 // sum of removed exponents: the frame
+  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
 
-  mw_d2 eraw[PS][4], braw[4];                      // probabilities of this lane's labels / of the blank, 2 steps each
-  mw_d2 xraw[4 * NE];                              // upstream edge values: alpha 2 steps per d2, beta 1 step (blank, label)
-#pragma unroll
-  for (int q = 0; q < 4 * NE; q++) xraw[q] = mw_d2{0.0, 0.0};
+  h_d2 eraw[4], braw[4], wraw[4];                  // the block's probabilities of this lane's label and of the blank (plain, tilted)
+  const int lab_off = lab * (kRow * 8), blank_off = blank * (kRow * 8), wb_off = (V + 1) * (kRow * 8);
   auto load_half = [&](int n, auto half_tag) {
     constexpr int H = decltype(half_tag)::value;
-    const int yo = y_off + (n & (kRingBlks - 1)) * blk_bytes + 32 * H;
-#pragma unroll
-    for (int r = 0; r < PS; r++) {
-      eraw[r][2 * H] = *(lds_d2*)(L0 + yo + lab_off[r]); eraw[r][2 * H + 1] = *(lds_d2*)(L0 + yo + lab_off[r] + 16);
-    }
+    const int yo = ring_off + (n % kRingBlks) * blk_bytes + 32 * H;
+    eraw[2 * H] = *(lds_d2*)(L0 + yo + lab_off); eraw[2 * H + 1] = *(lds_d2*)(L0 + yo + lab_off + 16);
     braw[2 * H] = *(lds_d2*)(L0 + yo + blank_off); braw[2 * H + 1] = *(lds_d2*)(L0 + yo + blank_off + 16);
-    if (!HEAD) {
-      const int xo = edge_in_off + (n & (kRingBlks - 1)) * (MwLds::kEdgeBlk * 8) + 32 * NE * H;
-#pragma unroll
-      for (int q = 0; q < 2 * NE; q++) xraw[2 * NE * H + q] = *(lds_d2*)(L0 + xo + 16 * q);
-    }
+    wraw[2 * H] = *(lds_d2*)(L0 + yo + wb_off); wraw[2 * H + 1] = *(lds_d2*)(L0 + yo + wb_off + 16);
   };
 
   auto run_block = [&](int n, auto steady_tag) {
     constexpr bool STEADY = decltype(steady_tag)::value;
     load_half(n, std::integral_constant<int, 1>{});
-    if (TAIL) *took = n + 1;                             // (in order behind this wave's reads above)
     const bool want_next = n + 1 < nblk;
-    // what the first half of block n+1 waits for: the producers' block (head) or the upstream slice (which has read it)
-    int next_ready = 0, lag_done = 0;
-    if (want_next) next_ready = HEAD ? filled[(n + 1) & (kRingBlks - 1)] : bdone[up];
-    if (ROLE == kHead && n >= kMwLag) lag_done = bdone[tailw];
-    double h0[kBlk], h1[kBlk];                            // what this slice's edge lane publishes
+    int next_filled = 0;
+    if (want_next) next_filled = peek(&myfilled[(n + 1) % kRingBlks]);
+    // the halo pairs, as the upstream wave left them after block n-1 (same frame: the rescale is common)
+    if (n > 0 && has_up) {
+      { PROF_SPIN_BEGIN HALO_WAIT(__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(prog + 4 * up)) >= n); PROF_SPIN_END(prof_nb) }
+      const h_d2 v = *(lds_d2*)(L0 + hl.bnd + (((DIR * kHaloMaxW + up) * kHaloSlots + ((n - 1) & (kHaloSlots - 1))) * kHaloLanes + (lane & (kHaloLanes - 1))) * 16);
+      if (halo) { c0 = v.x; c1 = v.y; }
+    }
     const int tbase = block_time(DIR, n, 0, T);
+    int xw = 0;
 #pragma unroll
     for (int tt = 0; tt < kBlk; tt++) {
       const int t = DIR == 0 ? tbase + tt : tbase - tt;
-      const double yb = braw[tt >> 1][tt & 1];
-      double e[PS];
-#pragma unroll
-      for (int r = 0; r < PS; r++) e[r] = eraw[r][tt >> 1][tt & 1];
-      double x0, x1 = 0.0;                                // upstream edge values for this step
-      if (DIR == 0) x0 = xraw[tt >> 1][tt & 1]; else { x0 = xraw[tt][0]; x1 = xraw[tt][1]; }
+      const double yb = braw[tt >> 1][tt & 1], e = eraw[tt >> 1][tt & 1], wb = wraw[tt >> 1][tt & 1];
       if (tt == 4) {
-        if (want_next) {
-          if (HEAD) { if (__builtin_amdgcn_readfirstlane(next_ready) != n + 2) MW_WAIT(filled[(n + 1) & (kRingBlks - 1)] == n + 2); }
-          else { if (__builtin_amdgcn_readfirstlane(next_ready) < n + 2) MW_WAIT(bdone[up] >= n + 2); }
-        }
+        xw = *(volatile lds_int*)(exw + 4 * (n & (kHaloSlots - 1)));      // normally there since two blocks ago; looked at after step 7
+        if (want_next && __builtin_amdgcn_readfirstlane(next_filled) != n + 2) { PROF_SPIN_BEGIN spin_until(&myfilled[(n + 1) % kRingBlks], n + 2); PROF_SPIN_END(prof_fill) }
         load_half(n + 1, std::integral_constant<int, 0>{});
       }
-      if (DIR == 0) h1[tt] = c[NC - 1]; else { h0[tt] = c[0]; h1[tt] = c[1]; }
-      const bool live = STEADY || t < T;
-      if (live) {
+      if (STEADY || t < T) {
         const bool first = !STEADY && (DIR == 0 ? t == 0 : t == T - 1);
         if (DIR == 0) {
+          // alpha_t[j] = (alpha[j] + r*alpha[j-1] + r^2*skip*alpha[j-2]) * y_t[l_j], ctc_loss.cpp:47-60
           if (first) {
-            if (i0 == 0) { c[0] = cond ? 1.0 : 0.0; c[1] = rr2 * e[0]; }          // ctc_loss.cpp:39-42
+            if (pair == 0) { c0 = cond ? 1.0 : 0.0; c1 = rr2 * e; }               // ctc_loss.cpp:39-42
           } else {
-            // label cell of the pair below this lane's first: lane n-1's last, lane 0 takes the upstream slice's edge value
-            const int lo = __builtin_amdgcn_update_dpp(__double2loint(x0), __double2loint(c[NC - 1]), 0x138, 0xf, 0xf, false);
-            const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x0), __double2hiint(c[NC - 1]), 0x138, 0xf, 0xf, false);
-            double pl = __hiloint2double(hi, lo);
-            const double wgt = rr2 * yb_prev;
-#pragma unroll
-            for (int r = 0; r < PS; r++) {
-              const double ob = c[2 * r], ol = c[2 * r + 1];
-              c[2 * r] = ob * yb_prev + pl;
-              c[2 * r + 1] = (ol + wgt * ob + sk[r] * pl) * e[r];
-              pl = ol;
-            }
+            const double pl = from_prev_lane(c1);          // label cell just below this lane's blank
+            const double ob = c0;
+            c0 = ob * yb_prev + pl;
+            c1 = (c1 + wb_prev * ob + sk * pl) * e;
           }
         } else {
+          // q_t[j] = (q[j] + r*q[j+1] + r^2*skipn*q[j+2]) * y_t[l_j]; q = beta * emission, ctc_loss.cpp:84-99
           if (first) {
-#pragma unroll
-            for (int r = 0; r < PS; r++) {
-              if (2 * (i0 + r) == L - 1 && cond) c[2 * r] = 1.0;                  // ctc_loss.cpp:76
-              if (2 * (i0 + r) + 1 == L - 2) c[2 * r + 1] = rr2 * e[r];           // ctc_loss.cpp:78
-            }
+            if (pair == S && cond) c0 = 1.0;                                       // ctc_loss.cpp:76
+            if (pair == S - 1) c1 = rr2 * e;                                       // ctc_loss.cpp:78
           } else {
-            const int blo = __builtin_amdgcn_update_dpp(__double2loint(x0), __double2loint(c[0]), 0x130, 0xf, 0xf, false);
-            const int bhi = __builtin_amdgcn_update_dpp(__double2hiint(x0), __double2hiint(c[0]), 0x130, 0xf, 0xf, false);
-            const int llo = __builtin_amdgcn_update_dpp(__double2loint(x1), __double2loint(c[1]), 0x130, 0xf, 0xf, false);
-            const int lhi = __builtin_amdgcn_update_dpp(__double2hiint(x1), __double2hiint(c[1]), 0x130, 0xf, 0xf, false);
-            double nb = __hiloint2double(bhi, blo), nl = __hiloint2double(lhi, llo);
-            const double wgt = rr2 * yb_prev;
-#pragma unroll
-            for (int r = PS - 1; r >= 0; r--) {
-              const double ob = c[2 * r], ol = c[2 * r + 1];
-              c[2 * r + 1] = (ol + wgt * nb + sk[r] * nl) * e[r];
-              c[2 * r] = ob * yb_prev + ol;
-              nb = ob; nl = ol;
-            }
+            const double give = wb_prev * c0 + sk * c1;        // what the label cell of the pair below takes from this pair
+            const double take = from_next_lane(give);
+            const double ol = c1;
+            c1 = (ol + take) * e;
+            c0 = c0 * yb_prev + ol;
           }
         }
-        yb_prev = yb;
-      }
-      if (tt == 6) {
-        // (dead steps too: the words below are read by the other slices whatever this block held)
-        int hi = 0;
-#pragma unroll
-        for (int k = 0; k < NC; k++) hi = max(hi, __double2hiint(c[k]));              // positive doubles order like ints
-        hi = wave_max(hi);
-        my_meas = hi > 0 ? ((hi >> 20) & 0x7ff) - 1023 : kNoMeas;
-        if (ROLE != kSolo) meas[(n & (kMwRing - 1)) * 4 + w] = my_meas;
-      } else if (tt == 7) {
-        // the common exponent of this block (decided by the head, see the header comment)
-        int e_now = 0;
-        if (HEAD) {
-          int m = my_meas;
-          if (ROLE == kHead && n >= kMwLag) {
-            if (__builtin_amdgcn_readfirstlane(lag_done) < n - kMwLag + 1) MW_WAIT(bdone[tailw] >= n - kMwLag + 1);
-            int since = 0;
-#pragma unroll
-            for (int k = 0; k < kMwLag; k++) since += e_hist[k];
-            for (int q = 0; q < NW; q++) {
-              if (q == w) continue;
-              const int mq = __builtin_amdgcn_readfirstlane(meas[((n - kMwLag) & (kMwRing - 1)) * 4 + q]);
-              if (mq > kNoMeas) m = max(m, mq - since);
-            }
+        yb_prev = yb; wb_prev = wb;
+        if (tt == 7) {
+          // the frame: every lane leaves the high word of its larger cell for the frame wave, and removes what that wave
+          // decided for the end of this block from the words of two blocks ago
+          *(volatile lds_int*)(mxl + (n & (kHaloSlots - 1)) * (kHaloMaxW * 256)) = max(__double2hiint(c0), __double2hiint(c1));
+          xw = __builtin_amdgcn_readfirstlane(xw);
+          if ((xw >> 12) != n) {
+            PROF_SPIN_BEGIN
+            int spins = 0;
+            do {
+              __builtin_amdgcn_s_sleep(1);
+              xw = __builtin_amdgcn_readfirstlane(*(volatile lds_int*)(exw + 4 * (n & (kHaloSlots - 1))));
+              if (++spins > (1 << 20)) { atomicOr(&p.flags[b], 128); xw = (n << 12) | 2048; }
+            } while ((xw >> 12) != n);
+            PROF_SPIN_END(prof_lag)
           }
-          if (m > kNoMeas) e_now = min(max(m, -1000), 1000);
-          if (ROLE == kHead) {
-            edec[n & (kMwRing - 1)] = e_now;
-#pragma unroll
-            for (int k = 0; k + 1 < kMwLag; k++) e_hist[k] = e_hist[k + 1];
-            e_hist[kMwLag - 1] = e_now;
-          }
-        } else {
-          e_now = __builtin_amdgcn_readfirstlane(edec[n & (kMwRing - 1)]);     // (the head is blocks ahead)
-        }
-        if (TAIL) {
-          // tracking exponent for the segment kernel: the row's true maximum at position 6 of this block (every slice
-          // upstream has published its own), as an absolute exponent -- what the single-wave form's frame IS
-          int g = my_meas;
-          if (ROLE == kTail)
-            for (int q = 0; q < NW; q++) { if (q != w) g = max(g, __builtin_amdgcn_readfirstlane(meas[(n & (kMwRing - 1)) * 4 + q])); }
-          if (g > kNoMeas) gabs = g + e_total;
-        }
-#pragma unroll
-        for (int k = 0; k < NC; k++) c[k] = ldexp(c[k], -e_now);
-        e_total += e_now;
-        if (live) {
-          if (W0) cum[(t >> 3) + (DIR == 0 ? 1 : 0)] = e_total;          // (every lane the same word: no divergence)
-          if (TAIL) trk[(t >> 3) + (DIR == 0 ? 1 : 0)] = gabs;
+          const int ex = (xw & 0xfff) - 2048;
+          c0 = ldexp(c0, -ex); c1 = ldexp(c1, -ex);
+          e_total += ex;
           const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
           if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
-            double cell[NC];                                // blank with its emission, label without the tilt
-#pragma unroll
-            for (int r = 0; r < PS; r++) { cell[2 * r] = c[2 * r] * yb_prev; cell[2 * r + 1] = c[2 * r + 1] * inv_rr; }
-            int m = 0;
-#pragma unroll
-            for (int k = 0; k < NC; k++) m = max(m, __double2hiint(cell[k]));
-            if (F2PPL >= 2) m = max(m, dpp_i<0xB1>(0, m));                // the segment kernel's lane = 2 lanes here
+            // block floating point: each group of F2PPL pairs stores its cells scaled by its own exponent
+            const double cell0 = c0 * yb_prev, cell1 = c1 * inv_rr;     // the true cells: blank with its emission, label without the tilt
+            int m = max(__double2hiint(cell0), __double2hiint(cell1));
+            if (F2PPL >= 2) m = max(m, dpp_i<0xB1>(0, m));              // quad_perm [1,0,3,2]
+            if (F2PPL >= 4) m = max(m, dpp_i<0x4E>(0, m));              // quad_perm [2,3,0,1]
             const int own = m > 0 ? ((m >> 20) & 0x7ff) - 1023 : -30000;
-            float* dst = ck + (size_t)(kk / kSeg) * p.CELLS + 128 * PS * w + NC * lane;
-#pragma unroll
-            for (int k = 0; k < NC; k++) dst[k] = m > 0 ? (float)ldexp(cell[k], -own) : 0.f;
-            if (F2PPL == 1) cke[((size_t)(kk / kSeg) * 2 + DIR) * 64 + lane] = (short)own;
-            else if ((lane & 1) == 0) cke[((size_t)(kk / kSeg) * 2 + DIR) * 64 + 32 * w + (lane >> 1)] = (short)own;
+            if (owned) {
+              float2 o;
+              o.x = m > 0 ? (float)ldexp(cell0, -own) : 0.f;
+              o.y = m > 0 ? (float)ldexp(cell1, -own) : 0.f;
+              *reinterpret_cast<float2*>(ck + (size_t)(kk / kSeg) * p.CELLS + 2 * pair) = o;
+              if ((pair & (F2PPL - 1)) == 0)
+                p.ckE[(((size_t)b * p.NS + kk / kSeg) * 2 + DIR) * 64 + pair / F2PPL] = (short)own;
+            }
           }
         }
       }
     }
-    // publish this block's edge values (the cells BEFORE each step) and the block itself
-    if (!TAIL) {
-      if (lane == (DIR == 0 ? 63 : 0)) {
-        lds_f64* dst = (lds_f64*)(L0 + edge_out_off + (n & (kRingBlks - 1)) * (MwLds::kEdgeBlk * 8));
-        if (DIR == 0) {
-#pragma unroll
-          for (int q = 0; q < 8; q++) dst[q] = h1[q];
-        } else {
-#pragma unroll
-          for (int q = 0; q < 8; q++) { dst[2 * q] = h0[q]; dst[2 * q + 1] = h1[q]; }
-        }
+    // edge pairs for the downstream wave, then the word that says so (and that this block's probabilities were read)
+    if (has_down) {
+      const bool edge = DIR == 0 ? lane >= 64 - kHaloLanes : lane < kHaloLanes;
+      if (edge) {
+        h_d2 v; v.x = c0; v.y = c1;
+        *(lds_d2*)(L0 + hl.bnd + (((DIR * kHaloMaxW + w) * kHaloSlots + (n & (kHaloSlots - 1))) * kHaloLanes + (lane & (kHaloLanes - 1))) * 16) = v;
       }
     }
-    asm volatile("" ::: "memory");
-    if (ROLE != kSolo) bdone[w] = n + 1;                  // (the tail's count is what the head's lagged exponents wait for)
+    *(volatile lds_int*)(prog + 4 * w) = n + 1;
   };
   {
-    if (HEAD) MW_WAIT(filled[0] == 1); else MW_WAIT(bdone[up] >= 1);
+    spin_until(&myfilled[0], 1);
     load_half(0, std::integral_constant<int, 0>{});
     const int steady_end = DIR == 0 ? T / kBlk : nblk;         // blocks [1, steady_end) are steady
     run_block(0, std::false_type{});
@@ -1068,72 +1012,98 @@ __device__ __forceinline__ void chain_slice_wave(const FastParams& p, int b, int
     for (; n < nblk; n++) run_block(n, std::false_type{});
   }
 
+#ifdef E2E_FAST_PROFILE
+  if (lane == 0 && b < 256) { unsigned long long* g = g_prof3 + ((size_t)b * 16 + DIR * 8 + w) * 4;
+    g[0] = __builtin_amdgcn_s_memtime() - prof_t0; g[1] = prof_fill; g[2] = prof_nb; g[3] = prof_lag; }
+#endif
   // ---- log Z from this side ----
   if (DIR == 0) {
-    // cells L-1 (blank of pair S) and L-2 (label of pair S-1): the last slice holds the first, the second may be the
-    // last cell of the slice below
-    if (!TAIL) {
-      if (lane == 63) *(lds_f64*)(L0 + zfin_off + 8 * w) = c[NC - 1];
-      asm volatile("" ::: "memory");
-      bdone[w] = nblk + 1;
-      return;
-    }
+    // cells L-1 (the blank of pair S) and L-2 (the label of pair S-1) may sit in two waves
     double z = 0.0;
-#pragma unroll
-    for (int r = 0; r < PS; r++) {
-      if (i0 + r == S) z += c[2 * r] * yb_prev;            // ctc_loss.cpp:63-70, un-tilted relative to cell L-1
-      if (i0 + r == S - 1) z += c[2 * r + 1];              // (= r * the label cell)
-    }
-    if (ROLE == kTail && S == 64 * PS * w) {               // pair S-1 is the last pair of slice w-1
-      MW_WAIT(bdone[w - 1] >= nblk + 1);
-      if (lane == 0) z += *(lds_f64*)(L0 + zfin_off + 8 * (w - 1));
-    }
+    if (owned && pair == S) z += c0 * yb_prev;            // ctc_loss.cpp:63-70, un-tilted relative to cell L-1
+    if (owned && pair == S - 1) z += c1;                  // (= r * the label cell)
     for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
-    if (lane == 0) {
-      const double lz = log(z) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log(rr);
-      p.logz[2 * b] = lz;
-      p.zt2[b] = log2(z) + (double)e_total;
-      p.losses[b] = (float)(-lz);
-      if (!(z > 0.0) || !(z < __builtin_huge_val())) atomicOr(&p.flags[b], 4);     // infeasible or out of range
+    *(volatile lds_f64*)(L0 + hl.zacc + 8 * w) = z;
+    *(volatile lds_int*)(prog + 4 * w) = nblk + 1;
+    if (w == 0) {
+      HALO_WAIT(__builtin_amdgcn_readfirstlane(lds_min8(prog)) >= nblk + 1);
+      if (lane == 0) {
+        double zs = 0.0;
+        for (int k = 0; k < W; k++) zs += *(volatile lds_f64*)(L0 + hl.zacc + 8 * k);
+        const double lz = log(zs) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log(rr);
+        p.logz[2 * b] = lz;
+        p.zt2[b] = log2(zs) + (double)e_total;
+        p.losses[b] = (float)(-lz);
+        if (!(zs > 0.0) || !(zs < __builtin_huge_val())) atomicOr(&p.flags[b], 4);     // infeasible or out of range
+      }
     }
-  } else if (W0 && lane == 0) {
-    const double z = (cond ? c[0] * yb_prev : 0.0) + c[1];     // sum_j alpha_0[j]*beta_0[j]
+  } else if (w == 0 && lane == 0) {
+    const double z = (cond ? c0 * yb_prev : 0.0) + c1;     // sum_j alpha_0[j]*beta_0[j]
     p.logz[2 * b + 1] = log(z) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log(rr);
   }
 }
 
-// a slice that holds no cell of this utterance: the segment kernel still reads the full row width -- leave zeros
-template <int DIR, int F2PPL>
-__device__ __forceinline__ void empty_slice_wave(const FastParams& p, int b, int lane, int w) {
-  constexpr int PS = F2PPL == 1 ? 1 : F2PPL / 2;
-  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
-  short* cke = p.ckE + (size_t)b * p.NS * 2 * 64;
-  for (int k = 1; k < p.NS; k++) {
-    float* dst = ck + (size_t)k * p.CELLS + 128 * PS * w + 2 * PS * lane;
-#pragma unroll
-    for (int q = 0; q < 2 * PS; q++) dst[q] = 0.f;
-    if (lane < 32) cke[((size_t)k * 2 + DIR) * 64 + 32 * w + lane] = (short)-30000;
+// The frame wave of a direction decides the exponent every chain wave removes at the end of block n: the absolute
+// exponent of the row's largest cell at the end of block n - kHaloLag, less what has been removed up to block n-1, so
+// that the frame after block n is that absolute exponent.  It also writes the cum exponents for the segment kernel.
+// (The chain waves only leave one word per lane and read one word per block; the reductions happen here, two blocks
+// ahead of where they are needed.)
+template <int DIR>
+__device__ __forceinline__ void halo_frame_wave(const FastParams& p, int b, int T, lds_u8* L0, const HaloLds hl, int lane, int W) {
+  static_assert(kHaloLag == 2, "the two exponents in flight are kept in two variables");
+  const int nblk = (T + kBlk - 1) / kBlk;
+  const int nres = DIR == 0 ? T / kBlk : nblk;       // blocks whose step 7 is live (alpha's last block may be short)
+  const int M = (T - 1) >> 3;
+  int* cum = (DIR == 0 ? p.cumA : p.cumB) + (size_t)b * p.NB;
+  lds_u8* prog = L0 + hl.prog + DIR * 32;
+  lds_u8* exw = L0 + hl.exw + DIR * (kHaloSlots * 4);
+  lds_u8* mxl = L0 + hl.mxl + (DIR * kHaloSlots * kHaloMaxW * 64 + lane) * 4;
+  if (lane == 0) {
+    if (DIR == 0) cum[0] = 0;
+    else { cum[M + 1] = 0; cum[M + 2] = 0; }
+    for (int n = 0; n < kHaloLag && n < nres; n++) cum[DIR == 0 ? n + 1 : M - n] = 0;      // (their words were set with the flags)
+  }
+  int through = 0;                    // sum of ex[k], k <= n + 1: the frame after block n + 1
+  int ex1 = 0, ex2 = 0;               // ex[n + 1], ex[n]
+  for (int n = 0; n + kHaloLag < nres; n++) {
+    HALO_WAIT(__builtin_amdgcn_readfirstlane(lds_min8(prog)) >= n + 1);
+    int m = 0;
+    for (int w = 0; w < W; w++) m = max(m, *(volatile lds_int*)(mxl + ((n & (kHaloSlots - 1)) * kHaloMaxW + w) * 256));
+    m = wave_max(m);                  // positive doubles order like ints
+    int ex = 0;
+    if (m > 0) {
+      const int absolute = ((m >> 20) & 0x7ff) - 1023 + (through - ex1 - ex2);     // block n was measured before ex[n] was removed
+      ex = max(min(absolute - through, 1000), -1000);
+    }
+    through += ex; ex2 = ex1; ex1 = ex;
+    const int nn = n + kHaloLag;
+    *(volatile lds_int*)(exw + 4 * (nn & (kHaloSlots - 1))) = (nn << 12) | (ex + 2048);
+    if (lane == 0) cum[DIR == 0 ? nn + 1 : M - nn] = through;
   }
 }
 
+// a wave that holds no cell of this utterance: the segment kernel still reads the full row width -- leave zeros
 template <int DIR, int F2PPL>
-__device__ __forceinline__ void slice_dispatch(const FastParams& p, int b, int T, int S, lds_u8* L0, int ring_bytes_dir,
-                                               int blk_bytes, int mw_off, int lane, int w, int NW) {
-  if (w >= NW) { empty_slice_wave<DIR, F2PPL>(p, b, lane, w); return; }
-  const bool head = DIR == 0 ? w == 0 : w == NW - 1, tail = DIR == 0 ? w == NW - 1 : w == 0;
-  if (head && tail) chain_slice_wave<DIR, F2PPL, kSolo>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
-  else if (F2PPL == 1) return;                                       // (one slice at most: only the solo form exists)
-  else if (head) chain_slice_wave<DIR, F2PPL, kHead>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
-  else chain_slice_wave<DIR, F2PPL, kTail>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, w, NW);
+__device__ __forceinline__ void halo_idle_wave(const FastParams& p, int b, int lane, int w) {
+  if (lane >= kHaloOwn) return;
+  const int pair = kHaloOwn * w + lane;
+  if (pair >= 64 * F2PPL) return;
+  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
+  short* cke = p.ckE + (size_t)b * p.NS * 2 * 64;
+  for (int k = 1; k < p.NS; k++) {
+    float2 z; z.x = 0.f; z.y = 0.f;
+    *reinterpret_cast<float2*>(ck + (size_t)k * p.CELLS + 2 * pair) = z;
+    if ((pair & (F2PPL - 1)) == 0) cke[((size_t)k * 2 + DIR) * 64 + pair / F2PPL] = (short)-30000;
+  }
 }
 
 template <int PPL>
-__global__ __launch_bounds__(576) void ctc_fast_chain_mw_kernel(FastParams p) {
+__global__ __launch_bounds__(1024) void ctc_fast_chain_halo_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V;
   const F1Lds lds(smem, V);
-  const MwLds mw(smem + align_up_dev(F1Lds::bytes(V), 16));
+  const HaloLds hl((int)align_up_dev(F1Lds::bytes(V), 32));
 
   if (b == 0 && tid < 4) p.ctl[tid] = 0;
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
@@ -1143,32 +1113,40 @@ __global__ __launch_bounds__(576) void ctc_fast_chain_mw_kernel(FastParams p) {
     return;
   }
   const int T = (int)Tq, S = (int)Sq;
+  constexpr int MAXW = (64 * PPL + kHaloOwn - 1) / kHaloOwn;     // waves that can hold a cell at this row width
+  const int W = min(S / kHaloOwn + 1, MAXW);                      // waves that hold a cell: pairs 0..S (pair S = the last blank)
   if (tid == 0) p.flags[b] = 0;
   if (tid < F1Lds::kSyncInts) lds.filled[tid] = 0;
-  if (tid < 8) mw.bdone[tid] = 0;
+  if (tid < 16) reinterpret_cast<int*>(smem + hl.prog)[tid] = (tid & 7) < W ? 0 : kHaloIdle;
+  if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHaloLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;
+  if (tid < 8) reinterpret_cast<double*>(smem + hl.zacc)[tid] = 0.0;
   for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
     lds.ring[(size_t)(i / kBlk) * lds.blk_elems + V * kRow + (i % kBlk)] = 0.0;
   __syncthreads();
 
-  // waves 0,1 = alpha slices 0,1 (SIMDs 0,2); waves 2,3 = beta slices 0,1 (SIMDs 1,3); waves 4-7 = probability rows, one per
-  // SIMD (4,6 alpha side, 5,7 beta side); wave 8 = lattice description.  A slice = 64*PS label pairs, PS = PPL/2.
-  constexpr int PS = PPL == 1 ? 1 : PPL / 2, MAXW = PPL == 1 ? 1 : 2;
   const int wave = __builtin_amdgcn_readfirstlane(wid);
-  const int NW = min(S / (64 * PS) + 1, MAXW);          // slices that hold a cell: pairs 0..S (pair S = the last blank)
   lds_u8* L0 = (lds_u8*)smem;
   const int blk_bytes = lds.blk_elems * 8, ring_bytes_dir = kRingBlks * blk_bytes;
-  const int mw_off = (int)align_up_dev(F1Lds::bytes(V), 16);
-  if (wave < 2) { if (wave < MAXW) slice_dispatch<0, PPL>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, wave, NW); }
-  else if (wave < 4) { if (wave - 2 < MAXW) slice_dispatch<1, PPL>(p, b, T, S, L0, ring_bytes_dir, blk_bytes, mw_off, lane, wave - 2, NW); }
-  else if (wave == 8) cellinfo_wave<PPL>(p, b, T, S, lds.sortcnt, lane);
+  if (wave < 8 || wave == 12 || wave == 13) {
+    const int d = wave & 1, w = wave < 8 ? wave >> 1 : 4;
+    if (w >= MAXW) return;
+    if (w >= W) { if (d == 0) halo_idle_wave<0, PPL>(p, b, lane, w); else halo_idle_wave<1, PPL>(p, b, lane, w); }
+    else if (d == 0) halo_chain_wave<0, PPL>(p, b, T, S, lds, L0, ring_bytes_dir, blk_bytes, hl, lane, w, W);
+    else halo_chain_wave<1, PPL>(p, b, T, S, lds, L0, ring_bytes_dir, blk_bytes, hl, lane, w, W);
+  } else if (wave == 14) {
+    cellinfo_wave<PPL>(p, b, T, S, lds.sortcnt, lane);
+    halo_frame_wave<1>(p, b, T, L0, hl, lane, W);
+  } else if (wave == 15) halo_frame_wave<0>(p, b, T, L0, hl, lane, W);
   else {
-    const int d = (wave - 4) & 1;                        // waves 4,6 -> alpha rows, 5,7 -> beta rows
-    const int first = (wave - 4) >> 1;                   // the two producers of a direction take alternate blocks
-    if (V <= 16) prep_wave<1>(p, b, T, d, first, 2, lds, lane);
-    else if (V <= 32) prep_wave<2>(p, b, T, d, first, 2, lds, lane);
-    else if (V <= 48) prep_wave<3>(p, b, T, d, first, 2, lds, lane);
-    else if (V <= 64) prep_wave<4>(p, b, T, d, first, 2, lds, lane);
-    else prep_wave<6>(p, b, T, d, first, 2, lds, lane);
+    const int d = (wave - 8) & 1;                        // waves 8,10 -> alpha rows, 9,11 -> beta rows
+    const int first = (wave - 8) >> 1;                   // the two producers of a direction take alternate blocks
+    lds_u8* prog = L0 + hl.prog + d * 32;
+    const double rr = (double)fast_tilt(S, T), rr2 = rr * rr;         // (the chain waves' own expression)
+    if (V <= 16) prep_wave<2, true>(p, b, T, d, first, 2, lds, lane, prog, rr2);
+    else if (V <= 32) prep_wave<4, true>(p, b, T, d, first, 2, lds, lane, prog, rr2);
+    else if (V <= 48) prep_wave<6, true>(p, b, T, d, first, 2, lds, lane, prog, rr2);
+    else if (V <= 64) prep_wave<8, true>(p, b, T, d, first, 2, lds, lane, prog, rr2);
+    else prep_wave<12, true>(p, b, T, d, first, 2, lds, lane, prog, rr2);
   }
 }
 
@@ -1675,17 +1653,20 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute");
   const size_t lds2 = F2Lds<PPL>::bytes(p.V);
-  // The multi-wave chains (ctc_fast_chain_mw_kernel) are parity-green but SLOWER on MI355X (B=256, T=1000, S<=200; the
-  // single-wave chain kernel takes 95 us = 215 cycles per step):
-  //   4 slices per direction (1 pair per lane, two slices + a producer per SIMD)   chain kernel 152 us
-  //   2 slices per direction (2 pairs per lane, one slice + a producer per SIMD)   chain kernel 120 us   <- this code
-  // Per 8-step block a slice wave executes ~300-340 instructions (170-200 VALU, of which 88 are the f64 steps) against 340
-  // (220 VALU) for a WHOLE single-wave chain: halving the cells per lane removes 80 f64 operations and adds the hand-off,
-  // edge, exponent-exchange and per-slice checkpoint code, most of it moves / selects / address arithmetic that the
-  // compiler emits per block.  A lone wave pays ~4.5 cycles for every instruction of any kind, and a slice that shares
-  // its SIMD with a producer wave (~200 VALU per block) is VALU-bound instead.  What would pay is fewer instructions in
-  // total: softmax rows computed once instead of once per direction, and an f32 lattice that carries alpha and beta in
-  // the two halves of packed instructions -- see DESIGN.md section 4.1.  Kept selectable for A/B (E2E_F1_MULTI=1).
+  // The halo chains (ctc_fast_chain_halo_kernel, E2E_F1_MULTI=1) are parity-green and as fast as the single-wave chains,
+  // not faster (MI355X, B=256, T=1000, V=29, S<=200): chain kernel 91.6 us against 94.6 us, the whole step 161 against
+  // 167 us; at S<=127 the single-wave form wins (120 against 129 us per step).  What was measured on the way:
+  //   first form, every wave reducing and comparing the frame words itself        118 us   (~250 instructions per block and wave)
+  //   + frame waves (a chain wave writes one word per lane, reads one per block)    94 us   (~150)
+  //   + producers 8 lanes x 8 rows per pass (~110 VALU per block instead of ~300)    94 us   (the ring never runs dry any more)
+  //   + tilted blank row from the producers, one value per step across beta lanes    92 us   (-10 % VALU in the chain waves)
+  //   timing experiment: the blank rows' 8 of 12 LDS reads per block removed         92 us
+  // A wave alone on its SIMD needs ~130 cycles per step for ~19 instructions, two chain waves that share a SIMD ~165 for
+  // the slower one; neither fewer VALU instructions nor fewer LDS reads move that.  The step is the latency of the
+  // dependent f64 chain (cell -> DPP -> multiply-add -> multiply -> next step's DPP) plus the per-block bookkeeping of an
+  // in-order wave; 4 pairs per lane in ONE wave amortise that latency over four independent pairs, 1 pair per lane in
+  // four waves pays it four times in parallel -- same wall time.  The multi-wave pipeline of the previous design (edge
+  // values through LDS every step) took 120-152 us.  Default: single wave.
   static const bool single_wave = getenv("E2E_F1_MULTI") == nullptr;
   if (single_wave) {
     hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
@@ -1694,13 +1675,14 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
     return E2E_OK;
   } else {
-    const size_t ldsm = align_up(lds1, 16) + MwLds::bytes();
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_mw_kernel<PPL>),
+    const size_t ldsm = align_up(lds1, 32) + HaloLds::bytes();
+    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_halo_kernel<PPL>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_fast_chain_mw_kernel<PPL>, dim3(p.B), dim3(576), ldsm, stream, p);
+    hipLaunchKernelGGL(ctc_fast_chain_halo_kernel<PPL>, dim3(p.B), dim3(1024), ldsm, stream, p);
   }
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
-  hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);
+  FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB;            // (one common frame, as with the single-wave chains)
+  hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
   return E2E_OK;
 }
@@ -1746,8 +1728,8 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
 }  // namespace
 
 bool fast_supported(int T, int V, int Smax, int dtype) {
-  (void)T;
-  return dtype == E2E_F32 && V >= 2 && V <= kMaxSmallV && ppl_for(Smax) != 0;
+  // (T: the halo chains tag their frame words with the block index in 19 bits)
+  return dtype == E2E_F32 && V >= 2 && V <= kMaxSmallV && ppl_for(Smax) != 0 && T < (1 << 22);
 }
 
 size_t fast_workspace_bytes(int B, int T, int V, int Smax) {
@@ -1810,6 +1792,11 @@ extern "C" int e2e_debug_fast_profile2(unsigned long long* host, int reset) {
   if (reset) { void* ptr; if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(e2e::g_prof2)) != hipSuccess) return E2E_ERR_HIP;
     return hipMemset(ptr, 0, sizeof(unsigned long long) * 16384 * 8) == hipSuccess ? 0 : E2E_ERR_HIP; }
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(e2e::g_prof2), sizeof(unsigned long long) * 16384 * 8) == hipSuccess ? 0 : E2E_ERR_HIP;
+}
+extern "C" int e2e_debug_fast_profile3(unsigned long long* host, int reset) {
+  if (reset) { void* ptr; if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(e2e::g_prof3)) != hipSuccess) return E2E_ERR_HIP;
+    return hipMemset(ptr, 0, sizeof(unsigned long long) * 256 * 16 * 4) == hipSuccess ? 0 : E2E_ERR_HIP; }
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(e2e::g_prof3), sizeof(unsigned long long) * 256 * 16 * 4) == hipSuccess ? 0 : E2E_ERR_HIP;
 }
 extern "C" int e2e_debug_fast_profile(unsigned long long* host, int n) {
   if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;

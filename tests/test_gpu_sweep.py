@@ -68,7 +68,7 @@ def test_sharp_unrelated_emissions_are_taken_or_handed_over_but_never_wrong():
 
 
 def test_multi_wave_chains_variant_matches_exact(monkeypatch):
-    """The experimental multi-wave form of the chain kernel (E2E_F1_MULTI=1, read once per process: run in a child)."""
+    """The experimental halo form of the chain kernel (several waves per chain, E2E_F1_MULTI=1, read once per process: run in a child)."""
     import subprocess
     import sys
     code = r'''
