@@ -38,6 +38,7 @@ namespace {
 constexpr int kSeg = kFastSeg;  // steps per F2 segment == checkpoint spacing (16)
 constexpr int kBlk = 8;         // prep -> chain hand-off block and rescale period
 constexpr int kRingBlks = 8;    // ring depth (blocks)
+constexpr int kRow32 = 12;      // floats per label row of an f32 ring block (ctc_fast_chain_hf_kernel): 8 steps + pad, 48 B
 constexpr int kRow = 10;        // doubles per label row of a ring block: 8 steps + pad (80 B spreads the 16-byte gathers over the banks)
 constexpr int kMaxSmallV = 96;  // alphabet columns the lattice kernels take (prep: <= 12 columns per lane)
 
@@ -64,6 +65,7 @@ struct FastParams {
   int* lstart;     // [B][130]  first label-sorted slot of every label (V+1 entries used)
   int* ctl;        // [4]  0: fallback workgroups that have finished (F1 clears it; the last one reduces the losses)
   float gscale;    // every gradient element is multiplied by this as it is written (e2e_ctc_loss_opts.grad_scale)
+  float ztol;      // |log2| tolerance of the segment kernel's self-check (kZTol with f64 chains, kZTolF32 with f32 chains)
   int NS, NB, CELLS;
 };
 
@@ -403,15 +405,16 @@ __device__ __forceinline__ float exp_le0(float x) {
 // (Four steps per pass with 16 lanes each was the first form: the reductions, the reciprocal and the address
 // arithmetic are paid per pass, and at V = 29 that was ~300 VALU instructions per block against ~110 here.  The
 // producers share their SIMDs with the chain waves, so their instruction count is the chains' speed too.)
-// HALO: the ring's readers are the waves of ctc_fast_chain_halo_kernel, whose progress words replace `took`.
-template <int NV, bool HALO = false>
+// MODE 0: f64 ring read by one chain wave (`took`); 1: f64 ring read by the waves of ctc_fast_chain_halo_kernel, whose
+// progress words replace `took`, plus the tilted blank row; 2: f32 ring of ctc_fast_chain_hf_kernel -- label rows of
+// kRow32 floats and one row of (blank probability, tilted blank probability) pairs.
+template <int NV, int MODE = 0>
 __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int dir, int first, int stride,
-                                          const F1Lds& lds, int lane, lds_u8* prog = nullptr, double rr2 = 0.0) {
+                                          unsigned char* myring_bytes, int blk_bytes, volatile int* myfilled, volatile int* took,
+                                          int lane, lds_u8* prog = nullptr, double rr2 = 0.0) {
+  constexpr bool HALO = MODE != 0;
   const int V = p.V;
   const int nblk = (T + kBlk - 1) / kBlk;
-  double* myring = lds.ring + (size_t)dir * kRingBlks * lds.blk_elems;
-  volatile int* myfilled = lds.filled + dir * kRingBlks;
-  volatile int* took = lds.took + dir;
   const float* x = p.x + (int64_t)b * p.sB;
   float* ytab = p.ytab + (size_t)b * p.T * V;
   const int tt = lane >> 3, l8 = lane & 7;
@@ -444,7 +447,8 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
       else spin_until_ge(took, n - kRingBlks + 1);
       PROF_SPIN_END(prof_spin)
     }
-    double* blk = myring + (size_t)slot * lds.blk_elems;
+    double* blk = reinterpret_cast<double*>(myring_bytes + (size_t)slot * blk_bytes);
+    float* blk32 = reinterpret_cast<float*>(myring_bytes + (size_t)slot * blk_bytes);
     const int t = block_time(dir, n, tt, T);
     const bool row_live = t < T;
     float y[NV];
@@ -475,8 +479,16 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       if (col_live[k]) {
-        blk[(l8 + 8 * k) * kRow + tt] = row_live ? (double)y[k] : 0.0;   // transposed: [label][step]
-        if (HALO && l8 + 8 * k == p.blank) blk[(V + 1) * kRow + tt] = row_live ? rr2 * (double)y[k] : 0.0;
+        if (MODE == 2) {
+          blk32[(l8 + 8 * k) * kRow32 + tt] = row_live ? y[k] : 0.f;       // transposed: [label][step]
+          if (l8 + 8 * k == p.blank) {
+            float2 yw; yw.x = row_live ? y[k] : 0.f; yw.y = row_live ? (float)rr2 * y[k] : 0.f;
+            *reinterpret_cast<float2*>(blk32 + (V + 1) * kRow32 + 2 * tt) = yw;
+          }
+        } else {
+          blk[(l8 + 8 * k) * kRow + tt] = row_live ? (double)y[k] : 0.0;   // transposed: [label][step]
+          if (MODE == 1 && l8 + 8 * k == p.blank) blk[(V + 1) * kRow + tt] = row_live ? rr2 * (double)y[k] : 0.0;
+        }
         if (dir == 0 && row_live) yrow[l8 + 8 * k] = y[k];
       }
     }
@@ -778,11 +790,15 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   else {
     const int d = (wave == 2 || wave == 6) ? 0 : 1;     // waves 2,6 -> alpha rows, waves 3,7 -> beta rows
     const int first = wave >= 6 ? 1 : 0;                 // the two producers of a direction take alternate blocks
-    if (V <= 16) prep_wave<2>(p, b, T, d, first, 2, lds, lane);
-    else if (V <= 32) prep_wave<4>(p, b, T, d, first, 2, lds, lane);
-    else if (V <= 48) prep_wave<6>(p, b, T, d, first, 2, lds, lane);
-    else if (V <= 64) prep_wave<8>(p, b, T, d, first, 2, lds, lane);
-    else prep_wave<12>(p, b, T, d, first, 2, lds, lane);
+    unsigned char* ring = reinterpret_cast<unsigned char*>(lds.ring + (size_t)d * kRingBlks * lds.blk_elems);
+    const int bb = lds.blk_elems * 8;
+    volatile int* fl = lds.filled + d * kRingBlks;
+    volatile int* tk = lds.took + d;
+    if (V <= 16) prep_wave<2>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
+    else if (V <= 32) prep_wave<4>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
+    else if (V <= 48) prep_wave<6>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
+    else if (V <= 64) prep_wave<8>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
+    else prep_wave<12>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
   }
 }
 
@@ -1048,16 +1064,20 @@ __device__ __forceinline__ void halo_chain_wave(const FastParams& p, int b, int 
 // that the frame after block n is that absolute exponent.  It also writes the cum exponents for the segment kernel.
 // (The chain waves only leave one word per lane and read one word per block; the reductions happen here, two blocks
 // ahead of where they are needed.)
-template <int DIR>
-__device__ __forceinline__ void halo_frame_wave(const FastParams& p, int b, int T, lds_u8* L0, const HaloLds hl, int lane, int W) {
+// BIAS: the chain waves keep their cells 2^BIAS above the frame (f32 cells: the lagged frame leaves the row ~70 bits
+// below its unit, and the cells need room under the row's maximum as well).
+template <int DIR, bool F32 = false, int BIAS = 0>
+__device__ __forceinline__ void halo_frame_wave(const FastParams& p, int b, int T, lds_u8* L0, int prog_off, int exw_off, int mxl_off,
+                                                int maxw, int lane, int W) {
   static_assert(kHaloLag == 2, "the two exponents in flight are kept in two variables");
   const int nblk = (T + kBlk - 1) / kBlk;
   const int nres = DIR == 0 ? T / kBlk : nblk;       // blocks whose step 7 is live (alpha's last block may be short)
   const int M = (T - 1) >> 3;
   int* cum = (DIR == 0 ? p.cumA : p.cumB) + (size_t)b * p.NB;
-  lds_u8* prog = L0 + hl.prog + DIR * 32;
-  lds_u8* exw = L0 + hl.exw + DIR * (kHaloSlots * 4);
-  lds_u8* mxl = L0 + hl.mxl + (DIR * kHaloSlots * kHaloMaxW * 64 + lane) * 4;
+  lds_u8* prog = L0 + prog_off + DIR * 32;
+  lds_u8* exw = L0 + exw_off + DIR * (kHaloSlots * 4);
+  lds_u8* mxl = L0 + mxl_off + (DIR * kHaloSlots * maxw * 64 + lane) * 4;
+  constexpr int kExMax = F32 ? 100 : 1000;           // (f32 cells: the whole exponent range is 2^+-126)
   if (lane == 0) {
     if (DIR == 0) cum[0] = 0;
     else { cum[M + 1] = 0; cum[M + 2] = 0; }
@@ -1068,12 +1088,13 @@ __device__ __forceinline__ void halo_frame_wave(const FastParams& p, int b, int 
   for (int n = 0; n + kHaloLag < nres; n++) {
     HALO_WAIT(__builtin_amdgcn_readfirstlane(lds_min8(prog)) >= n + 1);
     int m = 0;
-    for (int w = 0; w < W; w++) m = max(m, *(volatile lds_int*)(mxl + ((n & (kHaloSlots - 1)) * kHaloMaxW + w) * 256));
-    m = wave_max(m);                  // positive doubles order like ints
+    for (int w = 0; w < W; w++) m = max(m, *(volatile lds_int*)(mxl + ((n & (kHaloSlots - 1)) * maxw + w) * 256));
+    m = wave_max(m);                  // positive floating-point numbers order like ints
     int ex = 0;
     if (m > 0) {
-      const int absolute = ((m >> 20) & 0x7ff) - 1023 + (through - ex1 - ex2);     // block n was measured before ex[n] was removed
-      ex = max(min(absolute - through, 1000), -1000);
+      const int e = (F32 ? ((m >> 23) & 0xff) - 127 : ((m >> 20) & 0x7ff) - 1023) - BIAS;
+      const int absolute = e + (through - ex1 - ex2);     // block n was measured before ex[n] was removed
+      ex = max(min(absolute - through, kExMax), -kExMax);
     }
     through += ex; ex2 = ex1; ex1 = ex;
     const int nn = n + kHaloLag;
@@ -1135,18 +1156,355 @@ __global__ __launch_bounds__(1024) void ctc_fast_chain_halo_kernel(FastParams p)
     else halo_chain_wave<1, PPL>(p, b, T, S, lds, L0, ring_bytes_dir, blk_bytes, hl, lane, w, W);
   } else if (wave == 14) {
     cellinfo_wave<PPL>(p, b, T, S, lds.sortcnt, lane);
-    halo_frame_wave<1>(p, b, T, L0, hl, lane, W);
-  } else if (wave == 15) halo_frame_wave<0>(p, b, T, L0, hl, lane, W);
+    halo_frame_wave<1>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHaloMaxW, lane, W);
+  } else if (wave == 15) halo_frame_wave<0>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHaloMaxW, lane, W);
   else {
     const int d = (wave - 8) & 1;                        // waves 8,10 -> alpha rows, 9,11 -> beta rows
     const int first = (wave - 8) >> 1;                   // the two producers of a direction take alternate blocks
     lds_u8* prog = L0 + hl.prog + d * 32;
     const double rr = (double)fast_tilt(S, T), rr2 = rr * rr;         // (the chain waves' own expression)
-    if (V <= 16) prep_wave<2, true>(p, b, T, d, first, 2, lds, lane, prog, rr2);
-    else if (V <= 32) prep_wave<4, true>(p, b, T, d, first, 2, lds, lane, prog, rr2);
-    else if (V <= 48) prep_wave<6, true>(p, b, T, d, first, 2, lds, lane, prog, rr2);
-    else if (V <= 64) prep_wave<8, true>(p, b, T, d, first, 2, lds, lane, prog, rr2);
-    else prep_wave<12, true>(p, b, T, d, first, 2, lds, lane, prog, rr2);
+    unsigned char* ring = reinterpret_cast<unsigned char*>(lds.ring + (size_t)d * kRingBlks * lds.blk_elems);
+    volatile int* fl = lds.filled + d * kRingBlks;
+    if (V <= 16) prep_wave<2, 1>(p, b, T, d, first, 2, ring, blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 32) prep_wave<4, 1>(p, b, T, d, first, 2, ring, blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 48) prep_wave<6, 1>(p, b, T, d, first, 2, ring, blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 64) prep_wave<8, 1>(p, b, T, d, first, 2, ring, blk_bytes, fl, nullptr, lane, prog, rr2);
+    else prep_wave<12, 1>(p, b, T, d, first, 2, ring, blk_bytes, fl, nullptr, lane, prog, rr2);
+  }
+}
+
+// ============================================================================================
+// F1, f32 halo form: two label pairs per lane in packed f32 instructions
+// ============================================================================================
+// The halo structure above with an f32 lattice.  What a chain wave costs is its instruction count per step (an in-order
+// wave issues an instruction every ~5.5 cycles at best, a dependent one every ~8.5 whatever its type --
+// tools/diag/microbench/issue_latency.hip), and v_pk_fma_f32 advances two pairs per instruction: a lane holds the
+// pairs (B0, L0), (B1, L1) as the packed registers B = (B0, B1), L = (L0, L1), and a step is
+//   alpha: PL = (L1 of the lane below, L0);  B' = B*yb + PL;  L' = (L + wb*B + SK*PL) * E        1 DPP + 1 move + 4 packed
+//   beta:  G = wb*B + SK*L;  TK = (G1, G0 of the lane above);  L' = (L + TK) * E;  B' = B*yb + L  1 DPP + 1 move + 5 packed
+// for 120 owned pairs per wave (60 lanes + 4 halo lanes = 8 pairs, one of which goes stale per step): two waves per
+// direction cover S <= 239, three the rest.  The probability ring is f32 (label rows of 8 steps; the blank's row holds
+// (probability, tilted probability) pairs, so that one packed operand carries both factors).
+// Numerics: the cells carry f32 rounding through the whole utterance (~1e-6 relative in the partition sum over 1 000
+// steps, measured); the loss is well inside its tolerance with that, and the gradient rows are normalised by their own
+// row sum in the segment kernel, so that only the NON-uniform part of the drift reaches them.  The segment kernel's
+// self-check compares every row sum with the chains' partition sum and runs at 3e-5 instead of 4e-6 with these chains
+// (FastParams::ztol): a row may lose 2e-5 of its posterior mass before it is redone, an absolute gradient error of that
+// size.  The common frame lags 16 steps as above; f32 has 126 bits of range for it, and a row that sinks further is
+// caught by the self-check (the cells that matter were flushed).
+constexpr int kHfHalo = 4;                    // halo lanes = 8 pairs
+constexpr int kHfOwnLanes = 64 - kHfHalo;     // 60
+constexpr int kHfOwn = 2 * kHfOwnLanes;       // 120 pairs a wave owns
+constexpr int kHfMaxW = 3;                    // ceil(256 / 120)
+constexpr int kHfBias = 60;                   // the cells are kept 2^60 above the common frame: the frame lags the row by two
+                                              // blocks (~70 bits for uninformative emissions at V = 29), which would leave f32
+                                              // cells only ~56 bits under the row's maximum; so the maximum sits between 2^-10
+                                              // and 2^60, with 67 bits of head room for rows that grow (tilt > 1) during the lag
+
+struct HfLds {
+  // byte offsets from the start of the workgroup's LDS
+  int ring;        // [2][kRingBlks] blocks of blk_bytes: (V+1) label rows of kRow32 floats (row V: zeros) + 16 floats (yb, wb) x 8 steps
+  int blk_bytes;
+  int filled;      // [2][kRingBlks] ints
+  int sortcnt;     // [130] ints (cellinfo_wave)
+  int bnd;         // [2][kHfMaxW][kHaloSlots][kHfHalo] x 16 B: wave w's edge lanes (B0, L0, B1, L1) after block n
+  int zacc;        // [8] doubles
+  int prog;        // [2][8] ints
+  int exw;         // [2][kHaloSlots] ints
+  int mxl;         // [2][kHaloSlots][kHfMaxW][64] ints
+  int total;
+  __host__ __device__ explicit HfLds(int V) {
+    ring = 0;
+    blk_bytes = ((V + 1) * kRow32 + 16) * 4;
+    filled = ring + 2 * kRingBlks * blk_bytes;
+    sortcnt = filled + 2 * kRingBlks * 4;
+    bnd = (sortcnt + 130 * 4 + 15) & ~15;
+    zacc = bnd + 2 * kHfMaxW * kHaloSlots * kHfHalo * 16;
+    prog = zacc + 64;
+    exw = prog + 2 * 8 * 4;
+    mxl = exw + 2 * kHaloSlots * 4;
+    total = mxl + 2 * kHaloSlots * kHfMaxW * 64 * 4;
+  }
+};
+
+typedef float h_f2 __attribute__((ext_vector_type(2)));
+typedef float h_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) h_f4 lds_f4;
+
+template <int DIR, int F2PPL>
+__device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T, int S, unsigned char* smem, const HfLds hl,
+                                              int lane, int w, int W) {
+  lds_u8* L0 = (lds_u8*)smem;
+  const int V = p.V, blank = p.blank, L = 2 * S + 1;
+  const int nblk = (T + kBlk - 1) / kBlk;
+  const int ring_off = hl.ring + DIR * kRingBlks * hl.blk_bytes;
+  volatile int* myfilled = reinterpret_cast<int*>(smem + hl.filled) + DIR * kRingBlks;
+  lds_u8* prog = L0 + hl.prog + DIR * 32;
+  lds_u8* exw = L0 + hl.exw + DIR * (kHaloSlots * 4);
+  lds_u8* mxl = L0 + hl.mxl + ((DIR * kHaloSlots * kHfMaxW + w) * 64 + lane) * 4;      // + slot * kHfMaxW * 256
+  __builtin_amdgcn_s_setprio(3);
+  unsigned long long prof_fill = 0, prof_nb = 0, prof_lag = 0, prof_t0 = __builtin_amdgcn_s_memtime();
+  (void)prof_fill; (void)prof_nb; (void)prof_lag; (void)prof_t0;
+
+  // this lane's two label pairs p0, p0 + 1: blank cells 2*p0, 2*p0 + 2, label cells 2*p0 + 1, 2*p0 + 3
+  const int p0 = kHfOwn * w + 2 * (DIR == 0 ? lane - kHfHalo : lane);
+  const bool owned = (DIR == 0 ? lane >= kHfHalo : lane < kHfOwnLanes) && p0 < 64 * F2PPL;
+  const bool halo = DIR == 0 ? lane < kHfHalo : lane >= kHfOwnLanes;
+  const bool has_up = DIR == 0 ? w > 0 : w < W - 1;
+  const bool has_down = DIR == 0 ? w < W - 1 : w > 0;
+  const int up = DIR == 0 ? w - 1 : w + 1;
+  const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
+  const float r_tilt = fast_tilt(S, T), rr2 = r_tilt * r_tilt, inv_rr = 1.f / r_tilt;
+  int lab[2]; float skv[2]; bool badlab = false;
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int pr = p0 + r;
+    const bool in = pr >= 0 && pr < S;
+    const int li = in ? (int)tg[pr] : -1;
+    const int lpv = (pr >= 1 && pr - 1 < S) ? (int)tg[pr - 1] : -1;
+    lab[r] = (in && li >= 0 && li < V) ? li : V;           // V: the always-zero row
+    // alpha: the skip (pr-1) -> pr as pair pr sees it; beta: the same skip as pair pr-1 sees it (this pair prepares what
+    // the label cell of the pair below takes from it)
+    skv[r] = DIR == 0 ? ((in && pr >= 1 && li != blank && lpv != li) ? rr2 : 0.f)        // ctc_loss.cpp:53-57
+                      : ((in && pr >= 1 && lpv != blank && li != lpv) ? rr2 : 0.f);      // ctc_loss.cpp:91-96
+    badlab |= owned && in && (li == blank || li < 0 || li >= V);
+  }
+  if (DIR == 0 && __any(badlab)) { if (lane == 0) atomicOr(&p.flags[b], 2); }
+  const h_f2 SK = {skv[0], skv[1]};
+  const bool cond = (T > 1 || L == 1);            // ctc_loss.cpp:39,76
+
+  h_f2 Bc = {0.f, 0.f}, Lc = {0.f, 0.f};           // B~ (blank cells before their emission), L^ (label cells, tilted), times 2^kHfBias
+  const float kOne = 0x1p60f;
+  static_assert(kHfBias == 60, "kOne");
+  float yb_prev = 0.f, wb_prev = 0.f;
+  int e_total = 0;
+  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
+
+  h_f4 e0raw[2], e1raw[2], ywraw[4];               // the block's probabilities: 4 steps per register set / 2 steps of (yb, wb)
+  const int lab0_off = lab[0] * (kRow32 * 4), lab1_off = lab[1] * (kRow32 * 4), yw_off = (V + 1) * (kRow32 * 4);
+  auto load_half = [&](int n, auto half_tag) {
+    constexpr int H = decltype(half_tag)::value;
+    const int yo = ring_off + (n % kRingBlks) * hl.blk_bytes;
+    e0raw[H] = *(lds_f4*)(L0 + yo + lab0_off + 16 * H);
+    e1raw[H] = *(lds_f4*)(L0 + yo + lab1_off + 16 * H);
+    ywraw[2 * H] = *(lds_f4*)(L0 + yo + yw_off + 32 * H); ywraw[2 * H + 1] = *(lds_f4*)(L0 + yo + yw_off + 32 * H + 16);
+  };
+
+  auto run_block = [&](int n, auto steady_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    load_half(n, std::integral_constant<int, 1>{});
+    const bool want_next = n + 1 < nblk;
+    int next_filled = 0;
+    if (want_next) next_filled = peek(&myfilled[(n + 1) % kRingBlks]);
+    if (n > 0 && has_up) {
+      { PROF_SPIN_BEGIN HALO_WAIT(__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(prog + 4 * up)) >= n); PROF_SPIN_END(prof_nb) }
+      const h_f4 v = *(lds_f4*)(L0 + hl.bnd + (((DIR * kHfMaxW + up) * kHaloSlots + ((n - 1) & (kHaloSlots - 1))) * kHfHalo + (lane & (kHfHalo - 1))) * 16);
+      if (halo) { Bc.x = v.x; Lc.x = v.y; Bc.y = v.z; Lc.y = v.w; }
+    }
+    const int tbase = block_time(DIR, n, 0, T);
+    int xw = 0;
+#pragma unroll
+    for (int tt = 0; tt < kBlk; tt++) {
+      const int t = DIR == 0 ? tbase + tt : tbase - tt;
+      const float yb = ywraw[tt >> 1][2 * (tt & 1)], wb = ywraw[tt >> 1][2 * (tt & 1) + 1];
+      const h_f2 E = {e0raw[tt >> 2][tt & 3], e1raw[tt >> 2][tt & 3]};
+      if (tt == 4) {
+        xw = *(volatile lds_int*)(exw + 4 * (n & (kHaloSlots - 1)));
+        if (want_next && __builtin_amdgcn_readfirstlane(next_filled) != n + 2) { PROF_SPIN_BEGIN spin_until(&myfilled[(n + 1) % kRingBlks], n + 2); PROF_SPIN_END(prof_fill) }
+        load_half(n + 1, std::integral_constant<int, 0>{});
+      }
+      if (STEADY || t < T) {
+        const bool first = !STEADY && (DIR == 0 ? t == 0 : t == T - 1);
+        const h_f2 YB = {yb_prev, yb_prev}, WB = {wb_prev, wb_prev};
+        if (DIR == 0) {
+          // alpha_t[j] = (alpha[j] + r*alpha[j-1] + r^2*skip*alpha[j-2]) * y_t[l_j], ctc_loss.cpp:47-60
+          if (first) {
+            if (p0 == 0) { Bc.x = cond ? kOne : 0.f; Lc.x = kOne * rr2 * E.x; }     // ctc_loss.cpp:39-42
+          } else {
+            const h_f2 PL = {from_prev_lane(Lc.y), Lc.x};       // the label cell just below each pair's blank
+            const h_f2 Bn = __builtin_elementwise_fma(Bc, YB, PL);
+            h_f2 tl = __builtin_elementwise_fma(Bc, WB, Lc);
+            tl = __builtin_elementwise_fma(SK, PL, tl);
+            Lc = tl * E; Bc = Bn;
+          }
+        } else {
+          // q_t[j] = (q[j] + r*q[j+1] + r^2*skipn*q[j+2]) * y_t[l_j]; q = beta * emission, ctc_loss.cpp:84-99
+          if (first) {
+            if (cond) { if (p0 == S) Bc.x = kOne; if (p0 + 1 == S) Bc.y = kOne; }  // ctc_loss.cpp:76
+            if (p0 == S - 1) Lc.x = kOne * rr2 * E.x;                               // ctc_loss.cpp:78
+            if (p0 + 1 == S - 1) Lc.y = kOne * rr2 * E.y;
+          } else {
+            const h_f2 G = __builtin_elementwise_fma(WB, Bc, SK * Lc);      // what the label cell of the pair below takes
+            const h_f2 TK = {G.y, from_next_lane(G.x)};
+            const h_f2 Lo = Lc;
+            Lc = (Lo + TK) * E;
+            Bc = __builtin_elementwise_fma(Bc, YB, Lo);
+          }
+        }
+        yb_prev = yb; wb_prev = wb;
+        if (tt == 7) {
+          // the frame: see halo_chain_wave
+          const int m01 = max(__float_as_int(Bc.x), __float_as_int(Lc.x)), m23 = max(__float_as_int(Bc.y), __float_as_int(Lc.y));
+          *(volatile lds_int*)(mxl + (n & (kHaloSlots - 1)) * (kHfMaxW * 256)) = max(m01, m23);    // positive floats order like ints
+          xw = __builtin_amdgcn_readfirstlane(xw);
+          if ((xw >> 12) != n) {
+            PROF_SPIN_BEGIN
+            int spins = 0;
+            do {
+              __builtin_amdgcn_s_sleep(1);
+              xw = __builtin_amdgcn_readfirstlane(*(volatile lds_int*)(exw + 4 * (n & (kHaloSlots - 1))));
+              if (++spins > (1 << 20)) { atomicOr(&p.flags[b], 128); xw = (n << 12) | 2048; }
+            } while ((xw >> 12) != n);
+            PROF_SPIN_END(prof_lag)
+          }
+          const int ex = (xw & 0xfff) - 2048;
+          Bc.x = ldexpf(Bc.x, -ex); Bc.y = ldexpf(Bc.y, -ex); Lc.x = ldexpf(Lc.x, -ex); Lc.y = ldexpf(Lc.y, -ex);
+          e_total += ex;
+          const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
+          if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
+            // block floating point: each group of F2PPL pairs stores its cells scaled by its own exponent
+            const float c0 = Bc.x * yb_prev, c1 = Lc.x * inv_rr, c2 = Bc.y * yb_prev, c3 = Lc.y * inv_rr;   // the true cells
+            const int ma = max(__float_as_int(c0), __float_as_int(c1)), mb = max(__float_as_int(c2), __float_as_int(c3));
+            int m0 = ma, m1 = mb;                                           // exponent source of pair p0 / p0 + 1
+            if (F2PPL >= 2) { m0 = max(ma, mb); m1 = m0; }
+            if (F2PPL >= 4) { m0 = max(m0, dpp_i<0xB1>(0, m0)); m1 = m0; }  // quad_perm [1,0,3,2]: the lane pair
+            const int own0 = m0 > 0 ? ((m0 >> 23) & 0xff) - 127 : -30000, own1 = m1 > 0 ? ((m1 >> 23) & 0xff) - 127 : -30000;
+            const int st0 = m0 > 0 ? own0 - kHfBias : -30000, st1 = m1 > 0 ? own1 - kHfBias : -30000;     // relative to the frame
+            if (owned) {
+              h_f4 o;
+              o.x = m0 > 0 ? ldexpf(c0, -own0) : 0.f; o.y = m0 > 0 ? ldexpf(c1, -own0) : 0.f;
+              o.z = m1 > 0 ? ldexpf(c2, -own1) : 0.f; o.w = m1 > 0 ? ldexpf(c3, -own1) : 0.f;
+              *reinterpret_cast<h_f4*>(ck + (size_t)(kk / kSeg) * p.CELLS + 2 * p0) = o;
+              short* cke = p.ckE + (((size_t)b * p.NS + kk / kSeg) * 2 + DIR) * 64;
+              if (F2PPL == 1) { cke[p0] = (short)st0; cke[p0 + 1] = (short)st1; }
+              else if ((p0 & (F2PPL - 1)) == 0) cke[p0 / F2PPL] = (short)st0;
+            }
+          }
+        }
+      }
+    }
+    if (has_down) {
+      const bool edge = DIR == 0 ? lane >= 64 - kHfHalo : lane < kHfHalo;
+      if (edge) {
+        h_f4 v; v.x = Bc.x; v.y = Lc.x; v.z = Bc.y; v.w = Lc.y;
+        *(lds_f4*)(L0 + hl.bnd + (((DIR * kHfMaxW + w) * kHaloSlots + (n & (kHaloSlots - 1))) * kHfHalo + (lane & (kHfHalo - 1))) * 16) = v;
+      }
+    }
+    *(volatile lds_int*)(prog + 4 * w) = n + 1;
+  };
+  {
+    spin_until(&myfilled[0], 1);
+    load_half(0, std::integral_constant<int, 0>{});
+    const int steady_end = DIR == 0 ? T / kBlk : nblk;         // blocks [1, steady_end) are steady
+    run_block(0, std::false_type{});
+    int n = 1;
+    for (; n < steady_end; n++) run_block(n, std::true_type{});
+    for (; n < nblk; n++) run_block(n, std::false_type{});
+  }
+#ifdef E2E_FAST_PROFILE
+  if (lane == 0 && b < 256) { unsigned long long* g = g_prof3 + ((size_t)b * 16 + DIR * 8 + w) * 4;
+    g[0] = __builtin_amdgcn_s_memtime() - prof_t0; g[1] = prof_fill; g[2] = prof_nb; g[3] = prof_lag; }
+#endif
+  // ---- log Z from this side ----
+  if (DIR == 0) {
+    double z = 0.0;
+    if (owned) {
+      if (p0 == S) z += (double)Bc.x * (double)yb_prev;          // ctc_loss.cpp:63-70, un-tilted relative to cell L-1
+      if (p0 + 1 == S) z += (double)Bc.y * (double)yb_prev;
+      if (p0 == S - 1) z += (double)Lc.x;                        // (= r * the label cell)
+      if (p0 + 1 == S - 1) z += (double)Lc.y;
+    }
+    for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
+    *(volatile lds_f64*)(L0 + hl.zacc + 8 * w) = z;
+    *(volatile lds_int*)(prog + 4 * w) = nblk + 1;
+    if (w == 0) {
+      HALO_WAIT(__builtin_amdgcn_readfirstlane(lds_min8(prog)) >= nblk + 1);
+      if (lane == 0) {
+        double zs = 0.0;
+        for (int k = 0; k < W; k++) zs += *(volatile lds_f64*)(L0 + hl.zacc + 8 * k);
+        const double rr = (double)r_tilt;
+        const double lz = log(zs) + (double)(e_total - kHfBias) * 0.693147180559945309417 - (double)(L - 1) * log(rr);
+        p.logz[2 * b] = lz;
+        p.zt2[b] = log2(zs) + (double)(e_total - kHfBias);
+        p.losses[b] = (float)(-lz);
+        if (!(zs > 0.0) || !(zs < __builtin_huge_val())) atomicOr(&p.flags[b], 4);     // infeasible or out of range
+      }
+    }
+  } else if (w == 0 && lane == 0) {
+    const double z = (cond ? (double)Bc.x * (double)yb_prev : 0.0) + (double)Lc.x;     // sum_j alpha_0[j]*beta_0[j]
+    p.logz[2 * b + 1] = log(z) + (double)(e_total - kHfBias) * 0.693147180559945309417 - (double)(L - 1) * log((double)r_tilt);
+  }
+}
+
+// a wave that holds no cell of this utterance: the segment kernel still reads the full row width -- leave zeros
+template <int DIR, int F2PPL>
+__device__ __forceinline__ void hf_idle_wave(const FastParams& p, int b, int lane, int w) {
+  if (lane >= kHfOwnLanes) return;
+  const int p0 = kHfOwn * w + 2 * lane;
+  if (p0 >= 64 * F2PPL) return;
+  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
+  short* cke = p.ckE + (size_t)b * p.NS * 2 * 64;
+  for (int k = 1; k < p.NS; k++) {
+    h_f4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<h_f4*>(ck + (size_t)k * p.CELLS + 2 * p0) = z;
+    if (F2PPL == 1) { cke[((size_t)k * 2 + DIR) * 64 + p0] = (short)-30000; cke[((size_t)k * 2 + DIR) * 64 + p0 + 1] = (short)-30000; }
+    else if ((p0 & (F2PPL - 1)) == 0) cke[((size_t)k * 2 + DIR) * 64 + p0 / F2PPL] = (short)-30000;
+  }
+}
+
+// Waves: 0-3 = alpha0, beta0, alpha1, beta1 (SIMDs 0,2,1,3), 4,5 = alpha2, beta2, 6 = alpha's frame wave, 7 = lattice
+// description, then beta's frame wave, 8-11 = probability rows (8,10 alpha side, 9,11 beta side).
+template <int PPL>
+__global__ __launch_bounds__(768) void ctc_fast_chain_hf_kernel(FastParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int V = p.V;
+  const HfLds hl(V);
+
+  if (b == 0 && tid < 4) p.ctl[tid] = 0;
+  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
+  const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
+  if (bad) {                       // the exact kernel poisons this utterance
+    if (tid == 0) { p.flags[b] = 1; p.losses[b] = __builtin_nanf(""); }   // reason bit 0: bad lengths
+    return;
+  }
+  const int T = (int)Tq, S = (int)Sq;
+  constexpr int MAXW = (64 * PPL + kHfOwn - 1) / kHfOwn;          // waves that can hold a cell at this row width
+  const int W = min(S / kHfOwn + 1, MAXW);                        // waves that hold a cell: pairs 0..S (pair S = the last blank)
+  if (tid == 0) p.flags[b] = 0;
+  if (tid < 2 * kRingBlks) reinterpret_cast<int*>(smem + hl.filled)[tid] = 0;
+  if (tid < 16) reinterpret_cast<int*>(smem + hl.prog)[tid] = (tid & 7) < W ? 0 : kHaloIdle;
+  if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHaloLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;
+  if (tid < 8) reinterpret_cast<double*>(smem + hl.zacc)[tid] = 0.0;
+  for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
+    reinterpret_cast<float*>(smem + hl.ring + (i / kBlk) * hl.blk_bytes)[V * kRow32 + (i % kBlk)] = 0.f;
+  __syncthreads();
+
+  const int wave = __builtin_amdgcn_readfirstlane(wid);
+  lds_u8* L0 = (lds_u8*)smem;
+  if (wave < 6) {
+    const int d = wave & 1, w = wave >> 1;
+    if (w >= MAXW) return;
+    if (w >= W) { if (d == 0) hf_idle_wave<0, PPL>(p, b, lane, w); else hf_idle_wave<1, PPL>(p, b, lane, w); }
+    else if (d == 0) hf_chain_wave<0, PPL>(p, b, T, S, smem, hl, lane, w, W);
+    else hf_chain_wave<1, PPL>(p, b, T, S, smem, hl, lane, w, W);
+  } else if (wave == 6) halo_frame_wave<0, true, kHfBias>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W);
+  else if (wave == 7) {
+    cellinfo_wave<PPL>(p, b, T, S, reinterpret_cast<int*>(smem + hl.sortcnt), lane);
+    halo_frame_wave<1, true, kHfBias>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W);
+  } else {
+    const int d = (wave - 8) & 1;                        // waves 8,10 -> alpha rows, 9,11 -> beta rows
+    const int first = (wave - 8) >> 1;                   // the two producers of a direction take alternate blocks
+    lds_u8* prog = L0 + hl.prog + d * 32;
+    const float r_tilt = fast_tilt(S, T);
+    const double rr2 = (double)(r_tilt * r_tilt);        // (the chain waves' own expression, in f32)
+    unsigned char* ring = smem + hl.ring + d * kRingBlks * hl.blk_bytes;
+    volatile int* fl = reinterpret_cast<int*>(smem + hl.filled) + d * kRingBlks;
+    if (V <= 16) prep_wave<2, 2>(p, b, T, d, first, 2, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 32) prep_wave<4, 2>(p, b, T, d, first, 2, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 48) prep_wave<6, 2>(p, b, T, d, first, 2, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 64) prep_wave<8, 2>(p, b, T, d, first, 2, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else prep_wave<12, 2>(p, b, T, d, first, 2, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
   }
 }
 
@@ -1161,6 +1519,10 @@ constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before 
 #define E2E_ZTOL 4e-6f
 #endif
 constexpr float kZTol = E2E_ZTOL;   // |log2| tolerance of the rows' self-check (2.8e-6 relative; rounding alone stays below 1e-6)
+#ifndef E2E_ZTOL_F32
+#define E2E_ZTOL_F32 3e-5f
+#endif
+constexpr float kZTolF32 = E2E_ZTOL_F32;   // the same with f32 chains (ctc_fast_chain_hf_kernel), whose own rounding reaches ~5e-6
 constexpr int kYs = kSeg + 4;      // row stride (floats) of the transposed probability tile: 80 B spreads the
                                    // 16-byte gathers of different labels over the LDS bank row
 
@@ -1250,7 +1612,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
       if (wg < 16384 && live) atomicMax(reinterpret_cast<int*>(&g_zdev[wg]), __float_as_int(fminf(fabsf(dev), 1e30f))); }
 #endif
     // (smin / smax: see the range check at the end of the kernel)
-    const bool bad = live && !(fabsf(dev) <= kZTol && my_st >= E2E_SMIN);
+    const bool bad = live && !(fabsf(dev) <= p.ztol && my_st >= E2E_SMIN);
     if (__any(bad)) smin = 0.f;
     if (__any(live && !(my_st < __builtin_huge_valf()))) smax = __builtin_huge_valf();
   }
@@ -1668,6 +2030,18 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   // four waves pays it four times in parallel -- same wall time.  The multi-wave pipeline of the previous design (edge
   // values through LDS every step) took 120-152 us.  Default: single wave.
   static const bool single_wave = getenv("E2E_F1_MULTI") == nullptr;
+  static const bool f32_chains = getenv("E2E_F1_F32") != nullptr;
+  if (f32_chains) {
+    const HfLds hl(p.V);
+    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
+    hipLaunchKernelGGL(ctc_fast_chain_hf_kernel<PPL>, dim3(p.B), dim3(768), hl.total, stream, p);
+    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
+    FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB; q.ztol = kZTolF32;
+    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
+    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
+    return E2E_OK;
+  }
   if (single_wave) {
     hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
     FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB;          // (its frame follows the maximum itself)
@@ -1760,6 +2134,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart);
   p.ctl = reinterpret_cast<int*>(ws + l.ctl);
   p.gscale = (float)a.grad_scale;
+  p.ztol = kZTol;
   p.NS = l.NS; p.NB = l.NB; p.CELLS = l.CELLS;
   int rc;
   switch (ppl_for(a.Smax)) {
