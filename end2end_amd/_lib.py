@@ -23,11 +23,12 @@ _lock = threading.Lock()
 
 
 REDUCE_NONE, REDUCE_SUM, REDUCE_MEAN = 0, 1, 2
+CHAINS_F64, CHAINS_F32 = 0, 1
 
 
 class LossOpts(C.Structure):
     """e2e_ctc_loss_opts (include/e2e_ctc.h)."""
-    _fields_ = [("grad_scale", C.c_double), ("reduced", C.c_void_p), ("reduction", C.c_int)]
+    _fields_ = [("grad_scale", C.c_double), ("reduced", C.c_void_p), ("reduction", C.c_int), ("chains", C.c_int)]
 
 
 class E2EError(RuntimeError):

@@ -157,6 +157,9 @@ int e2e_ctc_loss_fwd_bwd_opt(const void* x, int dtype, int input_is_logprobs,
                (opts->reduction != E2E_REDUCE_NONE && !opts->reduced))) {
     set_error("bad e2e_ctc_loss_opts: reduction %d, reduced %p", opts->reduction, opts->reduced); return E2E_ERR_ARG;
   }
+  if (opts && opts->chains != E2E_CHAINS_F64 && opts->chains != E2E_CHAINS_F32) {
+    set_error("bad e2e_ctc_loss_opts: chains %d", opts->chains); return E2E_ERR_ARG;
+  }
   if (dtype != E2E_F32 && dtype != E2E_F64) { set_error("dtype must be E2E_F32 or E2E_F64"); return E2E_ERR_ARG; }
   if (B < 0 || T < 1 || V < 1 || Smax < 0) { set_error("bad sizes B=%d T=%d V=%d Smax=%d", B, T, V, Smax); return E2E_ERR_ARG; }
   if (blank < 0 || blank >= V) { set_error("blank=%d outside [0,%d)", blank, V); return E2E_ERR_ARG; }
@@ -170,7 +173,7 @@ int e2e_ctc_loss_fwd_bwd_opt(const void* x, int dtype, int input_is_logprobs,
   if (workspace && workspace_bytes >= (aligned - base)) { workspace_bytes -= (aligned - base); workspace = reinterpret_cast<void*>(aligned); }
   LossArgs a{x, dtype, input_is_logprobs ? 1 : 0, sB, sT, sV, targets, tgt_stride, x_len, t_len,
              B, T, V, Smax, blank, losses, grads, workspace, workspace_bytes, (hipStream_t)stream};
-  if (opts) { a.grad_scale = opts->grad_scale; a.reduced = opts->reduced; a.reduction = opts->reduction; }
+  if (opts) { a.grad_scale = opts->grad_scale; a.reduced = opts->reduced; a.reduction = opts->reduction; a.chains = opts->chains; }
   const int r = resolve_algo(algo, dtype, T, V, Smax);
   if (r == E2E_ALGO_EXACT) { const int rc = launch_exact(a); return rc != E2E_OK ? rc : launch_reduce_losses(a); }
   if (use_wide(dtype, T, V, Smax)) { const int rc = launch_wide(a, r == E2E_ALGO_AUTO); return rc != E2E_OK ? rc : launch_reduce_losses(a); }

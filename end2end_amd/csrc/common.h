@@ -32,6 +32,7 @@ struct LossArgs {
   double grad_scale = 1.0;
   void* reduced = nullptr;
   int reduction = 0;
+  int chains = 0;          // E2E_CHAINS_*
 };
 // sum / mean of the losses by one small launch (paths that have no tail to fold it into)
 int launch_reduce_losses(const LossArgs& a);

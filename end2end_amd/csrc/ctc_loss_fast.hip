@@ -66,6 +66,7 @@ struct FastParams {
   int* ctl;        // [4]  0: fallback workgroups that have finished (F1 clears it; the last one reduces the losses)
   float gscale;    // every gradient element is multiplied by this as it is written (e2e_ctc_loss_opts.grad_scale)
   float ztol;      // |log2| tolerance of the segment kernel's self-check (kZTol with f64 chains, kZTolF32 with f32 chains)
+  int chains;      // host side: E2E_CHAINS_* of the call
   int NS, NB, CELLS;
 };
 
@@ -492,7 +493,10 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
         if (dir == 0 && row_live) yrow[l8 + 8 * k] = y[k];
       }
     }
-    publish(&myfilled[slot], n + 1);     // every lane stores the same word: no divergence, one LDS write
+    // every lane stores the same word: no divergence, one LDS write.  (MODE 2: one word per producer, "my blocks up to n
+    // are there" -- the readers keep the minimum of the two in a scalar and look again only when they catch up.)
+    if (MODE == 2) publish(&myfilled[first], n + 2);
+    else publish(&myfilled[slot], n + 1);
 #pragma unroll
     for (int k = 0; k < NV; k++) xv[k] = xn[k];
   }
@@ -1064,42 +1068,50 @@ __device__ __forceinline__ void halo_chain_wave(const FastParams& p, int b, int 
 // that the frame after block n is that absolute exponent.  It also writes the cum exponents for the segment kernel.
 // (The chain waves only leave one word per lane and read one word per block; the reductions happen here, two blocks
 // ahead of where they are needed.)
-// BIAS: the chain waves keep their cells 2^BIAS above the frame (f32 cells: the lagged frame leaves the row ~70 bits
+// bias: the chain waves keep their cells 2^bias above the frame (f32 cells: the lagged frame leaves the row ~70 bits
 // below its unit, and the cells need room under the row's maximum as well).
-template <int DIR, bool F32 = false, int BIAS = 0>
+// LAG: blocks between the measurement and its use.  Two leave the waves a block of slack against each other; one keeps the
+// row within 8 steps' decay of its unit (f32 cells), at the price of the waves meeting at every block's end.
+template <int DIR, bool F32 = false, int LAG = kHaloLag, bool TRACK = false>
 __device__ __forceinline__ void halo_frame_wave(const FastParams& p, int b, int T, lds_u8* L0, int prog_off, int exw_off, int mxl_off,
-                                                int maxw, int lane, int W) {
-  static_assert(kHaloLag == 2, "the two exponents in flight are kept in two variables");
+                                                int maxw, int lane, int W, int bias = 0) {
+  static_assert(LAG == 1 || LAG == 2, "the exponents in flight are kept in two variables");
   const int nblk = (T + kBlk - 1) / kBlk;
   const int nres = DIR == 0 ? T / kBlk : nblk;       // blocks whose step 7 is live (alpha's last block may be short)
   const int M = (T - 1) >> 3;
   int* cum = (DIR == 0 ? p.cumA : p.cumB) + (size_t)b * p.NB;
+  // TRACK: the row's TRUE exponent per block as well (known here one block late, which does not matter to a kernel that
+  // runs afterwards): the segment kernel takes its in-segment rescales from these, the frame of a checkpoint from cum
+  int* trk = (DIR == 0 ? p.trkA : p.trkB) + (size_t)b * p.NB;
   lds_u8* prog = L0 + prog_off + DIR * 32;
   lds_u8* exw = L0 + exw_off + DIR * (kHaloSlots * 4);
   lds_u8* mxl = L0 + mxl_off + (DIR * kHaloSlots * maxw * 64 + lane) * 4;
   constexpr int kExMax = F32 ? 100 : 1000;           // (f32 cells: the whole exponent range is 2^+-126)
   if (lane == 0) {
-    if (DIR == 0) cum[0] = 0;
-    else { cum[M + 1] = 0; cum[M + 2] = 0; }
-    for (int n = 0; n < kHaloLag && n < nres; n++) cum[DIR == 0 ? n + 1 : M - n] = 0;      // (their words were set with the flags)
+    if (DIR == 0) { cum[0] = 0; if (TRACK) trk[0] = 0; }
+    else { cum[M + 1] = 0; cum[M + 2] = 0; if (TRACK) { trk[M + 1] = 0; trk[M + 2] = 0; } }
+    for (int n = 0; n < LAG && n < nres; n++) cum[DIR == 0 ? n + 1 : M - n] = 0;      // (their words were set with the flags)
   }
-  int through = 0;                    // sum of ex[k], k <= n + 1: the frame after block n + 1
-  int ex1 = 0, ex2 = 0;               // ex[n + 1], ex[n]
-  for (int n = 0; n + kHaloLag < nres; n++) {
+  int through = 0;                    // sum of ex[k], k < n + LAG: the frame after block n + LAG - 1
+  int ex1 = 0, ex2 = 0;               // ex[n + 1], ex[n] (LAG 2); ex[n] (LAG 1)
+  int absolute = 0;                   // exponent of the row's maximum at the end of block n, in absolute terms
+  for (int n = 0; n < (TRACK ? nres : nres - LAG); n++) {
     HALO_WAIT(__builtin_amdgcn_readfirstlane(lds_min8(prog)) >= n + 1);
     int m = 0;
     for (int w = 0; w < W; w++) m = max(m, *(volatile lds_int*)(mxl + ((n & (kHaloSlots - 1)) * maxw + w) * 256));
     m = wave_max(m);                  // positive floating-point numbers order like ints
-    int ex = 0;
     if (m > 0) {
-      const int e = (F32 ? ((m >> 23) & 0xff) - 127 : ((m >> 20) & 0x7ff) - 1023) - BIAS;
-      const int absolute = e + (through - ex1 - ex2);     // block n was measured before ex[n] was removed
-      ex = max(min(absolute - through, kExMax), -kExMax);
+      const int e = (F32 ? ((m >> 23) & 0xff) - 127 : ((m >> 20) & 0x7ff) - 1023) - bias;
+      absolute = e + (through - ex1 - (LAG == 2 ? ex2 : 0));     // block n was measured before ex[n] was removed
     }
-    through += ex; ex2 = ex1; ex1 = ex;
-    const int nn = n + kHaloLag;
-    *(volatile lds_int*)(exw + 4 * (nn & (kHaloSlots - 1))) = (nn << 12) | (ex + 2048);
-    if (lane == 0) cum[DIR == 0 ? nn + 1 : M - nn] = through;
+    if (TRACK && lane == 0) trk[DIR == 0 ? n + 1 : M - n] = absolute;
+    if (n + LAG < nres) {
+      const int ex = m > 0 ? max(min(absolute - through, kExMax), -kExMax) : 0;
+      through += ex; ex2 = ex1; ex1 = ex;
+      const int nn = n + LAG;
+      *(volatile lds_int*)(exw + 4 * (nn & (kHaloSlots - 1))) = (nn << 12) | (ex + 2048);
+      if (lane == 0) cum[DIR == 0 ? nn + 1 : M - nn] = through;
+    }
   }
 }
 
@@ -1188,24 +1200,32 @@ __global__ __launch_bounds__(1024) void ctc_fast_chain_halo_kernel(FastParams p)
 // Numerics: the cells carry f32 rounding through the whole utterance (~1e-6 relative in the partition sum over 1 000
 // steps, measured); the loss is well inside its tolerance with that, and the gradient rows are normalised by their own
 // row sum in the segment kernel, so that only the NON-uniform part of the drift reaches them.  The segment kernel's
-// self-check compares every row sum with the chains' partition sum and runs at 3e-5 instead of 4e-6 with these chains
-// (FastParams::ztol): a row may lose 2e-5 of its posterior mass before it is redone, an absolute gradient error of that
-// size.  The common frame lags 16 steps as above; f32 has 126 bits of range for it, and a row that sinks further is
+// self-check compares every row sum with the chains' partition sum and runs at 1e-5 instead of 4e-6 with these chains
+// (FastParams::ztol; their own rounding shows as 6e-7 median, 3e-6 at most over the sweeps): a row may lose 7e-6 of its
+// posterior mass before it is redone, an absolute gradient error of that size on top of the chains' drift (worst
+// gradient element over four randomised sweeps: 8.4e-6 off; include/e2e_ctc.h states 2e-5 for the option).  The common frame lags 16 steps as above; f32 has 126 bits of range for it, and a row that sinks further is
 // caught by the self-check (the cells that matter were flushed).
 constexpr int kHfHalo = 4;                    // halo lanes = 8 pairs
 constexpr int kHfOwnLanes = 64 - kHfHalo;     // 60
 constexpr int kHfOwn = 2 * kHfOwnLanes;       // 120 pairs a wave owns
 constexpr int kHfMaxW = 3;                    // ceil(256 / 120)
-constexpr int kHfBias = 60;                   // the cells are kept 2^60 above the common frame: the frame lags the row by two
-                                              // blocks (~70 bits for uninformative emissions at V = 29), which would leave f32
-                                              // cells only ~56 bits under the row's maximum; so the maximum sits between 2^-10
-                                              // and 2^60, with 67 bits of head room for rows that grow (tilt > 1) during the lag
+constexpr int kHfLag = 2;                     // the frame follows the row's maximum two blocks late (one: the waves meet at every
+                                              // block's end, 153 instead of 145 us per step at the headline shape)
+// The cells are kept 2^bias above that frame.  A row sinks 26-42 bits per block for uninformative emissions at V = 29..64
+// and is not rescaled at all during its first three blocks, and cells 100 bits under the row's maximum still carry
+// posterior mass at some t (measured: with the maximum at 2^-25 .. 2^-67, 15 % of the utterances at V = 64 lose 1e-4 of
+// log Z).  Without tilt > 1 a row's maximum grows by at most 3x per step (alpha[j] <= 3 max(alpha) y), 2^25.4 over the
+// 16 steps of lag: bias 100 cannot overflow.  With tilt > 1 (dense targets) rows can in principle grow faster; those keep
+// 10 bits more head room (with 40 instead, a third of the dense utterances at V = 64 sank out of range), and an overflow
+// ends as a non-finite row sum, which the segment kernel flags.
+// (Extrapolating the sinking rate to decide the frame was tried: the differences amplify the row-to-row variation.)
+__device__ __forceinline__ int hf_bias(float r_tilt) { return r_tilt <= 1.f ? 100 : 90; }
 
 struct HfLds {
   // byte offsets from the start of the workgroup's LDS
   int ring;        // [2][kRingBlks] blocks of blk_bytes: (V+1) label rows of kRow32 floats (row V: zeros) + 16 floats (yb, wb) x 8 steps
   int blk_bytes;
-  int filled;      // [2][kRingBlks] ints
+  int filled;      // [2][kRingBlks] ints; used: [dir][0..1] = 2 + the last block producer 0 / 1 of the direction has finished
   int sortcnt;     // [130] ints (cellinfo_wave)
   int bnd;         // [2][kHfMaxW][kHaloSlots][kHfHalo] x 16 B: wave w's edge lanes (B0, L0, B1, L1) after block n
   int zacc;        // [8] doubles
@@ -1273,12 +1293,30 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
   const h_f2 SK = {skv[0], skv[1]};
   const bool cond = (T > 1 || L == 1);            // ctc_loss.cpp:39,76
 
-  h_f2 Bc = {0.f, 0.f}, Lc = {0.f, 0.f};           // B~ (blank cells before their emission), L^ (label cells, tilted), times 2^kHfBias
-  const float kOne = 0x1p60f;
-  static_assert(kHfBias == 60, "kOne");
+  h_f2 Bc = {0.f, 0.f}, Lc = {0.f, 0.f};           // B~ (blank cells before their emission), L^ (label cells, tilted), times 2^bias
+  const int bias = hf_bias(r_tilt);
+  const float kOne = ldexpf(1.f, bias);
   float yb_prev = 0.f, wb_prev = 0.f;
   int e_total = 0;
-  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
+  // checkpoint rows are visited in order (alpha: slots 1, 2, ...; beta: the last one first): running pointers
+  const int slot0 = DIR == 0 ? 1 : (T - 1) / kSeg;
+  float* ckp = (DIR == 0 ? p.ckA : p.ckQ) + ((size_t)b * p.NS + slot0) * p.CELLS + 2 * p0;
+  short* ckep = p.ckE + (((size_t)b * p.NS + slot0) * 2 + DIR) * 64 + (F2PPL == 1 ? p0 : p0 / F2PPL);
+  const int ck_step = DIR == 0 ? p.CELLS : -p.CELLS;
+  int lead = 0;                                    // blocks of probabilities known to be in the ring: [0, lead)
+  auto need_blocks = [&](int k) {                  // (the producers run several blocks ahead: one look every few blocks)
+    if (lead < k) {
+      PROF_SPIN_BEGIN
+      for (;;) {
+        const int a0 = peek(&myfilled[0]), a1 = peek(&myfilled[1]);
+        lead = __builtin_amdgcn_readfirstlane(min(a0, a1));
+        if (lead >= k) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+      PROF_SPIN_END(prof_fill)
+    }
+  };
 
   h_f4 e0raw[2], e1raw[2], ywraw[4];               // the block's probabilities: 4 steps per register set / 2 steps of (yb, wb)
   const int lab0_off = lab[0] * (kRow32 * 4), lab1_off = lab[1] * (kRow32 * 4), yw_off = (V + 1) * (kRow32 * 4);
@@ -1294,8 +1332,6 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
     constexpr bool STEADY = decltype(steady_tag)::value;
     load_half(n, std::integral_constant<int, 1>{});
     const bool want_next = n + 1 < nblk;
-    int next_filled = 0;
-    if (want_next) next_filled = peek(&myfilled[(n + 1) % kRingBlks]);
     if (n > 0 && has_up) {
       { PROF_SPIN_BEGIN HALO_WAIT(__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(prog + 4 * up)) >= n); PROF_SPIN_END(prof_nb) }
       const h_f4 v = *(lds_f4*)(L0 + hl.bnd + (((DIR * kHfMaxW + up) * kHaloSlots + ((n - 1) & (kHaloSlots - 1))) * kHfHalo + (lane & (kHfHalo - 1))) * 16);
@@ -1310,7 +1346,7 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
       const h_f2 E = {e0raw[tt >> 2][tt & 3], e1raw[tt >> 2][tt & 3]};
       if (tt == 4) {
         xw = *(volatile lds_int*)(exw + 4 * (n & (kHaloSlots - 1)));
-        if (want_next && __builtin_amdgcn_readfirstlane(next_filled) != n + 2) { PROF_SPIN_BEGIN spin_until(&myfilled[(n + 1) % kRingBlks], n + 2); PROF_SPIN_END(prof_fill) }
+        if (want_next) need_blocks(n + 2);
         load_half(n + 1, std::integral_constant<int, 0>{});
       }
       if (STEADY || t < T) {
@@ -1363,22 +1399,22 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
           const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
           if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
             // block floating point: each group of F2PPL pairs stores its cells scaled by its own exponent
-            const float c0 = Bc.x * yb_prev, c1 = Lc.x * inv_rr, c2 = Bc.y * yb_prev, c3 = Lc.y * inv_rr;   // the true cells
+            const h_f2 cb = Bc * yb_prev, cl = Lc * inv_rr;          // the true cells: blank with its emission, label without the tilt
+            const float c0 = cb.x, c1 = cl.x, c2 = cb.y, c3 = cl.y;
             const int ma = max(__float_as_int(c0), __float_as_int(c1)), mb = max(__float_as_int(c2), __float_as_int(c3));
             int m0 = ma, m1 = mb;                                           // exponent source of pair p0 / p0 + 1
             if (F2PPL >= 2) { m0 = max(ma, mb); m1 = m0; }
             if (F2PPL >= 4) { m0 = max(m0, dpp_i<0xB1>(0, m0)); m1 = m0; }  // quad_perm [1,0,3,2]: the lane pair
             const int own0 = m0 > 0 ? ((m0 >> 23) & 0xff) - 127 : -30000, own1 = m1 > 0 ? ((m1 >> 23) & 0xff) - 127 : -30000;
-            const int st0 = m0 > 0 ? own0 - kHfBias : -30000, st1 = m1 > 0 ? own1 - kHfBias : -30000;     // relative to the frame
+            const int st0 = m0 > 0 ? own0 - bias : -30000, st1 = m1 > 0 ? own1 - bias : -30000;     // relative to the frame
             if (owned) {
-              h_f4 o;
-              o.x = m0 > 0 ? ldexpf(c0, -own0) : 0.f; o.y = m0 > 0 ? ldexpf(c1, -own0) : 0.f;
-              o.z = m1 > 0 ? ldexpf(c2, -own1) : 0.f; o.w = m1 > 0 ? ldexpf(c3, -own1) : 0.f;
-              *reinterpret_cast<h_f4*>(ck + (size_t)(kk / kSeg) * p.CELLS + 2 * p0) = o;
-              short* cke = p.ckE + (((size_t)b * p.NS + kk / kSeg) * 2 + DIR) * 64;
-              if (F2PPL == 1) { cke[p0] = (short)st0; cke[p0 + 1] = (short)st1; }
-              else if ((p0 & (F2PPL - 1)) == 0) cke[p0 / F2PPL] = (short)st0;
+              h_f4 o;                                                 // (cells of an all-zero group stay zero whatever the exponent)
+              o.x = ldexpf(c0, -own0); o.y = ldexpf(c1, -own0); o.z = ldexpf(c2, -own1); o.w = ldexpf(c3, -own1);
+              *reinterpret_cast<h_f4*>(ckp) = o;
+              if (F2PPL == 1) { ckep[0] = (short)st0; ckep[1] = (short)st1; }
+              else if ((p0 & (F2PPL - 1)) == 0) ckep[0] = (short)st0;
             }
+            ckp += ck_step; ckep += DIR == 0 ? 128 : -128;
           }
         }
       }
@@ -1393,7 +1429,7 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
     *(volatile lds_int*)(prog + 4 * w) = n + 1;
   };
   {
-    spin_until(&myfilled[0], 1);
+    need_blocks(1);
     load_half(0, std::integral_constant<int, 0>{});
     const int steady_end = DIR == 0 ? T / kBlk : nblk;         // blocks [1, steady_end) are steady
     run_block(0, std::false_type{});
@@ -1423,16 +1459,16 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
         double zs = 0.0;
         for (int k = 0; k < W; k++) zs += *(volatile lds_f64*)(L0 + hl.zacc + 8 * k);
         const double rr = (double)r_tilt;
-        const double lz = log(zs) + (double)(e_total - kHfBias) * 0.693147180559945309417 - (double)(L - 1) * log(rr);
+        const double lz = log(zs) + (double)(e_total - bias) * 0.693147180559945309417 - (double)(L - 1) * log(rr);
         p.logz[2 * b] = lz;
-        p.zt2[b] = log2(zs) + (double)(e_total - kHfBias);
+        p.zt2[b] = log2(zs) + (double)(e_total - bias);
         p.losses[b] = (float)(-lz);
         if (!(zs > 0.0) || !(zs < __builtin_huge_val())) atomicOr(&p.flags[b], 4);     // infeasible or out of range
       }
     }
   } else if (w == 0 && lane == 0) {
     const double z = (cond ? (double)Bc.x * (double)yb_prev : 0.0) + (double)Lc.x;     // sum_j alpha_0[j]*beta_0[j]
-    p.logz[2 * b + 1] = log(z) + (double)(e_total - kHfBias) * 0.693147180559945309417 - (double)(L - 1) * log((double)r_tilt);
+    p.logz[2 * b + 1] = log(z) + (double)(e_total - bias) * 0.693147180559945309417 - (double)(L - 1) * log((double)r_tilt);
   }
 }
 
@@ -1472,9 +1508,9 @@ __global__ __launch_bounds__(768) void ctc_fast_chain_hf_kernel(FastParams p) {
   constexpr int MAXW = (64 * PPL + kHfOwn - 1) / kHfOwn;          // waves that can hold a cell at this row width
   const int W = min(S / kHfOwn + 1, MAXW);                        // waves that hold a cell: pairs 0..S (pair S = the last blank)
   if (tid == 0) p.flags[b] = 0;
-  if (tid < 2 * kRingBlks) reinterpret_cast<int*>(smem + hl.filled)[tid] = 0;
+  if (tid < 2 * kRingBlks) reinterpret_cast<int*>(smem + hl.filled)[tid] = (tid & (kRingBlks - 1)) == 1 ? 1 : 0;
   if (tid < 16) reinterpret_cast<int*>(smem + hl.prog)[tid] = (tid & 7) < W ? 0 : kHaloIdle;
-  if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHaloLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;
+  if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHfLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;
   if (tid < 8) reinterpret_cast<double*>(smem + hl.zacc)[tid] = 0.0;
   for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
     reinterpret_cast<float*>(smem + hl.ring + (i / kBlk) * hl.blk_bytes)[V * kRow32 + (i % kBlk)] = 0.f;
@@ -1488,10 +1524,10 @@ __global__ __launch_bounds__(768) void ctc_fast_chain_hf_kernel(FastParams p) {
     if (w >= W) { if (d == 0) hf_idle_wave<0, PPL>(p, b, lane, w); else hf_idle_wave<1, PPL>(p, b, lane, w); }
     else if (d == 0) hf_chain_wave<0, PPL>(p, b, T, S, smem, hl, lane, w, W);
     else hf_chain_wave<1, PPL>(p, b, T, S, smem, hl, lane, w, W);
-  } else if (wave == 6) halo_frame_wave<0, true, kHfBias>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W);
+  } else if (wave == 6) halo_frame_wave<0, true, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W, hf_bias(fast_tilt(S, T)));
   else if (wave == 7) {
     cellinfo_wave<PPL>(p, b, T, S, reinterpret_cast<int*>(smem + hl.sortcnt), lane);
-    halo_frame_wave<1, true, kHfBias>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W);
+    halo_frame_wave<1, true, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W, hf_bias(fast_tilt(S, T)));
   } else {
     const int d = (wave - 8) & 1;                        // waves 8,10 -> alpha rows, 9,11 -> beta rows
     const int first = (wave - 8) >> 1;                   // the two producers of a direction take alternate blocks
@@ -1520,9 +1556,9 @@ constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before 
 #endif
 constexpr float kZTol = E2E_ZTOL;   // |log2| tolerance of the rows' self-check (2.8e-6 relative; rounding alone stays below 1e-6)
 #ifndef E2E_ZTOL_F32
-#define E2E_ZTOL_F32 3e-5f
+#define E2E_ZTOL_F32 1e-5f
 #endif
-constexpr float kZTolF32 = E2E_ZTOL_F32;   // the same with f32 chains (ctc_fast_chain_hf_kernel), whose own rounding reaches ~5e-6
+constexpr float kZTolF32 = E2E_ZTOL_F32;   // the same with f32 chains (ctc_fast_chain_hf_kernel), whose own rounding reaches 3e-6
 constexpr int kYs = kSeg + 4;      // row stride (floats) of the transposed probability tile: 80 B spreads the
                                    // 16-byte gathers of different labels over the LDS bank row
 
@@ -2030,14 +2066,16 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   // four waves pays it four times in parallel -- same wall time.  The multi-wave pipeline of the previous design (edge
   // values through LDS every step) took 120-152 us.  Default: single wave.
   static const bool single_wave = getenv("E2E_F1_MULTI") == nullptr;
-  static const bool f32_chains = getenv("E2E_F1_F32") != nullptr;
-  if (f32_chains) {
+  // f32 chains: where the caller allows them (e2e_ctc_loss_opts.chains) and they are faster, i.e. at the widest rows
+  // (120 / 118 / 100 us per step against 120 / 120 / 95 us at S <= 127 / 127 / 63); E2E_F1_F32=1 forces them everywhere (tests)
+  static const bool force_f32_chains = getenv("E2E_F1_F32") != nullptr;
+  if (force_f32_chains || (p.chains == E2E_CHAINS_F32 && PPL == 4)) {
     const HfLds hl(p.V);
     E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
     hipLaunchKernelGGL(ctc_fast_chain_hf_kernel<PPL>, dim3(p.B), dim3(768), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
-    FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB; q.ztol = kZTolF32;
+    FastParams q = p; q.ztol = kZTolF32;                          // (trkA / trkB: written by the frame waves)
     hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
     return E2E_OK;
@@ -2135,6 +2173,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.ctl = reinterpret_cast<int*>(ws + l.ctl);
   p.gscale = (float)a.grad_scale;
   p.ztol = kZTol;
+  p.chains = a.chains;
   p.NS = l.NS; p.NB = l.NB; p.CELLS = l.CELLS;
   int rc;
   switch (ppl_for(a.Smax)) {

@@ -69,6 +69,8 @@ PYBIND11_MODULE(_C, m) {
   m.attr("REDUCE_NONE") = E2E_REDUCE_NONE;
   m.attr("REDUCE_SUM") = E2E_REDUCE_SUM;
   m.attr("REDUCE_MEAN") = E2E_REDUCE_MEAN;
+  m.attr("CHAINS_F64") = E2E_CHAINS_F64;
+  m.attr("CHAINS_F32") = E2E_CHAINS_F32;
 
   m.def("abi_version", [] { return e2e_ctc_abi_version(); });
   m.def("last_error", [] { return std::string(e2e_last_error()); });
@@ -77,13 +79,13 @@ PYBIND11_MODULE(_C, m) {
     return e2e_ctc_loss_workspace_bytes(B, T, V, Smax, dtype, algo);
   });
 
-  // (grad_scale / reduced / reduction: e2e_ctc_loss_opts; the defaults are the plain call)
+  // (grad_scale / reduced / reduction / chains: e2e_ctc_loss_opts; the defaults are the plain call)
   m.def("ctc_loss_fwd_bwd",
         [](uintptr_t x, int dtype, bool input_is_logprobs, int64_t sB, int64_t sT, int64_t sV, uintptr_t targets,
            int64_t tgt_stride, uintptr_t x_len, uintptr_t t_len, int B, int T, int V, int Smax, int blank,
            uintptr_t losses, uintptr_t grads, uintptr_t workspace, size_t workspace_bytes, int algo, uintptr_t stream,
-           double grad_scale, uintptr_t reduced, int reduction) {
-          e2e_ctc_loss_opts o{grad_scale, ptr<void>(reduced), reduction};
+           double grad_scale, uintptr_t reduced, int reduction, int chains) {
+          e2e_ctc_loss_opts o{grad_scale, ptr<void>(reduced), reduction, chains};
           check(e2e_ctc_loss_fwd_bwd_opt(ptr<const void>(x), dtype, input_is_logprobs ? 1 : 0, sB, sT, sV,
                                          ptr<const int64_t>(targets), tgt_stride, ptr<const int64_t>(x_len),
                                          ptr<const int64_t>(t_len), B, T, V, Smax, blank, ptr<void>(losses),
@@ -94,7 +96,7 @@ PYBIND11_MODULE(_C, m) {
         py::arg("targets"), py::arg("tgt_stride"), py::arg("x_len"), py::arg("t_len"), py::arg("B"), py::arg("T"),
         py::arg("V"), py::arg("Smax"), py::arg("blank"), py::arg("losses"), py::arg("grads"), py::arg("workspace"),
         py::arg("workspace_bytes"), py::arg("algo"), py::arg("stream"), py::arg("grad_scale") = 1.0,
-        py::arg("reduced") = 0, py::arg("reduction") = E2E_REDUCE_NONE);
+        py::arg("reduced") = 0, py::arg("reduction") = E2E_REDUCE_NONE, py::arg("chains") = E2E_CHAINS_F64);
 
   m.def("ctc_scale_grads",
         [](uintptr_t grads, int dtype, uintptr_t scale, int B, int64_t row_elems, uintptr_t stream) {

@@ -9,9 +9,10 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_AUTO, keep=None, opts=None):
+def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_AUTO, keep=None, opts=None, chains=None):
     """x: torch tensor (B,T,V) on any device with any strides (moved to the GPU keeping its layout).
-    opts = (grad_scale, reduction): call e2e_ctc_loss_fwd_bwd_opt and return (losses, grads, reduced)."""
+    opts = (grad_scale, reduction): call e2e_ctc_loss_fwd_bwd_opt and return (losses, grads, reduced).
+    chains = _lib.CHAINS_F32: the same entry point with e2e_ctc_loss_opts.chains set (returns (losses, grads))."""
     L = _lib.load()
     d = dev()
     if not x.is_cuda:
@@ -36,8 +37,12 @@ def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_
             targets.data_ptr(), targets.stride(0), xl.data_ptr(), tl.data_ptr(),
             B, T, V, Smax, blank, losses.data_ptr(), grads.data_ptr(),
             ws.data_ptr(), ws.numel(), algo, _lib.stream_ptr(d))
-    if opts is None:
+    if opts is None and chains is None:
         _lib.check(L.e2e_ctc_loss_fwd_bwd(*args))
+    elif opts is None:
+        import ctypes
+        o = _lib.LossOpts(1.0, None, _lib.REDUCE_NONE, int(chains))
+        _lib.check(L.e2e_ctc_loss_fwd_bwd_opt(*args, ctypes.byref(o)))
     else:
         reduced = torch.full((1,), 7.0, dtype=x.dtype, device=d)
         o = _lib.LossOpts(float(opts[0]), reduced.data_ptr() if opts[1] else None, int(opts[1]))

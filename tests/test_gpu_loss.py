@@ -97,6 +97,27 @@ def test_c2_shape_sample_against_oracle(algo):
     U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
 
 
+def test_c2_shape_sample_with_f32_chains_against_oracle():
+    # the same with e2e_ctc_loss_opts.chains = E2E_CHAINS_F32: losses as tight as ever, gradient elements within the
+    # 2e-5 absolute that include/e2e_ctc.h states for the option
+    g = torch.Generator().manual_seed(0)
+    B, T, V, S = 6, 1000, 29, 200
+    x = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tl = torch.randint(S // 2, S + 1, (B,), generator=g)
+    tl[0] = S
+    xl = torch.tensor([T, T, T - 37, T, 640, T])
+    lp = torch.log_softmax(x.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    losses, grads = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_FAST, chains=_lib.CHAINS_F32)
+    assert np.isfinite(losses).all()
+    for b in range(B):
+        g_o[b, xl[b]:] = 0.0
+    U.assert_same(losses, l_o, 2e-6, 1e-6, "losses")
+    U.assert_same(grads, g_o, F32_RTOL, 2e-5, "grads")
+    assert np.abs(grads - g_o).max() > 0        # (not the f64 chains' result by accident)
+
+
 @pytest.mark.parametrize("algo", ALGOS, ids=ALGO_IDS.get)
 def test_wide_alphabet_sample_against_oracle(algo):
     # C5-like: V=8000, S<=64, T=256 on two utterances (per-utterance alphabet compaction around the lattice kernels)

@@ -198,3 +198,19 @@ def test_decoder_rejects_an_alphabet_that_does_not_match_the_labels():
     dec = CTCDecoder(beam_width=4, labels=["_", "a", "b"])
     with pytest.raises(ValueError, match="labels"):
         dec.decode(torch.randn(1, 5, 4).cuda())
+
+
+def test_engine_with_f32_chains_keeps_the_interface_and_the_stated_tolerance():
+    """CTCLossEngine(blank, f32_chains=True): same call, same result types; long targets go through the packed-f32 chains."""
+    from end2end_amd.engines import CTCLossEngine
+    g = torch.Generator().manual_seed(12)
+    B, T, V, S = 3, 400, 29, 180
+    lp = torch.log_softmax(torch.randn(B, T, V, generator=g), -1)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl, tl = torch.tensor([T, T - 9, T]), torch.tensor([S, 150, 131])
+    l0, g0 = CTCLossEngine(0).compute(lp, tg, xl, tl)
+    l1, g1 = CTCLossEngine(0, f32_chains=True).compute(lp, tg, xl, tl)
+    assert l1.device == lp.device and l1.dtype == lp.dtype and g1.shape == lp.shape
+    U.assert_same(l1.numpy(), l0.numpy(), 2e-6, 1e-6, "losses")
+    U.assert_same(g1.numpy(), g0.numpy(), 1e-4, 2e-5, "grads")
+    assert not torch.equal(g0, g1)          # (a different kernel did run)
