@@ -436,6 +436,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     for (int k = 0; k < NV; k++) out[k] = (row_live && col_live[k]) ? xr[col_off[k]] : ninf;
   };
   float xv[NV];
+  int consumed = 0;                 // blocks the ring's readers are known to have finished with (HALO)
   float lpmin = 0.f;                // smallest FINITE log-probability this wave has seen (alpha-side producers)
   load_block(first, xv);
   for (int n = first; n < nblk; n += stride) {       // this wave fills every `stride`-th block
@@ -444,8 +445,14 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     const int slot = n % kRingBlks;
     if (n >= kRingBlks) {
       PROF_SPIN_BEGIN
-      if (HALO) { while (__builtin_amdgcn_readfirstlane(lds_min8(prog)) < n - kRingBlks + 1) __builtin_amdgcn_s_sleep(1); asm volatile("" ::: "memory"); }
-      else spin_until_ge(took, n - kRingBlks + 1);
+      if (HALO) {
+        // (the readers' progress is looked at again only when the last look does not cover this block)
+        while (consumed < n - kRingBlks + 1) {
+          consumed = __builtin_amdgcn_readfirstlane(lds_min8(prog));
+          if (consumed < n - kRingBlks + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+      } else spin_until_ge(took, n - kRingBlks + 1);
       PROF_SPIN_END(prof_spin)
     }
     double* blk = reinterpret_cast<double*>(myring_bytes + (size_t)slot * blk_bytes);
@@ -495,7 +502,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     }
     // every lane stores the same word: no divergence, one LDS write.  (MODE 2: one word per producer, "my blocks up to n
     // are there" -- the readers keep the minimum of the two in a scalar and look again only when they catch up.)
-    if (MODE == 2) publish(&myfilled[first], n + 2);
+    if (MODE == 2) publish(&myfilled[first], n + stride);
     else publish(&myfilled[slot], n + 1);
 #pragma unroll
     for (int k = 0; k < NV; k++) xv[k] = xn[k];
@@ -1076,6 +1083,7 @@ template <int DIR, bool F32 = false, int LAG = kHaloLag, bool TRACK = false>
 __device__ __forceinline__ void halo_frame_wave(const FastParams& p, int b, int T, lds_u8* L0, int prog_off, int exw_off, int mxl_off,
                                                 int maxw, int lane, int W, int bias = 0) {
   static_assert(LAG == 1 || LAG == 2, "the exponents in flight are kept in two variables");
+  __builtin_amdgcn_s_setprio(3);                     // (little work, but the chain waves wait for its word every block)
   const int nblk = (T + kBlk - 1) / kBlk;
   const int nres = DIR == 0 ? T / kBlk : nblk;       // blocks whose step 7 is live (alpha's last block may be short)
   const int M = (T - 1) >> 3;
@@ -1194,8 +1202,10 @@ __global__ __launch_bounds__(1024) void ctc_fast_chain_halo_kernel(FastParams p)
 // pairs (B0, L0), (B1, L1) as the packed registers B = (B0, B1), L = (L0, L1), and a step is
 //   alpha: PL = (L1 of the lane below, L0);  B' = B*yb + PL;  L' = (L + wb*B + SK*PL) * E        1 DPP + 1 move + 4 packed
 //   beta:  G = wb*B + SK*L;  TK = (G1, G0 of the lane above);  L' = (L + TK) * E;  B' = B*yb + L  1 DPP + 1 move + 5 packed
-// for 120 owned pairs per wave (60 lanes + 4 halo lanes = 8 pairs, one of which goes stale per step): two waves per
-// direction cover S <= 239, three the rest.  The probability ring is f32 (label rows of 8 steps; the blank's row holds
+// for 112 owned pairs per wave (56 lanes + 8 halo lanes = 16 pairs, one of which goes stale per step, so that the edge
+// lanes are exchanged every 16 steps): two waves per direction cover S <= 223, three the rest.  The checkpoint rows leave
+// a chain wave as one LDS write of its true cells; the direction's frame wave, which has the time, finds the block
+// floating-point exponents, converts and stores them.  The probability ring is f32 (label rows of 8 steps; the blank's row holds
 // (probability, tilted probability) pairs, so that one packed operand carries both factors).
 // Numerics: the cells carry f32 rounding through the whole utterance (~1e-6 relative in the partition sum over 1 000
 // steps, measured); the loss is well inside its tolerance with that, and the gradient rows are normalised by their own
@@ -1205,10 +1215,11 @@ __global__ __launch_bounds__(1024) void ctc_fast_chain_halo_kernel(FastParams p)
 // posterior mass before it is redone, an absolute gradient error of that size on top of the chains' drift (worst
 // gradient element over four randomised sweeps: 8.4e-6 off; include/e2e_ctc.h states 2e-5 for the option).  The common frame lags 16 steps as above; f32 has 126 bits of range for it, and a row that sinks further is
 // caught by the self-check (the cells that matter were flushed).
-constexpr int kHfHalo = 4;                    // halo lanes = 8 pairs
-constexpr int kHfOwnLanes = 64 - kHfHalo;     // 60
-constexpr int kHfOwn = 2 * kHfOwnLanes;       // 120 pairs a wave owns
-constexpr int kHfMaxW = 3;                    // ceil(256 / 120)
+constexpr int kHfHalo = 8;                    // halo lanes = 16 pairs: the waves exchange edge lanes every SECOND block
+constexpr int kHfOwnLanes = 64 - kHfHalo;     // 56
+constexpr int kHfOwn = 2 * kHfOwnLanes;       // 112 pairs a wave owns
+constexpr int kHfMaxW = 3;                    // ceil(256 / 112)
+constexpr int kHfProducers = 3;               // probability-row waves per direction (with two the chains waited for the ring)
 constexpr int kHfLag = 2;                     // the frame follows the row's maximum two blocks late (one: the waves meet at every
                                               // block's end, 153 instead of 145 us per step at the headline shape)
 // The cells are kept 2^bias above that frame.  A row sinks 26-42 bits per block for uninformative emissions at V = 29..64
@@ -1225,13 +1236,14 @@ struct HfLds {
   // byte offsets from the start of the workgroup's LDS
   int ring;        // [2][kRingBlks] blocks of blk_bytes: (V+1) label rows of kRow32 floats (row V: zeros) + 16 floats (yb, wb) x 8 steps
   int blk_bytes;
-  int filled;      // [2][kRingBlks] ints; used: [dir][0..1] = 2 + the last block producer 0 / 1 of the direction has finished
+  int filled;      // [2][kRingBlks] ints; used: [dir][f] = kHfProducers + the last block producer f of the direction has finished
   int sortcnt;     // [130] ints (cellinfo_wave)
   int bnd;         // [2][kHfMaxW][kHaloSlots][kHfHalo] x 16 B: wave w's edge lanes (B0, L0, B1, L1) after block n
   int zacc;        // [8] doubles
   int prog;        // [2][8] ints
   int exw;         // [2][kHaloSlots] ints
   int mxl;         // [2][kHaloSlots][kHfMaxW][64] ints
+  int ckb;         // [2][2][kHfMaxW][64] x 16 B: a checkpoint row's true cells (B0, L0, B1, L1 per lane), double-buffered
   int total;
   __host__ __device__ explicit HfLds(int V) {
     ring = 0;
@@ -1243,7 +1255,8 @@ struct HfLds {
     prog = zacc + 64;
     exw = prog + 2 * 8 * 4;
     mxl = exw + 2 * kHaloSlots * 4;
-    total = mxl + 2 * kHaloSlots * kHfMaxW * 64 * 4;
+    ckb = mxl + 2 * kHaloSlots * kHfMaxW * 64 * 4;
+    total = ckb + 2 * 2 * kHfMaxW * 64 * 16;
   }
 };
 
@@ -1298,18 +1311,15 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
   const float kOne = ldexpf(1.f, bias);
   float yb_prev = 0.f, wb_prev = 0.f;
   int e_total = 0;
-  // checkpoint rows are visited in order (alpha: slots 1, 2, ...; beta: the last one first): running pointers
-  const int slot0 = DIR == 0 ? 1 : (T - 1) / kSeg;
-  float* ckp = (DIR == 0 ? p.ckA : p.ckQ) + ((size_t)b * p.NS + slot0) * p.CELLS + 2 * p0;
-  short* ckep = p.ckE + (((size_t)b * p.NS + slot0) * 2 + DIR) * 64 + (F2PPL == 1 ? p0 : p0 / F2PPL);
-  const int ck_step = DIR == 0 ? p.CELLS : -p.CELLS;
   int lead = 0;                                    // blocks of probabilities known to be in the ring: [0, lead)
   auto need_blocks = [&](int k) {                  // (the producers run several blocks ahead: one look every few blocks)
     if (lead < k) {
       PROF_SPIN_BEGIN
       for (;;) {
-        const int a0 = peek(&myfilled[0]), a1 = peek(&myfilled[1]);
-        lead = __builtin_amdgcn_readfirstlane(min(a0, a1));
+        int a = peek(&myfilled[0]);
+#pragma unroll
+        for (int f = 1; f < kHfProducers; f++) a = min(a, peek(&myfilled[f]));
+        lead = __builtin_amdgcn_readfirstlane(a);
         if (lead >= k) break;
         __builtin_amdgcn_s_sleep(1);
       }
@@ -1332,7 +1342,7 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
     constexpr bool STEADY = decltype(steady_tag)::value;
     load_half(n, std::integral_constant<int, 1>{});
     const bool want_next = n + 1 < nblk;
-    if (n > 0 && has_up) {
+    if (n > 0 && (n & 1) == 0 && has_up) {          // the halo lasts two blocks
       { PROF_SPIN_BEGIN HALO_WAIT(__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(prog + 4 * up)) >= n); PROF_SPIN_END(prof_nb) }
       const h_f4 v = *(lds_f4*)(L0 + hl.bnd + (((DIR * kHfMaxW + up) * kHaloSlots + ((n - 1) & (kHaloSlots - 1))) * kHfHalo + (lane & (kHfHalo - 1))) * 16);
       if (halo) { Bc.x = v.x; Lc.x = v.y; Bc.y = v.z; Lc.y = v.w; }
@@ -1398,28 +1408,15 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
           e_total += ex;
           const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
           if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
-            // block floating point: each group of F2PPL pairs stores its cells scaled by its own exponent
-            const h_f2 cb = Bc * yb_prev, cl = Lc * inv_rr;          // the true cells: blank with its emission, label without the tilt
-            const float c0 = cb.x, c1 = cl.x, c2 = cb.y, c3 = cl.y;
-            const int ma = max(__float_as_int(c0), __float_as_int(c1)), mb = max(__float_as_int(c2), __float_as_int(c3));
-            int m0 = ma, m1 = mb;                                           // exponent source of pair p0 / p0 + 1
-            if (F2PPL >= 2) { m0 = max(ma, mb); m1 = m0; }
-            if (F2PPL >= 4) { m0 = max(m0, dpp_i<0xB1>(0, m0)); m1 = m0; }  // quad_perm [1,0,3,2]: the lane pair
-            const int own0 = m0 > 0 ? ((m0 >> 23) & 0xff) - 127 : -30000, own1 = m1 > 0 ? ((m1 >> 23) & 0xff) - 127 : -30000;
-            const int st0 = m0 > 0 ? own0 - bias : -30000, st1 = m1 > 0 ? own1 - bias : -30000;     // relative to the frame
-            if (owned) {
-              h_f4 o;                                                 // (cells of an all-zero group stay zero whatever the exponent)
-              o.x = ldexpf(c0, -own0); o.y = ldexpf(c1, -own0); o.z = ldexpf(c2, -own1); o.w = ldexpf(c3, -own1);
-              *reinterpret_cast<h_f4*>(ckp) = o;
-              if (F2PPL == 1) { ckep[0] = (short)st0; ckep[1] = (short)st1; }
-              else if ((p0 & (F2PPL - 1)) == 0) ckep[0] = (short)st0;
-            }
-            ckp += ck_step; ckep += DIR == 0 ? 128 : -128;
+            // the true cells (blank with its emission, label without the tilt); the frame wave converts and stores them
+            const h_f2 cb = Bc * yb_prev, cl = Lc * inv_rr;
+            h_f4 o; o.x = cb.x; o.y = cl.x; o.z = cb.y; o.w = cl.y;
+            *(lds_f4*)(L0 + hl.ckb + ((((DIR * 2 + ((kk / kSeg) & 1)) * kHfMaxW + w) * 64 + lane) * 16)) = o;
           }
         }
       }
     }
-    if (has_down) {
+    if ((n & 1) && has_down) {
       const bool edge = DIR == 0 ? lane >= 64 - kHfHalo : lane < kHfHalo;
       if (edge) {
         h_f4 v; v.x = Bc.x; v.y = Lc.x; v.z = Bc.y; v.w = Lc.y;
@@ -1472,6 +1469,46 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
   }
 }
 
+// The checkpoint wave of a direction: the chain waves leave a checkpoint row's true cells in LDS; this wave finds the
+// exponent of every group of F2PPL pairs (the segment kernel's lanes), scales, and stores cells and exponents.  (First
+// given to the frame wave: that one is on the chains' critical path -- they wait for its word every block -- and the
+// extra work showed up as 20-35 cycles per step of waiting.)
+template <int DIR, int F2PPL>
+__device__ __forceinline__ void hf_ckpt_wave(const FastParams& p, int b, int T, lds_u8* L0, const HfLds hl, int lane, int W, int bias) {
+  const int nblk = (T + kBlk - 1) / kBlk;
+  const int nres = DIR == 0 ? T / kBlk : nblk;       // blocks whose step 7 is live (alpha's last block may be short)
+  const int M = (T - 1) >> 3;
+  lds_u8* prog = L0 + hl.prog + DIR * 32;
+  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
+  const int idx = DIR == 0 ? lane - kHfHalo : lane;
+  const bool own_lane = DIR == 0 ? lane >= kHfHalo : lane < kHfOwnLanes;
+  for (int n = 0; n < nres; n++) {
+    // the checkpoint row of this block, if it has one (alpha row 16k-1 / beta row 16k -> slot k)
+    const int kk = DIR == 0 ? 8 * (n + 1) : 8 * (M - n);
+    if (!((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T)) continue;
+    HALO_WAIT(__builtin_amdgcn_readfirstlane(lds_min8(prog)) >= n + 1);
+    const int slot = kk / kSeg;
+    for (int w = 0; w < W; w++) {
+      const h_f4 c = *(lds_f4*)(L0 + hl.ckb + ((((DIR * 2 + (slot & 1)) * kHfMaxW + w) * 64 + lane) * 16));
+      const int p0 = kHfOwn * w + 2 * idx;
+      const int ma = max(__float_as_int(c.x), __float_as_int(c.y)), mb = max(__float_as_int(c.z), __float_as_int(c.w));
+      int m0 = ma, m1 = mb;                                           // exponent source of pair p0 / p0 + 1
+      if (F2PPL >= 2) { m0 = max(ma, mb); m1 = m0; }
+      if (F2PPL >= 4) { m0 = max(m0, dpp_i<0xB1>(0, m0)); m1 = m0; }  // quad_perm [1,0,3,2]: the lane pair
+      const int own0 = ((m0 >> 23) & 0xff) - 127, own1 = ((m1 >> 23) & 0xff) - 127;
+      const int st0 = m0 > 0 ? own0 - bias : -30000, st1 = m1 > 0 ? own1 - bias : -30000;     // relative to the frame
+      if (own_lane && p0 < 64 * F2PPL) {
+        h_f4 o;                                                       // (cells of an all-zero group stay zero whatever the exponent)
+        o.x = ldexpf(c.x, -own0); o.y = ldexpf(c.y, -own0); o.z = ldexpf(c.z, -own1); o.w = ldexpf(c.w, -own1);
+        *reinterpret_cast<h_f4*>(ck + (size_t)slot * p.CELLS + 2 * p0) = o;
+        short* cke = p.ckE + (((size_t)b * p.NS + slot) * 2 + DIR) * 64;
+        if (F2PPL == 1) { cke[p0] = (short)st0; cke[p0 + 1] = (short)st1; }
+        else if ((p0 & (F2PPL - 1)) == 0) cke[p0 / F2PPL] = (short)st0;
+      }
+    }
+  }
+}
+
 // a wave that holds no cell of this utterance: the segment kernel still reads the full row width -- leave zeros
 template <int DIR, int F2PPL>
 __device__ __forceinline__ void hf_idle_wave(const FastParams& p, int b, int lane, int w) {
@@ -1488,10 +1525,10 @@ __device__ __forceinline__ void hf_idle_wave(const FastParams& p, int b, int lan
   }
 }
 
-// Waves: 0-3 = alpha0, beta0, alpha1, beta1 (SIMDs 0,2,1,3), 4,5 = alpha2, beta2, 6 = alpha's frame wave, 7 = lattice
-// description, then beta's frame wave, 8-11 = probability rows (8,10 alpha side, 9,11 beta side).
+// Waves: 0-3 = alpha0, beta0, alpha1, beta1 (SIMDs 0,2,1,3), 4,5 = alpha2, beta2, 6,7 = the frame waves, 8-13 = probability
+// rows (even: alpha side, odd: beta side), 14,15 = the checkpoint waves (15 writes the lattice description first).
 template <int PPL>
-__global__ __launch_bounds__(768) void ctc_fast_chain_hf_kernel(FastParams p) {
+__global__ __launch_bounds__(1024) void ctc_fast_chain_hf_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V;
@@ -1508,7 +1545,7 @@ __global__ __launch_bounds__(768) void ctc_fast_chain_hf_kernel(FastParams p) {
   constexpr int MAXW = (64 * PPL + kHfOwn - 1) / kHfOwn;          // waves that can hold a cell at this row width
   const int W = min(S / kHfOwn + 1, MAXW);                        // waves that hold a cell: pairs 0..S (pair S = the last blank)
   if (tid == 0) p.flags[b] = 0;
-  if (tid < 2 * kRingBlks) reinterpret_cast<int*>(smem + hl.filled)[tid] = (tid & (kRingBlks - 1)) == 1 ? 1 : 0;
+  if (tid < 2 * kRingBlks) reinterpret_cast<int*>(smem + hl.filled)[tid] = (tid & (kRingBlks - 1)) < kHfProducers ? (tid & (kRingBlks - 1)) : 0;
   if (tid < 16) reinterpret_cast<int*>(smem + hl.prog)[tid] = (tid & 7) < W ? 0 : kHaloIdle;
   if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHfLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;
   if (tid < 8) reinterpret_cast<double*>(smem + hl.zacc)[tid] = 0.0;
@@ -1525,22 +1562,24 @@ __global__ __launch_bounds__(768) void ctc_fast_chain_hf_kernel(FastParams p) {
     else if (d == 0) hf_chain_wave<0, PPL>(p, b, T, S, smem, hl, lane, w, W);
     else hf_chain_wave<1, PPL>(p, b, T, S, smem, hl, lane, w, W);
   } else if (wave == 6) halo_frame_wave<0, true, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W, hf_bias(fast_tilt(S, T)));
-  else if (wave == 7) {
+  else if (wave == 7) halo_frame_wave<1, true, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W, hf_bias(fast_tilt(S, T)));
+  else if (wave == 14) hf_ckpt_wave<0, PPL>(p, b, T, L0, hl, lane, W, hf_bias(fast_tilt(S, T)));
+  else if (wave == 15) {
     cellinfo_wave<PPL>(p, b, T, S, reinterpret_cast<int*>(smem + hl.sortcnt), lane);
-    halo_frame_wave<1, true, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W, hf_bias(fast_tilt(S, T)));
+    hf_ckpt_wave<1, PPL>(p, b, T, L0, hl, lane, W, hf_bias(fast_tilt(S, T)));
   } else {
-    const int d = (wave - 8) & 1;                        // waves 8,10 -> alpha rows, 9,11 -> beta rows
-    const int first = (wave - 8) >> 1;                   // the two producers of a direction take alternate blocks
+    const int d = (wave - 8) & 1;                        // waves 8,10,12 -> alpha rows, 9,11,13 -> beta rows
+    const int first = (wave - 8) >> 1;                   // the producers of a direction take every kHfProducers-th block
     lds_u8* prog = L0 + hl.prog + d * 32;
     const float r_tilt = fast_tilt(S, T);
     const double rr2 = (double)(r_tilt * r_tilt);        // (the chain waves' own expression, in f32)
     unsigned char* ring = smem + hl.ring + d * kRingBlks * hl.blk_bytes;
     volatile int* fl = reinterpret_cast<int*>(smem + hl.filled) + d * kRingBlks;
-    if (V <= 16) prep_wave<2, 2>(p, b, T, d, first, 2, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 32) prep_wave<4, 2>(p, b, T, d, first, 2, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 48) prep_wave<6, 2>(p, b, T, d, first, 2, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 64) prep_wave<8, 2>(p, b, T, d, first, 2, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else prep_wave<12, 2>(p, b, T, d, first, 2, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    if (V <= 16) prep_wave<2, 2>(p, b, T, d, first, kHfProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 32) prep_wave<4, 2>(p, b, T, d, first, kHfProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 48) prep_wave<6, 2>(p, b, T, d, first, kHfProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 64) prep_wave<8, 2>(p, b, T, d, first, kHfProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else prep_wave<12, 2>(p, b, T, d, first, kHfProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
   }
 }
 
@@ -2073,7 +2112,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
     const HfLds hl(p.V);
     E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_fast_chain_hf_kernel<PPL>, dim3(p.B), dim3(768), hl.total, stream, p);
+    hipLaunchKernelGGL(ctc_fast_chain_hf_kernel<PPL>, dim3(p.B), dim3(1024), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
     FastParams q = p; q.ztol = kZTolF32;                          // (trkA / trkB: written by the frame waves)
     hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
