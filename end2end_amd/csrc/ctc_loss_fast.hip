@@ -665,10 +665,12 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
 #pragma unroll
             for (int k = 0; k < NC; k++) m = max(m, __double2hiint(cell[k]));
             const int own = m > 0 ? ((m >> 20) & 0x7ff) - 1023 : -30000;
-            float* dst = ck + (size_t)(kk / kSeg) * p.CELLS + lane * NC;
+            if (lane * NC < L) {                   // (lanes past the lattice's 2S+1 cells: the segment kernel does not read them)
+              float* dst = ck + (size_t)(kk / kSeg) * p.CELLS + lane * NC;
 #pragma unroll
-            for (int k = 0; k < NC; k++) dst[k] = m > 0 ? (float)ldexp(cell[k], -own) : 0.f;
-            p.ckE[(((size_t)b * p.NS + kk / kSeg) * 2 + DIR) * 64 + lane] = (short)own;
+              for (int k = 0; k < NC; k++) dst[k] = m > 0 ? (float)ldexp(cell[k], -own) : 0.f;
+              p.ckE[(((size_t)b * p.NS + kk / kSeg) * 2 + DIR) * 64 + lane] = (short)own;
+            }
           }
         } else if (tt == 6) {
           int hi = 0;
@@ -1007,7 +1009,7 @@ __device__ __forceinline__ void halo_chain_wave(const FastParams& p, int b, int 
             if (F2PPL >= 2) m = max(m, dpp_i<0xB1>(0, m));              // quad_perm [1,0,3,2]
             if (F2PPL >= 4) m = max(m, dpp_i<0x4E>(0, m));              // quad_perm [2,3,0,1]
             const int own = m > 0 ? ((m >> 20) & 0x7ff) - 1023 : -30000;
-            if (owned) {
+            if (owned && (pair & ~(F2PPL - 1)) <= S) {            // (groups past the lattice are not read)
               float2 o;
               o.x = m > 0 ? (float)ldexp(cell0, -own) : 0.f;
               o.y = m > 0 ? (float)ldexp(cell1, -own) : 0.f;
@@ -1123,21 +1125,6 @@ __device__ __forceinline__ void halo_frame_wave(const FastParams& p, int b, int 
   }
 }
 
-// a wave that holds no cell of this utterance: the segment kernel still reads the full row width -- leave zeros
-template <int DIR, int F2PPL>
-__device__ __forceinline__ void halo_idle_wave(const FastParams& p, int b, int lane, int w) {
-  if (lane >= kHaloOwn) return;
-  const int pair = kHaloOwn * w + lane;
-  if (pair >= 64 * F2PPL) return;
-  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
-  short* cke = p.ckE + (size_t)b * p.NS * 2 * 64;
-  for (int k = 1; k < p.NS; k++) {
-    float2 z; z.x = 0.f; z.y = 0.f;
-    *reinterpret_cast<float2*>(ck + (size_t)k * p.CELLS + 2 * pair) = z;
-    if ((pair & (F2PPL - 1)) == 0) cke[((size_t)k * 2 + DIR) * 64 + pair / F2PPL] = (short)-30000;
-  }
-}
-
 template <int PPL>
 __global__ __launch_bounds__(1024) void ctc_fast_chain_halo_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1171,8 +1158,8 @@ __global__ __launch_bounds__(1024) void ctc_fast_chain_halo_kernel(FastParams p)
   if (wave < 8 || wave == 12 || wave == 13) {
     const int d = wave & 1, w = wave < 8 ? wave >> 1 : 4;
     if (w >= MAXW) return;
-    if (w >= W) { if (d == 0) halo_idle_wave<0, PPL>(p, b, lane, w); else halo_idle_wave<1, PPL>(p, b, lane, w); }
-    else if (d == 0) halo_chain_wave<0, PPL>(p, b, T, S, lds, L0, ring_bytes_dir, blk_bytes, hl, lane, w, W);
+    if (w >= W) return;              // (holds no cell of this utterance; the segment kernel does not read past the lattice)
+    if (d == 0) halo_chain_wave<0, PPL>(p, b, T, S, lds, L0, ring_bytes_dir, blk_bytes, hl, lane, w, W);
     else halo_chain_wave<1, PPL>(p, b, T, S, lds, L0, ring_bytes_dir, blk_bytes, hl, lane, w, W);
   } else if (wave == 14) {
     cellinfo_wave<PPL>(p, b, T, S, lds.sortcnt, lane);
@@ -1474,7 +1461,7 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
 // given to the frame wave: that one is on the chains' critical path -- they wait for its word every block -- and the
 // extra work showed up as 20-35 cycles per step of waiting.)
 template <int DIR, int F2PPL>
-__device__ __forceinline__ void hf_ckpt_wave(const FastParams& p, int b, int T, lds_u8* L0, const HfLds hl, int lane, int W, int bias) {
+__device__ __forceinline__ void hf_ckpt_wave(const FastParams& p, int b, int T, int S, lds_u8* L0, const HfLds hl, int lane, int W, int bias) {
   const int nblk = (T + kBlk - 1) / kBlk;
   const int nres = DIR == 0 ? T / kBlk : nblk;       // blocks whose step 7 is live (alpha's last block may be short)
   const int M = (T - 1) >> 3;
@@ -1497,7 +1484,7 @@ __device__ __forceinline__ void hf_ckpt_wave(const FastParams& p, int b, int T, 
       if (F2PPL >= 4) { m0 = max(m0, dpp_i<0xB1>(0, m0)); m1 = m0; }  // quad_perm [1,0,3,2]: the lane pair
       const int own0 = ((m0 >> 23) & 0xff) - 127, own1 = ((m1 >> 23) & 0xff) - 127;
       const int st0 = m0 > 0 ? own0 - bias : -30000, st1 = m1 > 0 ? own1 - bias : -30000;     // relative to the frame
-      if (own_lane && p0 < 64 * F2PPL) {
+      if (own_lane && p0 < 64 * F2PPL && (p0 & ~(F2PPL - 1)) <= S) {      // (groups past the lattice are not read)
         h_f4 o;                                                       // (cells of an all-zero group stay zero whatever the exponent)
         o.x = ldexpf(c.x, -own0); o.y = ldexpf(c.y, -own0); o.z = ldexpf(c.z, -own1); o.w = ldexpf(c.w, -own1);
         *reinterpret_cast<h_f4*>(ck + (size_t)slot * p.CELLS + 2 * p0) = o;
@@ -1506,22 +1493,6 @@ __device__ __forceinline__ void hf_ckpt_wave(const FastParams& p, int b, int T, 
         else if ((p0 & (F2PPL - 1)) == 0) cke[p0 / F2PPL] = (short)st0;
       }
     }
-  }
-}
-
-// a wave that holds no cell of this utterance: the segment kernel still reads the full row width -- leave zeros
-template <int DIR, int F2PPL>
-__device__ __forceinline__ void hf_idle_wave(const FastParams& p, int b, int lane, int w) {
-  if (lane >= kHfOwnLanes) return;
-  const int p0 = kHfOwn * w + 2 * lane;
-  if (p0 >= 64 * F2PPL) return;
-  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
-  short* cke = p.ckE + (size_t)b * p.NS * 2 * 64;
-  for (int k = 1; k < p.NS; k++) {
-    h_f4 z = {0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<h_f4*>(ck + (size_t)k * p.CELLS + 2 * p0) = z;
-    if (F2PPL == 1) { cke[((size_t)k * 2 + DIR) * 64 + p0] = (short)-30000; cke[((size_t)k * 2 + DIR) * 64 + p0 + 1] = (short)-30000; }
-    else if ((p0 & (F2PPL - 1)) == 0) cke[((size_t)k * 2 + DIR) * 64 + p0 / F2PPL] = (short)-30000;
   }
 }
 
@@ -1558,15 +1529,15 @@ __global__ __launch_bounds__(1024) void ctc_fast_chain_hf_kernel(FastParams p) {
   if (wave < 6) {
     const int d = wave & 1, w = wave >> 1;
     if (w >= MAXW) return;
-    if (w >= W) { if (d == 0) hf_idle_wave<0, PPL>(p, b, lane, w); else hf_idle_wave<1, PPL>(p, b, lane, w); }
-    else if (d == 0) hf_chain_wave<0, PPL>(p, b, T, S, smem, hl, lane, w, W);
+    if (w >= W) return;              // (holds no cell of this utterance; the segment kernel does not read past the lattice)
+    if (d == 0) hf_chain_wave<0, PPL>(p, b, T, S, smem, hl, lane, w, W);
     else hf_chain_wave<1, PPL>(p, b, T, S, smem, hl, lane, w, W);
   } else if (wave == 6) halo_frame_wave<0, true, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W, hf_bias(fast_tilt(S, T)));
   else if (wave == 7) halo_frame_wave<1, true, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W, hf_bias(fast_tilt(S, T)));
-  else if (wave == 14) hf_ckpt_wave<0, PPL>(p, b, T, L0, hl, lane, W, hf_bias(fast_tilt(S, T)));
+  else if (wave == 14) hf_ckpt_wave<0, PPL>(p, b, T, S, L0, hl, lane, W, hf_bias(fast_tilt(S, T)));
   else if (wave == 15) {
     cellinfo_wave<PPL>(p, b, T, S, reinterpret_cast<int*>(smem + hl.sortcnt), lane);
-    hf_ckpt_wave<1, PPL>(p, b, T, L0, hl, lane, W, hf_bias(fast_tilt(S, T)));
+    hf_ckpt_wave<1, PPL>(p, b, T, S, L0, hl, lane, W, hf_bias(fast_tilt(S, T)));
   } else {
     const int d = (wave - 8) & 1;                        // waves 8,10,12 -> alpha rows, 9,11,13 -> beta rows
     const int first = (wave - 8) >> 1;                   // the producers of a direction take every kHfProducers-th block
@@ -1729,8 +1700,9 @@ struct SegIn {
   int eA7, eA15, eB0, eB8;          // rescale exponents inside the segment
   int EA0, EB16;                    // what the chains had removed in total: alpha before step t0, beta down to step t0+16
   float zfrac; int zint;            // the chains' log2 of the tilted partition sum (zt2), split: zint + zfrac
-  __device__ void load(const FastParams& p, int b, int seg, int lane) {
+  __device__ void load(const FastParams& p, int b, int seg, int S, int lane) {
     const int t0 = seg * kSeg;
+    const bool in_lattice = lane * 2 * PPL <= 2 * S;      // (the chains store no cells past the lattice's 2S+1)
     const int* cA = p.cumA + (size_t)b * p.NB + (t0 >> 3);
     const int* cB = p.cumB + (size_t)b * p.NB + (t0 >> 3);
     const int* tA = p.trkA + (size_t)b * p.NB + (t0 >> 3);
@@ -1745,19 +1717,25 @@ struct SegIn {
 #pragma unroll
     for (int k = 0; k < 2 * PPL; k++) a[k] = 0.f;
     if (seg > 0) {
-      const float* src = p.ckA + ((size_t)b * p.NS + seg) * p.CELLS + lane * 2 * PPL;
+      ownA = -30000;
+      if (in_lattice) {
+        const float* src = p.ckA + ((size_t)b * p.NS + seg) * p.CELLS + lane * 2 * PPL;
 #pragma unroll
-      for (int k = 0; k < 2 * PPL; k++) a[k] = src[k];
-      ownA = p.ckE[(((size_t)b * p.NS + seg) * 2 + 0) * 64 + lane];
+        for (int k = 0; k < 2 * PPL; k++) a[k] = src[k];
+        ownA = p.ckE[(((size_t)b * p.NS + seg) * 2 + 0) * 64 + lane];
+      }
     }
     ownB = 0;
 #pragma unroll
     for (int k = 0; k < 2 * PPL; k++) q[k] = 0.f;
     if (seg + 1 < p.NS) {            // (row seg+1 exists; whether it is meaningful depends on the utterance's length)
-      const float* src = p.ckQ + ((size_t)b * p.NS + seg + 1) * p.CELLS + lane * 2 * PPL;
+      ownB = -30000;
+      if (in_lattice) {
+        const float* src = p.ckQ + ((size_t)b * p.NS + seg + 1) * p.CELLS + lane * 2 * PPL;
 #pragma unroll
-      for (int k = 0; k < 2 * PPL; k++) q[k] = src[k];
-      ownB = p.ckE[(((size_t)b * p.NS + seg + 1) * 2 + 1) * 64 + lane];
+        for (int k = 0; k < 2 * PPL; k++) q[k] = src[k];
+        ownB = p.ckE[(((size_t)b * p.NS + seg + 1) * 2 + 1) * 64 + lane];
+      }
     }
   }
 };
@@ -2004,7 +1982,7 @@ __device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char*
   }
   // (c) alpha checkpoint and the rescale exponents
   SegIn<PPL> in;
-  in.load(p, b, seg, lane);
+  in.load(p, b, seg, (int)Sq, lane);       // (Sq was requested first and has had the other requests' time to arrive)
 
   if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
   const int T = (int)Tq, S = (int)Sq;
