@@ -357,14 +357,12 @@ struct LaneCells {
 // F1 device code
 // ============================================================================================
 // LDS of F1.  Per direction a ring of kRingBlks blocks; a block holds the probabilities of its 8 steps TRANSPOSED:
-// [label v][step] doubles, plus an all-zero row V for lattice cells past the utterance's labels and a row V+1 that holds
-// the blank's probability times the squared tilt (what a label cell takes from the blank below it: one multiplication
-// per step and wave less in the halo chains).
+// [label v][step] doubles, plus an all-zero row V for lattice cells past the utterance's labels.
 // What costs on this machine is the number of LDS instructions (a wave pays >= 12 cycles for each, whatever its
 // width), so the per-lane gather is arranged to pull 4 consecutive time steps of the lane's label per instruction:
 // 2 reads per label cell and block instead of 8, and the producers need no gather at all.
 struct F1Lds {
-  double* ring;      // [2][kRingBlks][V+2][kRow]  (f64: saves the chains' conversions, 2.5 % of the step at B = 256.  It
+  double* ring;      // [2][kRingBlks][V+1][kRow]  (f64: saves the chains' conversions, 2.5 % of the step at B = 256.  It
                      //  costs them 30 VGPRs, though: at 146 a second workgroup does not fit on the CU, which an f32 ring
                      //  (114) allows -- measured +7 % at B = 1024 with the second workgroup's roles rotated onto SIMDs 1/3)
   int* filled;       // [2][kRingBlks]   probability block n of a direction is complete (== n+1)
@@ -373,13 +371,13 @@ struct F1Lds {
   int blk_elems;
   static constexpr int kSyncInts = 2 * kRingBlks + 2;
   __device__ F1Lds(unsigned char* smem, int V) {
-    blk_elems = (V + 2) * kRow;
+    blk_elems = (V + 1) * kRow;
     ring = reinterpret_cast<double*>(smem);
     filled = reinterpret_cast<int*>(ring + 2 * kRingBlks * blk_elems);
     took = filled + 2 * kRingBlks;
     sortcnt = took + 2;
   }
-  __host__ __device__ static size_t bytes(int V) { return sizeof(double) * 2 * kRingBlks * (V + 2) * kRow + sizeof(int) * (kSyncInts + 130); }
+  __host__ __device__ static size_t bytes(int V) { return sizeof(double) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * (kSyncInts + 130); }
 };
 
 // Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
@@ -406,9 +404,9 @@ __device__ __forceinline__ float exp_le0(float x) {
 // (Four steps per pass with 16 lanes each was the first form: the reductions, the reciprocal and the address
 // arithmetic are paid per pass, and at V = 29 that was ~300 VALU instructions per block against ~110 here.  The
 // producers share their SIMDs with the chain waves, so their instruction count is the chains' speed too.)
-// MODE 0: f64 ring read by one chain wave (`took`); 1: f64 ring read by the waves of ctc_fast_chain_halo_kernel, whose
-// progress words replace `took`, plus the tilted blank row; 2: f32 ring of ctc_fast_chain_hf_kernel -- label rows of
-// kRow32 floats and one row of (blank probability, tilted blank probability) pairs.
+// MODE 0: f64 ring read by one chain wave (`took`); 2: f32 ring of ctc_fast_chain_hf_kernel -- label rows of kRow32
+// floats and one row of (blank probability, tilted blank probability) pairs, read by several waves whose progress words
+// replace `took`.
 template <int NV, int MODE = 0>
 __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int dir, int first, int stride,
                                           unsigned char* myring_bytes, int blk_bytes, volatile int* myfilled, volatile int* took,
@@ -495,7 +493,6 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
           }
         } else {
           blk[(l8 + 8 * k) * kRow + tt] = row_live ? (double)y[k] : 0.0;   // transposed: [label][step]
-          if (MODE == 1 && l8 + 8 * k == p.blank) blk[(V + 1) * kRow + tt] = row_live ? rr2 * (double)y[k] : 0.0;
         }
         if (dir == 0 && row_live) yrow[l8 + 8 * k] = y[k];
       }
@@ -816,56 +813,28 @@ __global__ __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
 }
 
 // ============================================================================================
-// F1, halo form: each chain runs on up to FIVE waves that exchange cells once per 8-step block
+// F1, halo form: each chain runs on several waves that exchange cells once per 16 steps (packed f32: the caller's option)
 // ============================================================================================
-// A chain's speed is its instruction count per step (a lone wave issues one instruction per ~4.5 cycles), and one wave
-// that carries 8 cells per lane needs ~47 of them.  Here a wave carries ONE label pair per lane.  Cell j of row t depends
-// on cells j, j-1, j-2 of row t-1 only: mass moves by at most one label pair per step.  So a wave that OWNS 56 pairs and
-// also carries the 8 pairs next to them on the upstream side (the halo: lanes 0..7 for alpha, 56..63 for beta) can run
-// a whole block of 8 steps without hearing from its neighbour -- each step one more halo lane goes stale, and after the
-// eighth exactly the owned lanes are still right.  Then the halo is refilled from the neighbour's published edge pairs.
-// Nothing is exchanged per step; 8/64 of the arithmetic is redundant.
-//   * hand-over: wave w publishes its 8 edge pairs and `prog[w] = n+1` at the end of block n; its downstream neighbour
-//     waits for that before block n+1.  The same word releases the producers' ring slot.
-//   * the power-of-two rescale stays COMMON to the whole row (one frame per direction: edge pairs need no conversion, and
-//     the segment kernel sees the same cumA / cumB / zt2 as with the single-wave chains).  At the end of block n every
-//     lane leaves the high word of its larger cell in LDS (two instructions); a FRAME WAVE per direction reduces the words
-//     of block n once all chain waves have passed it and publishes the exponent to remove at the end of block n+2:
-//     the absolute exponent of the row's maximum at block n less what has been removed since (absolute: a delayed
-//     RELATIVE correction oscillates).  A chain wave reads one tagged word per block.  Two blocks of slack keep the
-//     waves from running in lock-step; f64 cells have the range for 16 steps of lag.
-//   * multiplying by powers of two is exact: checkpoints and the cum exponents differ from the single-wave form's only
-//     in where the frame sits.
+// Cell j of row t depends on cells j, j-1, j-2 of row t-1 only: mass moves by at most one label pair per step.  So a
+// wave that OWNS a range of pairs and also carries the h pairs next to them on the upstream side (the halo: the first
+// lanes for alpha, the last for beta) can run h steps without hearing from its neighbour -- each step one more halo pair
+// goes stale, and after the h-th exactly the owned lanes are still right.  Then the halo is refilled from the
+// neighbour's published edge lanes.  Nothing is exchanged per step; h/128 of the arithmetic is redundant.
+//   * hand-over: wave w publishes its edge lanes and `prog[w]` at the end of a block; its downstream neighbour waits for
+//     that before it needs them.  The same word releases the producers' ring slot.
+//   * the power-of-two rescale stays COMMON to the whole row (one frame per direction: edge lanes need no conversion, and
+//     the segment kernel sees cumA / cumB / zt2 as with the single-wave chains).  At the end of block n every lane leaves
+//     the high word of its largest cell in LDS; a FRAME WAVE per direction reduces the words of block n once all chain
+//     waves have passed it and publishes the exponent to remove at the end of block n+2: the absolute exponent of the
+//     row's maximum at block n less what has been removed since (absolute: a delayed RELATIVE correction oscillates).
+//     A chain wave reads one tagged word per block.  Two blocks of slack keep the waves from running in lock-step.
 //   * beta hands ONE value down per step, like alpha hands one up: a lane prepares what the label cell of the pair below
 //     takes from its pair (blank * tilted blank probability + label * skip), instead of shipping both cells.
-// Waves of a workgroup land on the SIMDs in the order 0,2,1,3,...: waves 0-7 = alpha/beta waves 0..3 interleaved,
-// 8-11 = probability rows (8,10 alpha side, 9,11 beta side), 12,13 = alpha/beta wave 4, 14 = lattice description, then
-// beta's frame wave, 15 = alpha's frame wave.
-constexpr int kHaloLanes = kBlk;              // pairs a wave recomputes (one goes stale per step)
-constexpr int kHaloOwn = 64 - kHaloLanes;     // pairs a wave owns
-constexpr int kHaloMaxW = 5;                  // ceil(256 / 56)
-constexpr int kHaloSlots = 8;                 // ring depth (blocks) of the published exponents and edge pairs
+// (An f64 form of this -- one pair per lane, five waves per direction -- was built first: parity-green and exactly as fast
+// as the single-wave chains, 91.6 against 94.6 us; see DESIGN.md 4.1c.  It is not in the tree any more.)
+constexpr int kHaloSlots = 8;                 // ring depth (blocks) of the published exponents and edge lanes
 constexpr int kHaloLag = 2;                   // blocks between measuring the row's exponent and removing it
 constexpr int kHaloIdle = 0x3fffffff;         // prog[] of a wave that holds no cell of the utterance
-
-struct HaloLds {
-  // byte offsets from the start of the workgroup's LDS
-  int bnd;         // [2][kHaloMaxW][kHaloSlots][kHaloLanes] pairs of doubles: wave w's edge pairs after block n
-  int zacc;        // [8] doubles: each alpha wave's share of the partition sum (cells L-1 and L-2 may sit in two waves)
-  int prog;        // [2][8] ints: blocks a wave has finished and published
-  int exw;         // [2][kHaloSlots] ints: (n << 12 | exponent + 2048) the frame wave decided for the end of block n
-  int mxl;         // [2][kHaloSlots][kHaloMaxW][64] ints: high word of every lane's larger cell at the end of block n
-  __host__ __device__ explicit HaloLds(int base) {
-    bnd = base;
-    zacc = bnd + 2 * kHaloMaxW * kHaloSlots * kHaloLanes * 16;
-    prog = zacc + 64;
-    exw = prog + 2 * 8 * 4;
-    mxl = exw + 2 * kHaloSlots * 4;
-  }
-  __host__ __device__ static size_t bytes() {
-    return 2 * kHaloMaxW * kHaloSlots * kHaloLanes * 16 + 64 + 2 * 8 * 4 + 2 * kHaloSlots * 4 + 2 * kHaloSlots * kHaloMaxW * 64 * 4;
-  }
-};
 
 // Hand-off waits are bounded: a protocol error flags the utterance (bit 128 -> the exact kernel redoes it) instead of
 // hanging the GPU.  (~2^20 polls of >= 64 cycles: far beyond any legitimate wait.)
@@ -877,200 +846,6 @@ struct HaloLds {
     }                                                                                            \
     asm volatile("" ::: "memory");                                                               \
   } while (0)
-
-// F2PPL: label pairs per lane of the SEGMENT kernel, which fixes the checkpoint rows' width (128*F2PPL cells) and the
-// granularity of their block-floating-point exponents (one per segment-kernel lane = F2PPL lanes here; 56 and 8 are
-// multiples of 4, so such a group never straddles two waves or a wave's halo).
-template <int DIR, int F2PPL>
-__device__ __forceinline__ void halo_chain_wave(const FastParams& p, int b, int T, int S, const F1Lds& lds, lds_u8* L0,
-                                                int ring_bytes_dir, int blk_bytes, const HaloLds hl, int lane, int w, int W) {
-  const int V = p.V, blank = p.blank, L = 2 * S + 1;
-  const int nblk = (T + kBlk - 1) / kBlk;
-  const int ring_off = DIR * ring_bytes_dir;
-  volatile int* myfilled = lds.filled + DIR * kRingBlks;
-  lds_u8* prog = L0 + hl.prog + DIR * 32;
-  lds_u8* exw = L0 + hl.exw + DIR * (kHaloSlots * 4);
-  lds_u8* mxl = L0 + hl.mxl + ((DIR * kHaloSlots * kHaloMaxW + w) * 64 + lane) * 4;      // + slot * kHaloMaxW * 256
-  __builtin_amdgcn_s_setprio(3);
-  unsigned long long prof_fill = 0, prof_nb = 0, prof_lag = 0, prof_t0 = __builtin_amdgcn_s_memtime();
-  (void)prof_fill; (void)prof_nb; (void)prof_lag; (void)prof_t0;
-
-  // this lane's label pair: blank cell 2*pair, label cell 2*pair + 1
-  const int pair = DIR == 0 ? kHaloOwn * w + lane - kHaloLanes : kHaloOwn * w + lane;
-  const bool owned = (DIR == 0 ? lane >= kHaloLanes : lane < kHaloOwn) && pair < 64 * F2PPL;
-  const bool halo = DIR == 0 ? lane < kHaloLanes : lane >= kHaloOwn;
-  const bool has_up = DIR == 0 ? w > 0 : w < W - 1;             // a wave whose edge pairs this one needs
-  const bool has_down = DIR == 0 ? w < W - 1 : w > 0;
-  const int up = DIR == 0 ? w - 1 : w + 1;
-  const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
-  const bool in = pair >= 0 && pair < S;
-  const int li = in ? (int)tg[pair] : -1;
-  const int lpv = (pair >= 1 && pair - 1 < S) ? (int)tg[pair - 1] : -1;
-  const int lnx = (pair >= -1 && pair + 1 < S) ? (int)tg[pair + 1] : -1;
-  const int lab = (in && li >= 0 && li < V) ? li : V;           // V: the always-zero column
-  const float r_tilt = fast_tilt(S, T);
-  const double rr = (double)r_tilt, rr2 = rr * rr, inv_rr = 1.0 / rr;
-  // alpha: the skip (pair-1) -> pair as this pair sees it; beta: the same skip as the pair BELOW sees it -- a beta lane
-  // prepares what that pair takes from it, so that one value crosses the lanes per step instead of two
-  const float skf = DIR == 0 ? ((in && pair >= 1 && li != blank && lpv != li) ? r_tilt * r_tilt : 0.f)      // ctc_loss.cpp:53-57
-                             : ((in && pair >= 1 && lpv != blank && li != lpv) ? r_tilt * r_tilt : 0.f);     // ctc_loss.cpp:91-96
-  const double sk = (double)skf;
-  (void)lnx;
-  if (DIR == 0 && __any(owned && in && (li == blank || li < 0 || li >= V))) { if (lane == 0) atomicOr(&p.flags[b], 2); }
-  const bool cond = (T > 1 || L == 1);            // ctc_loss.cpp:39,76
-
-  double c0 = 0.0, c1 = 0.0;                       // the pair: c0 = B~ (blank cell before its emission), c1 = L^ (label cell, tilted)
-  double yb_prev = 0.0, wb_prev = 0.0;             // blank probability of the frame processed last, and r^2 times it
-  int e_total = 0;                                 // sum of removed exponents: the frame
-  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
-
-  h_d2 eraw[4], braw[4], wraw[4];                  // the block's probabilities of this lane's label and of the blank (plain, tilted)
-  const int lab_off = lab * (kRow * 8), blank_off = blank * (kRow * 8), wb_off = (V + 1) * (kRow * 8);
-  auto load_half = [&](int n, auto half_tag) {
-    constexpr int H = decltype(half_tag)::value;
-    const int yo = ring_off + (n % kRingBlks) * blk_bytes + 32 * H;
-    eraw[2 * H] = *(lds_d2*)(L0 + yo + lab_off); eraw[2 * H + 1] = *(lds_d2*)(L0 + yo + lab_off + 16);
-    braw[2 * H] = *(lds_d2*)(L0 + yo + blank_off); braw[2 * H + 1] = *(lds_d2*)(L0 + yo + blank_off + 16);
-    wraw[2 * H] = *(lds_d2*)(L0 + yo + wb_off); wraw[2 * H + 1] = *(lds_d2*)(L0 + yo + wb_off + 16);
-  };
-
-  auto run_block = [&](int n, auto steady_tag) {
-    constexpr bool STEADY = decltype(steady_tag)::value;
-    load_half(n, std::integral_constant<int, 1>{});
-    const bool want_next = n + 1 < nblk;
-    int next_filled = 0;
-    if (want_next) next_filled = peek(&myfilled[(n + 1) % kRingBlks]);
-    // the halo pairs, as the upstream wave left them after block n-1 (same frame: the rescale is common)
-    if (n > 0 && has_up) {
-      { PROF_SPIN_BEGIN HALO_WAIT(__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(prog + 4 * up)) >= n); PROF_SPIN_END(prof_nb) }
-      const h_d2 v = *(lds_d2*)(L0 + hl.bnd + (((DIR * kHaloMaxW + up) * kHaloSlots + ((n - 1) & (kHaloSlots - 1))) * kHaloLanes + (lane & (kHaloLanes - 1))) * 16);
-      if (halo) { c0 = v.x; c1 = v.y; }
-    }
-    const int tbase = block_time(DIR, n, 0, T);
-    int xw = 0;
-#pragma unroll
-    for (int tt = 0; tt < kBlk; tt++) {
-      const int t = DIR == 0 ? tbase + tt : tbase - tt;
-      const double yb = braw[tt >> 1][tt & 1], e = eraw[tt >> 1][tt & 1], wb = wraw[tt >> 1][tt & 1];
-      if (tt == 4) {
-        xw = *(volatile lds_int*)(exw + 4 * (n & (kHaloSlots - 1)));      // normally there since two blocks ago; looked at after step 7
-        if (want_next && __builtin_amdgcn_readfirstlane(next_filled) != n + 2) { PROF_SPIN_BEGIN spin_until(&myfilled[(n + 1) % kRingBlks], n + 2); PROF_SPIN_END(prof_fill) }
-        load_half(n + 1, std::integral_constant<int, 0>{});
-      }
-      if (STEADY || t < T) {
-        const bool first = !STEADY && (DIR == 0 ? t == 0 : t == T - 1);
-        if (DIR == 0) {
-          // alpha_t[j] = (alpha[j] + r*alpha[j-1] + r^2*skip*alpha[j-2]) * y_t[l_j], ctc_loss.cpp:47-60
-          if (first) {
-            if (pair == 0) { c0 = cond ? 1.0 : 0.0; c1 = rr2 * e; }               // ctc_loss.cpp:39-42
-          } else {
-            const double pl = from_prev_lane(c1);          // label cell just below this lane's blank
-            const double ob = c0;
-            c0 = ob * yb_prev + pl;
-            c1 = (c1 + wb_prev * ob + sk * pl) * e;
-          }
-        } else {
-          // q_t[j] = (q[j] + r*q[j+1] + r^2*skipn*q[j+2]) * y_t[l_j]; q = beta * emission, ctc_loss.cpp:84-99
-          if (first) {
-            if (pair == S && cond) c0 = 1.0;                                       // ctc_loss.cpp:76
-            if (pair == S - 1) c1 = rr2 * e;                                       // ctc_loss.cpp:78
-          } else {
-            const double give = wb_prev * c0 + sk * c1;        // what the label cell of the pair below takes from this pair
-            const double take = from_next_lane(give);
-            const double ol = c1;
-            c1 = (ol + take) * e;
-            c0 = c0 * yb_prev + ol;
-          }
-        }
-        yb_prev = yb; wb_prev = wb;
-        if (tt == 7) {
-          // the frame: every lane leaves the high word of its larger cell for the frame wave, and removes what that wave
-          // decided for the end of this block from the words of two blocks ago
-          *(volatile lds_int*)(mxl + (n & (kHaloSlots - 1)) * (kHaloMaxW * 256)) = max(__double2hiint(c0), __double2hiint(c1));
-          xw = __builtin_amdgcn_readfirstlane(xw);
-          if ((xw >> 12) != n) {
-            PROF_SPIN_BEGIN
-            int spins = 0;
-            do {
-              __builtin_amdgcn_s_sleep(1);
-              xw = __builtin_amdgcn_readfirstlane(*(volatile lds_int*)(exw + 4 * (n & (kHaloSlots - 1))));
-              if (++spins > (1 << 20)) { atomicOr(&p.flags[b], 128); xw = (n << 12) | 2048; }
-            } while ((xw >> 12) != n);
-            PROF_SPIN_END(prof_lag)
-          }
-          const int ex = (xw & 0xfff) - 2048;
-          c0 = ldexp(c0, -ex); c1 = ldexp(c1, -ex);
-          e_total += ex;
-          const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
-          if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
-            // block floating point: each group of F2PPL pairs stores its cells scaled by its own exponent
-            const double cell0 = c0 * yb_prev, cell1 = c1 * inv_rr;     // the true cells: blank with its emission, label without the tilt
-            int m = max(__double2hiint(cell0), __double2hiint(cell1));
-            if (F2PPL >= 2) m = max(m, dpp_i<0xB1>(0, m));              // quad_perm [1,0,3,2]
-            if (F2PPL >= 4) m = max(m, dpp_i<0x4E>(0, m));              // quad_perm [2,3,0,1]
-            const int own = m > 0 ? ((m >> 20) & 0x7ff) - 1023 : -30000;
-            if (owned && (pair & ~(F2PPL - 1)) <= S) {            // (groups past the lattice are not read)
-              float2 o;
-              o.x = m > 0 ? (float)ldexp(cell0, -own) : 0.f;
-              o.y = m > 0 ? (float)ldexp(cell1, -own) : 0.f;
-              *reinterpret_cast<float2*>(ck + (size_t)(kk / kSeg) * p.CELLS + 2 * pair) = o;
-              if ((pair & (F2PPL - 1)) == 0)
-                p.ckE[(((size_t)b * p.NS + kk / kSeg) * 2 + DIR) * 64 + pair / F2PPL] = (short)own;
-            }
-          }
-        }
-      }
-    }
-    // edge pairs for the downstream wave, then the word that says so (and that this block's probabilities were read)
-    if (has_down) {
-      const bool edge = DIR == 0 ? lane >= 64 - kHaloLanes : lane < kHaloLanes;
-      if (edge) {
-        h_d2 v; v.x = c0; v.y = c1;
-        *(lds_d2*)(L0 + hl.bnd + (((DIR * kHaloMaxW + w) * kHaloSlots + (n & (kHaloSlots - 1))) * kHaloLanes + (lane & (kHaloLanes - 1))) * 16) = v;
-      }
-    }
-    *(volatile lds_int*)(prog + 4 * w) = n + 1;
-  };
-  {
-    spin_until(&myfilled[0], 1);
-    load_half(0, std::integral_constant<int, 0>{});
-    const int steady_end = DIR == 0 ? T / kBlk : nblk;         // blocks [1, steady_end) are steady
-    run_block(0, std::false_type{});
-    int n = 1;
-    for (; n < steady_end; n++) run_block(n, std::true_type{});
-    for (; n < nblk; n++) run_block(n, std::false_type{});
-  }
-
-#ifdef E2E_FAST_PROFILE
-  if (lane == 0 && b < 256) { unsigned long long* g = g_prof3 + ((size_t)b * 16 + DIR * 8 + w) * 4;
-    g[0] = __builtin_amdgcn_s_memtime() - prof_t0; g[1] = prof_fill; g[2] = prof_nb; g[3] = prof_lag; }
-#endif
-  // ---- log Z from this side ----
-  if (DIR == 0) {
-    // cells L-1 (the blank of pair S) and L-2 (the label of pair S-1) may sit in two waves
-    double z = 0.0;
-    if (owned && pair == S) z += c0 * yb_prev;            // ctc_loss.cpp:63-70, un-tilted relative to cell L-1
-    if (owned && pair == S - 1) z += c1;                  // (= r * the label cell)
-    for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o, 64);
-    *(volatile lds_f64*)(L0 + hl.zacc + 8 * w) = z;
-    *(volatile lds_int*)(prog + 4 * w) = nblk + 1;
-    if (w == 0) {
-      HALO_WAIT(__builtin_amdgcn_readfirstlane(lds_min8(prog)) >= nblk + 1);
-      if (lane == 0) {
-        double zs = 0.0;
-        for (int k = 0; k < W; k++) zs += *(volatile lds_f64*)(L0 + hl.zacc + 8 * k);
-        const double lz = log(zs) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log(rr);
-        p.logz[2 * b] = lz;
-        p.zt2[b] = log2(zs) + (double)e_total;
-        p.losses[b] = (float)(-lz);
-        if (!(zs > 0.0) || !(zs < __builtin_huge_val())) atomicOr(&p.flags[b], 4);     // infeasible or out of range
-      }
-    }
-  } else if (w == 0 && lane == 0) {
-    const double z = (cond ? c0 * yb_prev : 0.0) + c1;     // sum_j alpha_0[j]*beta_0[j]
-    p.logz[2 * b + 1] = log(z) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log(rr);
-  }
-}
 
 // The frame wave of a direction decides the exponent every chain wave removes at the end of block n: the absolute
 // exponent of the row's largest cell at the end of block n - kHaloLag, less what has been removed up to block n-1, so
@@ -1125,64 +900,7 @@ __device__ __forceinline__ void halo_frame_wave(const FastParams& p, int b, int 
   }
 }
 
-template <int PPL>
-__global__ __launch_bounds__(1024) void ctc_fast_chain_halo_kernel(FastParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int V = p.V;
-  const F1Lds lds(smem, V);
-  const HaloLds hl((int)align_up_dev(F1Lds::bytes(V), 32));
-
-  if (b == 0 && tid < 4) p.ctl[tid] = 0;
-  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
-  const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
-  if (bad) {                       // the exact kernel poisons this utterance
-    if (tid == 0) { p.flags[b] = 1; p.losses[b] = __builtin_nanf(""); }   // reason bit 0: bad lengths
-    return;
-  }
-  const int T = (int)Tq, S = (int)Sq;
-  constexpr int MAXW = (64 * PPL + kHaloOwn - 1) / kHaloOwn;     // waves that can hold a cell at this row width
-  const int W = min(S / kHaloOwn + 1, MAXW);                      // waves that hold a cell: pairs 0..S (pair S = the last blank)
-  if (tid == 0) p.flags[b] = 0;
-  if (tid < F1Lds::kSyncInts) lds.filled[tid] = 0;
-  if (tid < 16) reinterpret_cast<int*>(smem + hl.prog)[tid] = (tid & 7) < W ? 0 : kHaloIdle;
-  if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHaloLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;
-  if (tid < 8) reinterpret_cast<double*>(smem + hl.zacc)[tid] = 0.0;
-  for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
-    lds.ring[(size_t)(i / kBlk) * lds.blk_elems + V * kRow + (i % kBlk)] = 0.0;
-  __syncthreads();
-
-  const int wave = __builtin_amdgcn_readfirstlane(wid);
-  lds_u8* L0 = (lds_u8*)smem;
-  const int blk_bytes = lds.blk_elems * 8, ring_bytes_dir = kRingBlks * blk_bytes;
-  if (wave < 8 || wave == 12 || wave == 13) {
-    const int d = wave & 1, w = wave < 8 ? wave >> 1 : 4;
-    if (w >= MAXW) return;
-    if (w >= W) return;              // (holds no cell of this utterance; the segment kernel does not read past the lattice)
-    if (d == 0) halo_chain_wave<0, PPL>(p, b, T, S, lds, L0, ring_bytes_dir, blk_bytes, hl, lane, w, W);
-    else halo_chain_wave<1, PPL>(p, b, T, S, lds, L0, ring_bytes_dir, blk_bytes, hl, lane, w, W);
-  } else if (wave == 14) {
-    cellinfo_wave<PPL>(p, b, T, S, lds.sortcnt, lane);
-    halo_frame_wave<1>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHaloMaxW, lane, W);
-  } else if (wave == 15) halo_frame_wave<0>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHaloMaxW, lane, W);
-  else {
-    const int d = (wave - 8) & 1;                        // waves 8,10 -> alpha rows, 9,11 -> beta rows
-    const int first = (wave - 8) >> 1;                   // the two producers of a direction take alternate blocks
-    lds_u8* prog = L0 + hl.prog + d * 32;
-    const double rr = (double)fast_tilt(S, T), rr2 = rr * rr;         // (the chain waves' own expression)
-    unsigned char* ring = reinterpret_cast<unsigned char*>(lds.ring + (size_t)d * kRingBlks * lds.blk_elems);
-    volatile int* fl = lds.filled + d * kRingBlks;
-    if (V <= 16) prep_wave<2, 1>(p, b, T, d, first, 2, ring, blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 32) prep_wave<4, 1>(p, b, T, d, first, 2, ring, blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 48) prep_wave<6, 1>(p, b, T, d, first, 2, ring, blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 64) prep_wave<8, 1>(p, b, T, d, first, 2, ring, blk_bytes, fl, nullptr, lane, prog, rr2);
-    else prep_wave<12, 1>(p, b, T, d, first, 2, ring, blk_bytes, fl, nullptr, lane, prog, rr2);
-  }
-}
-
-// ============================================================================================
-// F1, f32 halo form: two label pairs per lane in packed f32 instructions
-// ============================================================================================
+// ---- the chains in packed f32 -----------------------------------------------------------------
 // The halo structure above with an f32 lattice.  What a chain wave costs is its instruction count per step (an in-order
 // wave issues an instruction every ~5.5 cycles at best, a dependent one every ~8.5 whatever its type --
 // tools/diag/microbench/issue_latency.hip), and v_pk_fma_f32 advances two pairs per instruction: a lane holds the
@@ -1376,7 +1094,7 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
         }
         yb_prev = yb; wb_prev = wb;
         if (tt == 7) {
-          // the frame: see halo_chain_wave
+          // the frame (see the section's header): leave the high word of the largest cell, remove what the frame wave decided
           const int m01 = max(__float_as_int(Bc.x), __float_as_int(Lc.x)), m23 = max(__float_as_int(Bc.y), __float_as_int(Lc.y));
           *(volatile lds_int*)(mxl + (n & (kHaloSlots - 1)) * (kHfMaxW * 256)) = max(m01, m23);    // positive floats order like ints
           xw = __builtin_amdgcn_readfirstlane(xw);
@@ -2068,23 +1786,9 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute");
   const size_t lds2 = F2Lds<PPL>::bytes(p.V);
-  // The halo chains (ctc_fast_chain_halo_kernel, E2E_F1_MULTI=1) are parity-green and as fast as the single-wave chains,
-  // not faster (MI355X, B=256, T=1000, V=29, S<=200): chain kernel 91.6 us against 94.6 us, the whole step 161 against
-  // 167 us; at S<=127 the single-wave form wins (120 against 129 us per step).  What was measured on the way:
-  //   first form, every wave reducing and comparing the frame words itself        118 us   (~250 instructions per block and wave)
-  //   + frame waves (a chain wave writes one word per lane, reads one per block)    94 us   (~150)
-  //   + producers 8 lanes x 8 rows per pass (~110 VALU per block instead of ~300)    94 us   (the ring never runs dry any more)
-  //   + tilted blank row from the producers, one value per step across beta lanes    92 us   (-10 % VALU in the chain waves)
-  //   timing experiment: the blank rows' 8 of 12 LDS reads per block removed         92 us
-  // A wave alone on its SIMD needs ~130 cycles per step for ~19 instructions, two chain waves that share a SIMD ~165 for
-  // the slower one; neither fewer VALU instructions nor fewer LDS reads move that.  The step is the latency of the
-  // dependent f64 chain (cell -> DPP -> multiply-add -> multiply -> next step's DPP) plus the per-block bookkeeping of an
-  // in-order wave; 4 pairs per lane in ONE wave amortise that latency over four independent pairs, 1 pair per lane in
-  // four waves pays it four times in parallel -- same wall time.  The multi-wave pipeline of the previous design (edge
-  // values through LDS every step) took 120-152 us.  Default: single wave.
-  static const bool single_wave = getenv("E2E_F1_MULTI") == nullptr;
   // f32 chains: where the caller allows them (e2e_ctc_loss_opts.chains) and they are faster, i.e. at the widest rows
-  // (120 / 118 / 100 us per step against 120 / 120 / 95 us at S <= 127 / 127 / 63); E2E_F1_F32=1 forces them everywhere (tests)
+  // (145 against 165 us per step at S <= 200, but 115 / 93 against 120 / 94 us at S <= 127 / 63, with looser gradients: not
+  // worth it there); E2E_F1_F32=1 forces them everywhere (tests)
   static const bool force_f32_chains = getenv("E2E_F1_F32") != nullptr;
   if (force_f32_chains || (p.chains == E2E_CHAINS_F32 && PPL == 4)) {
     const HfLds hl(p.V);
@@ -2097,20 +1801,9 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
     return E2E_OK;
   }
-  if (single_wave) {
-    hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
-    FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB;          // (its frame follows the maximum itself)
-    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
-    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
-    return E2E_OK;
-  } else {
-    const size_t ldsm = align_up(lds1, 32) + HaloLds::bytes();
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_halo_kernel<PPL>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_fast_chain_halo_kernel<PPL>, dim3(p.B), dim3(1024), ldsm, stream, p);
-  }
+  hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
-  FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB;            // (one common frame, as with the single-wave chains)
+  FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB;          // (its frame follows the maximum itself)
   hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
   return E2E_OK;

@@ -130,8 +130,3 @@ print("ok")
 def test_f32_chains_forced_for_every_row_width_match_exact():
     """E2E_F1_F32=1 sends every shape through the f32 chain kernel (1, 2 and 4 label pairs per segment-kernel lane)."""
     _variant_in_child("E2E_F1_F32", F32_CHAINS_GRAD_ATOL)
-
-
-def test_multi_wave_chains_variant_matches_exact():
-    """The experimental f64 halo form of the chain kernel (several waves per chain, E2E_F1_MULTI=1)."""
-    _variant_in_child("E2E_F1_MULTI", 2e-6)

@@ -152,7 +152,7 @@ def test_bench_helpers(tmp_path, monkeypatch):
     deterministic, and `--gpus N` without a launcher starts N ranks through torch.distributed.run on 127.0.0.1."""
     import bench
     t = bench.recorded_traffic(bench.WORKLOAD["name"])
-    assert t is not None and 2.5e8 < t < 3.5e8
+    assert t is not None and 1.5e8 < t < 3.5e8
     labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
     a, b = tmp_path / "a.arpa", tmp_path / "b.arpa"
     bench.synthetic_arpa(str(a), labels, n_words=200, seed=3)

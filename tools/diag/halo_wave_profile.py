@@ -1,4 +1,5 @@
-# per-wave cycle accounts of the halo chain kernel (instrumented library: tools/diag/build_profile_lib.sh; run with E2E_F1_MULTI=1)
+# per-wave cycle accounts of the f32 halo chain kernel (instrumented library: tools/diag/build_profile_lib.sh, taken off
+# .gpurunignore for the call; run with E2E_F1_F32=1).  The wave-count classes printed are S // 56 + 1.
 import sys, ctypes as C, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
