@@ -126,8 +126,10 @@ __device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, in
 #pragma unroll
       for (int k = 0; k < NC; k++) a[k] = 0.0;
     } else {
+      // (the chains store no cells past the lattice's 2S+1: lanes beyond it hold zeros)
+      const bool in_lattice = lane * NC < L;
       const float* src = rt.ckA + ((size_t)b * rt.NS + seg) * rt.CELLS + lane * NC;
-      const int own = rt.ckE[(((size_t)b * rt.NS + seg) * 2 + 0) * 64 + lane];
+      const int own = in_lattice ? rt.ckE[(((size_t)b * rt.NS + seg) * 2 + 0) * 64 + lane] : -30000;
 #pragma unroll
       for (int k = 0; k < NC; k++) a[k] = own > -30000 ? ldexp((double)src[k], own) : 0.0;
     }
@@ -162,8 +164,9 @@ __device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, in
     double q[NC];
     const bool last_seg = (t0 + n == T);
     if (!last_seg) {
+      const bool in_lattice = lane * NC < L;
       const float* src = rt.ckQ + ((size_t)b * rt.NS + seg + 1) * rt.CELLS + lane * NC;
-      const int own = rt.ckE[(((size_t)b * rt.NS + seg + 1) * 2 + 1) * 64 + lane];
+      const int own = in_lattice ? rt.ckE[(((size_t)b * rt.NS + seg + 1) * 2 + 1) * 64 + lane] : -30000;
 #pragma unroll
       for (int k = 0; k < NC; k++) q[k] = own > -30000 ? ldexp((double)src[k], own) : 0.0;
     } else {
@@ -276,6 +279,7 @@ __device__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, 
     else if (p.retry.PPL == 4) ok = retry_segments_f64<IO, 4>(p, smem, b, slot);
     __syncthreads();
     if (ok) return;
+    if (tid == 0 && p.ctl) atomicAdd(&p.ctl[1], 1);      // (diagnostics: redone in full although only the segments' range gave out)
   }
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   if (p.mode == 2 || Tq < 1 || Tq > Tmax || Sq < 0 || Sq > Smax) {   // invalid lengths: poison, do not crash

@@ -63,7 +63,8 @@ struct FastParams {
   int* flags;      // [B]       != 0: redo with the exact kernel
   unsigned* cinfo; // [B][CELLS/2]  per label pair: label | sorted slot << 8 | alpha skip << 16 | beta skip << 17
   int* lstart;     // [B][130]  first label-sorted slot of every label (V+1 entries used)
-  int* ctl;        // [4]  0: fallback workgroups that have finished (F1 clears it; the last one reduces the losses)
+  int* ctl;        // [4]  0: fallback workgroups that have finished (F1 clears it; the last one reduces the losses);
+                   //      1: flagged utterances the f64 redo of the segments could not settle (diagnostics)
   float gscale;    // every gradient element is multiplied by this as it is written (e2e_ctc_loss_opts.grad_scale)
   float ztol;      // |log2| tolerance of the segment kernel's self-check (kZTol with f64 chains, kZTolF32 with f32 chains)
   int chains;      // host side: E2E_CHAINS_* of the call
@@ -1930,6 +1931,18 @@ extern "C" int e2e_debug_fast_profile(unsigned long long* host, int n) {
 
 // Diagnostics (not part of include/e2e_ctc.h): copy the fast path's per-utterance flag words and both log Z
 // values out of a workspace that the last e2e_ctc_loss_fwd_bwd(ALGO_FAST/AUTO) call used.  Synchronises.
+// Diagnostics: how many flagged utterances of the last AUTO call the f64 redo of the segments could NOT settle (they were
+// recomputed by the exact kernel: ~7 ms for a batch instead of ~1).  Synchronises.
+extern "C" int e2e_debug_fast_redo_failures(const void* workspace, int B, int T, int V, int Smax, int* count_host) {
+  uintptr_t base = reinterpret_cast<uintptr_t>(workspace);
+  const char* ws = reinterpret_cast<const char*>((base + 255) & ~(uintptr_t)255);
+  const e2e::FastLayout l = e2e::fast_layout(B, T, V, Smax);
+  if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
+  int ctl[4];
+  if (hipMemcpy(ctl, ws + l.ctl, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) return E2E_ERR_HIP;
+  *count_host = ctl[1];
+  return E2E_OK;
+}
 extern "C" int e2e_debug_fast_state(const void* workspace, int B, int T, int V, int Smax, int* flags_host, double* logz_host) {
   uintptr_t base = reinterpret_cast<uintptr_t>(workspace);
   const char* ws = reinterpret_cast<const char*>((base + 255) & ~(uintptr_t)255);

@@ -130,3 +130,25 @@ print("ok")
 def test_f32_chains_forced_for_every_row_width_match_exact():
     """E2E_F1_F32=1 sends every shape through the f32 chain kernel (1, 2 and 4 label pairs per segment-kernel lane)."""
     _variant_in_child("E2E_F1_F32", F32_CHAINS_GRAD_ATOL)
+
+
+def test_flagged_utterances_are_settled_by_the_segment_redo_not_by_the_exact_kernel():
+    """The headline shape with emissions that contradict the targets (logits x3): a third of the utterances leave the
+    f32 segment kernel's range.  They must be redone from the chains' checkpoints in f64 (~1 ms for the batch), not by
+    the exact kernel (~7 ms): a regression here is invisible in the results and shows only as a step-time cliff."""
+    import ctypes
+    L = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    B, T, V, S = 64, 1000, 29, 200
+    x = (torch.randn(B, T, V, generator=g) * 3.0)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl = torch.full((B,), T); tl = torch.randint(S // 2, S + 1, (B,), generator=g)
+    kept = {}
+    lf, _ = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    la, _ = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_AUTO, keep=kept)
+    flagged = int(np.isnan(lf).sum())
+    assert flagged >= 4 and np.isfinite(la).all()
+    n = ctypes.c_int(-1)
+    L.e2e_debug_fast_redo_failures.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    assert L.e2e_debug_fast_redo_failures(kept["workspace"].data_ptr(), B, T, V, S, ctypes.byref(n)) == 0
+    assert 0 <= n.value <= flagged // 4, (n.value, flagged)
