@@ -950,6 +950,7 @@ struct HfLds {
   int exw;         // [2][kHaloSlots] ints
   int mxl;         // [2][kHaloSlots][kHfMaxW][64] ints
   int ckb;         // [2][2][kHfMaxW][64] x 16 B: a checkpoint row's true cells (B0, L0, B1, L1 per lane), double-buffered
+  int ckdone;      // [2] ints: checkpoint rows the direction's checkpoint wave has finished reading
   int total;
   __host__ __device__ explicit HfLds(int V) {
     ring = 0;
@@ -962,7 +963,8 @@ struct HfLds {
     exw = prog + 2 * 8 * 4;
     mxl = exw + 2 * kHaloSlots * 4;
     ckb = mxl + 2 * kHaloSlots * kHfMaxW * 64 * 4;
-    total = ckb + 2 * 2 * kHfMaxW * 64 * 16;
+    ckdone = ckb + 2 * 2 * kHfMaxW * 64 * 16;
+    total = ckdone + 16;
   }
 };
 
@@ -1017,6 +1019,7 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
   const float kOne = ldexpf(1.f, bias);
   float yb_prev = 0.f, wb_prev = 0.f;
   int e_total = 0;
+  int nck = 0;                                     // checkpoint rows handed to the checkpoint wave
   int lead = 0;                                    // blocks of probabilities known to be in the ring: [0, lead)
   auto need_blocks = [&](int k) {                  // (the producers run several blocks ahead: one look every few blocks)
     if (lead < k) {
@@ -1115,6 +1118,9 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
           const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
           if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
             // the true cells (blank with its emission, label without the tilt); the frame wave converts and stores them
+            // (two buffers: the checkpoint wave has 16 steps for each and is normally long done with the row before last)
+            if (nck >= 2) HALO_WAIT(__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(L0 + hl.ckdone + 4 * DIR)) >= nck - 1);
+            nck++;
             const h_f2 cb = Bc * yb_prev, cl = Lc * inv_rr;
             h_f4 o; o.x = cb.x; o.y = cl.x; o.z = cb.y; o.w = cl.y;
             *(lds_f4*)(L0 + hl.ckb + ((((DIR * 2 + ((kk / kSeg) & 1)) * kHfMaxW + w) * 64 + lane) * 16)) = o;
@@ -1188,14 +1194,22 @@ __device__ __forceinline__ void hf_ckpt_wave(const FastParams& p, int b, int T, 
   float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
   const int idx = DIR == 0 ? lane - kHfHalo : lane;
   const bool own_lane = DIR == 0 ? lane >= kHfHalo : lane < kHfOwnLanes;
+  int done = 0;
   for (int n = 0; n < nres; n++) {
     // the checkpoint row of this block, if it has one (alpha row 16k-1 / beta row 16k -> slot k)
     const int kk = DIR == 0 ? 8 * (n + 1) : 8 * (M - n);
     if (!((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T)) continue;
     HALO_WAIT(__builtin_amdgcn_readfirstlane(lds_min8(prog)) >= n + 1);
     const int slot = kk / kSeg;
-    for (int w = 0; w < W; w++) {
-      const h_f4 c = *(lds_f4*)(L0 + hl.ckb + ((((DIR * 2 + (slot & 1)) * kHfMaxW + w) * 64 + lane) * 16));
+    h_f4 cw[kHfMaxW];
+#pragma unroll
+    for (int w = 0; w < kHfMaxW; w++)
+      if (w < W) cw[w] = *(lds_f4*)(L0 + hl.ckb + ((((DIR * 2 + (slot & 1)) * kHfMaxW + w) * 64 + lane) * 16));
+    *(volatile lds_int*)(L0 + hl.ckdone + 4 * DIR) = ++done;       // (LDS runs this wave's operations in order: the reads are done)
+#pragma unroll
+    for (int w = 0; w < kHfMaxW; w++) {
+      if (w >= W) break;
+      const h_f4 c = cw[w];
       const int p0 = kHfOwn * w + 2 * idx;
       const int ma = max(__float_as_int(c.x), __float_as_int(c.y)), mb = max(__float_as_int(c.z), __float_as_int(c.w));
       int m0 = ma, m1 = mb;                                           // exponent source of pair p0 / p0 + 1
@@ -1239,6 +1253,7 @@ __global__ __launch_bounds__(1024) void ctc_fast_chain_hf_kernel(FastParams p) {
   if (tid < 16) reinterpret_cast<int*>(smem + hl.prog)[tid] = (tid & 7) < W ? 0 : kHaloIdle;
   if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHfLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;
   if (tid < 8) reinterpret_cast<double*>(smem + hl.zacc)[tid] = 0.0;
+  if (tid < 2) reinterpret_cast<int*>(smem + hl.ckdone)[tid] = 0;
   for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
     reinterpret_cast<float*>(smem + hl.ring + (i / kBlk) * hl.blk_bytes)[V * kRow32 + (i % kBlk)] = 0.f;
   __syncthreads();
