@@ -405,9 +405,8 @@ __device__ __forceinline__ float exp_le0(float x) {
 // (Four steps per pass with 16 lanes each was the first form: the reductions, the reciprocal and the address
 // arithmetic are paid per pass, and at V = 29 that was ~300 VALU instructions per block against ~110 here.  The
 // producers share their SIMDs with the chain waves, so their instruction count is the chains' speed too.)
-// MODE 0: f64 ring read by one chain wave (`took`); 2: f32 ring of ctc_fast_chain_hf_kernel -- label rows of kRow32
-// floats and one row of (blank probability, tilted blank probability) pairs, read by several waves whose progress words
-// replace `took`.
+// MODE 0: f64 ring read by one chain wave (`took`); 1 / 2: f64 / f32 ring of ctc_fast_chain_hf_kernel -- label rows and one
+// row of (blank probability, tilted blank probability) pairs, read by several waves whose progress words replace `took`.
 template <int NV, int MODE = 0>
 __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int dir, int first, int stride,
                                           unsigned char* myring_bytes, int blk_bytes, volatile int* myfilled, volatile int* took,
@@ -492,15 +491,21 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
             float2 yw; yw.x = row_live ? y[k] : 0.f; yw.y = row_live ? (float)rr2 * y[k] : 0.f;
             *reinterpret_cast<float2*>(blk32 + (V + 1) * kRow32 + 2 * tt) = yw;
           }
+        } else if (MODE == 1) {
+          blk[(l8 + 8 * k) * kRow + tt] = row_live ? (double)y[k] : 0.0;
+          if (l8 + 8 * k == p.blank) {
+            double2 yw; yw.x = row_live ? (double)y[k] : 0.0; yw.y = row_live ? rr2 * (double)y[k] : 0.0;
+            *reinterpret_cast<double2*>(blk + (V + 1) * kRow + 2 * tt) = yw;
+          }
         } else {
           blk[(l8 + 8 * k) * kRow + tt] = row_live ? (double)y[k] : 0.0;   // transposed: [label][step]
         }
         if (dir == 0 && row_live) yrow[l8 + 8 * k] = y[k];
       }
     }
-    // every lane stores the same word: no divergence, one LDS write.  (MODE 2: one word per producer, "my blocks up to n
+    // every lane stores the same word: no divergence, one LDS write.  (MODE 1, 2: one word per producer, "my blocks up to n
     // are there" -- the readers keep the minimum of the two in a scalar and look again only when they catch up.)
-    if (MODE == 2) publish(&myfilled[first], n + stride);
+    if (MODE != 0) publish(&myfilled[first], n + stride);
     else publish(&myfilled[slot], n + 1);
 #pragma unroll
     for (int k = 0; k < NV; k++) xv[k] = xn[k];
@@ -924,11 +929,9 @@ __device__ __forceinline__ void halo_frame_wave(const FastParams& p, int b, int 
 constexpr int kHfHalo = 8;                    // halo lanes = 16 pairs: the waves exchange edge lanes every SECOND block
 constexpr int kHfOwnLanes = 64 - kHfHalo;     // 56
 constexpr int kHfOwn = 2 * kHfOwnLanes;       // 112 pairs a wave owns
-constexpr int kHfMaxW = 3;                    // ceil(256 / 112)
-constexpr int kHfProducers = 3;               // probability-row waves per direction (with two the chains waited for the ring)
 constexpr int kHfLag = 2;                     // the frame follows the row's maximum two blocks late (one: the waves meet at every
                                               // block's end, 153 instead of 145 us per step at the headline shape)
-// The cells are kept 2^bias above that frame.  A row sinks 26-42 bits per block for uninformative emissions at V = 29..64
+// f32: the cells are kept 2^bias above that frame.  A row sinks 26-42 bits per block for uninformative emissions at V = 29..64
 // and is not rescaled at all during its first three blocks, and cells 100 bits under the row's maximum still carry
 // posterior mass at some t (measured: with the maximum at 2^-25 .. 2^-67, 15 % of the utterances at V = 64 lose 1e-4 of
 // log Z).  Without tilt > 1 a row's maximum grows by at most 3x per step (alpha[j] <= 3 max(alpha) y), 2^25.4 over the
@@ -938,43 +941,74 @@ constexpr int kHfLag = 2;                     // the frame follows the row's max
 // (Extrapolating the sinking rate to decide the frame was tried: the differences amplify the row-to-row variation.)
 __device__ __forceinline__ int hf_bias(float r_tilt) { return r_tilt <= 1.f ? 100 : 90; }
 
-struct HfLds {
-  // byte offsets from the start of the workgroup's LDS
-  int ring;        // [2][kRingBlks] blocks of blk_bytes: (V+1) label rows of kRow32 floats (row V: zeros) + 16 floats (yb, wb) x 8 steps
-  int blk_bytes;
-  int filled;      // [2][kRingBlks] ints; used: [dir][f] = kHfProducers + the last block producer f of the direction has finished
-  int sortcnt;     // [130] ints (cellinfo_wave)
-  int bnd;         // [2][kHfMaxW][kHaloSlots][kHfHalo] x 16 B: wave w's edge lanes (B0, L0, B1, L1) after block n
-  int zacc;        // [8] doubles
-  int prog;        // [2][8] ints
-  int exw;         // [2][kHaloSlots] ints
-  int mxl;         // [2][kHaloSlots][kHfMaxW][64] ints
-  int ckb;         // [2][2][kHfMaxW][64] x 16 B: a checkpoint row's true cells (B0, L0, B1, L1 per lane), double-buffered
-  int ckdone;      // [2] ints: checkpoint rows the direction's checkpoint wave has finished reading
-  int total;
-  __host__ __device__ explicit HfLds(int V) {
-    ring = 0;
-    blk_bytes = ((V + 1) * kRow32 + 16) * 4;
-    filled = ring + 2 * kRingBlks * blk_bytes;
-    sortcnt = filled + 2 * kRingBlks * 4;
-    bnd = (sortcnt + 130 * 4 + 15) & ~15;
-    zacc = bnd + 2 * kHfMaxW * kHaloSlots * kHfHalo * 16;
-    prog = zacc + 64;
-    exw = prog + 2 * 8 * 4;
-    mxl = exw + 2 * kHaloSlots * 4;
-    ckb = mxl + 2 * kHaloSlots * kHfMaxW * 64 * 4;
-    ckdone = ckb + 2 * 2 * kHfMaxW * 64 * 16;
-    total = ckdone + 16;
-  }
-};
-
 typedef float h_f2 __attribute__((ext_vector_type(2)));
 typedef float h_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) h_f4 lds_f4;
 
-template <int DIR, int F2PPL>
+// The two arithmetics of the halo chains.  Both hold two label pairs per lane as B = (B0, B1), L = (L0, L1).
+//   ChainF32: packed instructions, 3 waves per direction at most (any S <= 255), 3 producers per direction, 16 waves.
+//   ChainF64: the same structure in f64 -- the default for targets of 64..223 labels: every result as the single-wave
+//             chains give it (same recurrence, same f64 cells; powers of two apart), 2 waves per direction, 14 waves.
+struct ChainF32 {
+  typedef float T; typedef h_f2 V2;
+  static constexpr bool kF32 = true;
+  static constexpr int kMaxW = 3, kProducers = 3, kRowElems = kRow32, kElem = 4;
+  static constexpr int kWaves = 2 * kMaxW + 2 + 2 * kProducers + 2;
+  __device__ static int top(float v) { return __float_as_int(v); }             // positive values order like these ints
+  __device__ static int expo(int m) { return ((m >> 23) & 0xff) - 127; }
+  __device__ static int bias(float r) { return hf_bias(r); }
+  __device__ static float scale(float v, int e) { return ldexpf(v, e); }
+  __device__ static float tilt2(float r) { return r * r; }
+};
+struct ChainF64 {
+  typedef double T; typedef h_d2 V2;
+  static constexpr bool kF32 = false;
+  static constexpr int kMaxW = 2, kProducers = 3, kRowElems = kRow, kElem = 8;
+  static constexpr int kWaves = 2 * kMaxW + 2 + 2 * kProducers + 2;
+  __device__ static int top(double v) { return __double2hiint(v); }
+  __device__ static int expo(int m) { return ((m >> 20) & 0x7ff) - 1023; }
+  __device__ static int bias(float) { return 0; }                                // (f64 cells have the range for the lag)
+  __device__ static double scale(double v, int e) { return ldexp(v, e); }
+  __device__ static double tilt2(float r) { return (double)r * (double)r; }
+};
+
+struct HfLds {
+  // byte offsets from the start of the workgroup's LDS
+  int ring;        // [2][kRingBlks] blocks of blk_bytes: (V+1) label rows of kRowElems cells (row V: zeros) + 16 cells (yb, wb) x 8 steps
+  int blk_bytes;
+  int filled;      // [2][kRingBlks] ints; used: [dir][f] = kProducers + the last block producer f of the direction has finished
+  int sortcnt;     // [130] ints (cellinfo_wave)
+  int bnd;         // [2][kMaxW][kHaloSlots][kHfHalo] x 4 cells: wave w's edge lanes (B0, L0, B1, L1) after block n
+  int zacc;        // [8] doubles
+  int prog;        // [2][8] ints
+  int exw;         // [2][kHaloSlots] ints
+  int mxl;         // [2][kHaloSlots][kMaxW][64] ints
+  int ckb;         // [2][2][kMaxW][64] x 4 cells: a checkpoint row's true cells (B0, L0, B1, L1 per lane), double-buffered
+  int ckdone;      // [2] ints: checkpoint rows the direction's checkpoint wave has finished reading
+  int total;
+  __host__ __device__ HfLds(int V, int row_elems, int elem, int maxw) {
+    ring = 0;
+    blk_bytes = ((V + 1) * row_elems + 16) * elem;
+    filled = ring + 2 * kRingBlks * blk_bytes;
+    sortcnt = filled + 2 * kRingBlks * 4;
+    bnd = (sortcnt + 130 * 4 + 15) & ~15;
+    zacc = bnd + 2 * maxw * kHaloSlots * kHfHalo * 4 * elem;
+    prog = zacc + 64;
+    exw = prog + 2 * 8 * 4;
+    mxl = exw + 2 * kHaloSlots * 4;
+    ckb = mxl + 2 * kHaloSlots * maxw * 64 * 4;
+    ckdone = ckb + 2 * 2 * maxw * 64 * 4 * elem;
+    total = ckdone + 16;
+  }
+  template <typename X> __host__ __device__ static HfLds of(int V) { return HfLds(V, X::kRowElems, X::kElem, X::kMaxW); }
+};
+
+template <int DIR, int F2PPL, typename X>
 __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T, int S, unsigned char* smem, const HfLds hl,
                                               int lane, int w, int W) {
+  typedef typename X::T CT;
+  typedef typename X::V2 V2;
+  constexpr int kCell = X::kElem, kLane4 = 4 * X::kElem;          // bytes of a cell / of a lane's four cells
   lds_u8* L0 = (lds_u8*)smem;
   const int V = p.V, blank = p.blank, L = 2 * S + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
@@ -982,7 +1016,7 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
   volatile int* myfilled = reinterpret_cast<int*>(smem + hl.filled) + DIR * kRingBlks;
   lds_u8* prog = L0 + hl.prog + DIR * 32;
   lds_u8* exw = L0 + hl.exw + DIR * (kHaloSlots * 4);
-  lds_u8* mxl = L0 + hl.mxl + ((DIR * kHaloSlots * kHfMaxW + w) * 64 + lane) * 4;      // + slot * kHfMaxW * 256
+  lds_u8* mxl = L0 + hl.mxl + ((DIR * kHaloSlots * X::kMaxW + w) * 64 + lane) * 4;      // + slot * kMaxW * 256
   __builtin_amdgcn_s_setprio(3);
   unsigned long long prof_fill = 0, prof_nb = 0, prof_lag = 0, prof_t0 = __builtin_amdgcn_s_memtime();
   (void)prof_fill; (void)prof_nb; (void)prof_lag; (void)prof_t0;
@@ -995,8 +1029,10 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
   const bool has_down = DIR == 0 ? w < W - 1 : w > 0;
   const int up = DIR == 0 ? w - 1 : w + 1;
   const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
-  const float r_tilt = fast_tilt(S, T), rr2 = r_tilt * r_tilt, inv_rr = 1.f / r_tilt;
-  int lab[2]; float skv[2]; bool badlab = false;
+  const float r_tilt = fast_tilt(S, T);
+  const CT rr2 = X::tilt2(r_tilt), inv_rr = (CT)1 / (CT)r_tilt;
+  const CT skip_w = (CT)(r_tilt * r_tilt);        // (the segment kernel's weight of a skip: the tilt squared in f32)
+  int lab[2]; CT skv[2]; bool badlab = false;
 #pragma unroll
   for (int r = 0; r < 2; r++) {
     const int pr = p0 + r;
@@ -1006,18 +1042,18 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
     lab[r] = (in && li >= 0 && li < V) ? li : V;           // V: the always-zero row
     // alpha: the skip (pr-1) -> pr as pair pr sees it; beta: the same skip as pair pr-1 sees it (this pair prepares what
     // the label cell of the pair below takes from it)
-    skv[r] = DIR == 0 ? ((in && pr >= 1 && li != blank && lpv != li) ? rr2 : 0.f)        // ctc_loss.cpp:53-57
-                      : ((in && pr >= 1 && lpv != blank && li != lpv) ? rr2 : 0.f);      // ctc_loss.cpp:91-96
+    skv[r] = DIR == 0 ? ((in && pr >= 1 && li != blank && lpv != li) ? skip_w : (CT)0)   // ctc_loss.cpp:53-57
+                      : ((in && pr >= 1 && lpv != blank && li != lpv) ? skip_w : (CT)0); // ctc_loss.cpp:91-96
     badlab |= owned && in && (li == blank || li < 0 || li >= V);
   }
   if (DIR == 0 && __any(badlab)) { if (lane == 0) atomicOr(&p.flags[b], 2); }
-  const h_f2 SK = {skv[0], skv[1]};
+  const V2 SK = {skv[0], skv[1]};
   const bool cond = (T > 1 || L == 1);            // ctc_loss.cpp:39,76
 
-  h_f2 Bc = {0.f, 0.f}, Lc = {0.f, 0.f};           // B~ (blank cells before their emission), L^ (label cells, tilted), times 2^bias
-  const int bias = hf_bias(r_tilt);
-  const float kOne = ldexpf(1.f, bias);
-  float yb_prev = 0.f, wb_prev = 0.f;
+  V2 Bc = {(CT)0, (CT)0}, Lc = {(CT)0, (CT)0};     // B~ (blank cells before their emission), L^ (label cells, tilted), times 2^bias
+  const int bias = X::bias(r_tilt);
+  const CT kOne = X::scale((CT)1, bias);
+  CT yb_prev = (CT)0, wb_prev = (CT)0;
   int e_total = 0;
   int nck = 0;                                     // checkpoint rows handed to the checkpoint wave
   int lead = 0;                                    // blocks of probabilities known to be in the ring: [0, lead)
@@ -1027,7 +1063,7 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
       for (;;) {
         int a = peek(&myfilled[0]);
 #pragma unroll
-        for (int f = 1; f < kHfProducers; f++) a = min(a, peek(&myfilled[f]));
+        for (int f = 1; f < X::kProducers; f++) a = min(a, peek(&myfilled[f]));
         lead = __builtin_amdgcn_readfirstlane(a);
         if (lead >= k) break;
         __builtin_amdgcn_s_sleep(1);
@@ -1037,14 +1073,32 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
     }
   };
 
-  h_f4 e0raw[2], e1raw[2], ywraw[4];               // the block's probabilities: 4 steps per register set / 2 steps of (yb, wb)
-  const int lab0_off = lab[0] * (kRow32 * 4), lab1_off = lab[1] * (kRow32 * 4), yw_off = (V + 1) * (kRow32 * 4);
-  auto load_half = [&](int n, auto half_tag) {
+  CT e0[kBlk], e1[kBlk], ybw[2 * kBlk];             // the block's probabilities of the two labels; (yb, wb) per step
+  const int lab0_off = lab[0] * (X::kRowElems * kCell), lab1_off = lab[1] * (X::kRowElems * kCell), yw_off = (V + 1) * (X::kRowElems * kCell);
+  auto load_half = [&](int n, auto half_tag) {     // steps 4H .. 4H+3 of block n
     constexpr int H = decltype(half_tag)::value;
     const int yo = ring_off + (n % kRingBlks) * hl.blk_bytes;
-    e0raw[H] = *(lds_f4*)(L0 + yo + lab0_off + 16 * H);
-    e1raw[H] = *(lds_f4*)(L0 + yo + lab1_off + 16 * H);
-    ywraw[2 * H] = *(lds_f4*)(L0 + yo + yw_off + 32 * H); ywraw[2 * H + 1] = *(lds_f4*)(L0 + yo + yw_off + 32 * H + 16);
+    if constexpr (X::kF32) {
+      const h_f4 a0 = *(lds_f4*)(L0 + yo + lab0_off + 16 * H), a1 = *(lds_f4*)(L0 + yo + lab1_off + 16 * H);
+      const h_f4 y0 = *(lds_f4*)(L0 + yo + yw_off + 32 * H), y1 = *(lds_f4*)(L0 + yo + yw_off + 32 * H + 16);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { e0[4 * H + k] = a0[k]; e1[4 * H + k] = a1[k]; ybw[8 * H + k] = y0[k]; ybw[8 * H + 4 + k] = y1[k]; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const h_d2 a0 = *(lds_d2*)(L0 + yo + lab0_off + 32 * H + 16 * q), a1 = *(lds_d2*)(L0 + yo + lab1_off + 32 * H + 16 * q);
+        e0[4 * H + 2 * q] = a0.x; e0[4 * H + 2 * q + 1] = a0.y; e1[4 * H + 2 * q] = a1.x; e1[4 * H + 2 * q + 1] = a1.y;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const h_d2 y = *(lds_d2*)(L0 + yo + yw_off + 64 * H + 16 * q);
+        ybw[8 * H + 2 * q] = y.x; ybw[8 * H + 2 * q + 1] = y.y;
+      }
+    }
+  };
+  auto store4 = [&](int off, CT x0, CT x1, CT x2, CT x3) {      // a lane's four cells
+    if constexpr (X::kF32) { h_f4 v; v.x = x0; v.y = x1; v.z = x2; v.w = x3; *(lds_f4*)(L0 + off) = v; }
+    else { h_d2 u, v; u.x = x0; u.y = x1; v.x = x2; v.y = x3; *(lds_d2*)(L0 + off) = u; *(lds_d2*)(L0 + off + 16) = v; }
   };
 
   auto run_block = [&](int n, auto steady_tag) {
@@ -1053,16 +1107,22 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
     const bool want_next = n + 1 < nblk;
     if (n > 0 && (n & 1) == 0 && has_up) {          // the halo lasts two blocks
       { PROF_SPIN_BEGIN HALO_WAIT(__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(prog + 4 * up)) >= n); PROF_SPIN_END(prof_nb) }
-      const h_f4 v = *(lds_f4*)(L0 + hl.bnd + (((DIR * kHfMaxW + up) * kHaloSlots + ((n - 1) & (kHaloSlots - 1))) * kHfHalo + (lane & (kHfHalo - 1))) * 16);
-      if (halo) { Bc.x = v.x; Lc.x = v.y; Bc.y = v.z; Lc.y = v.w; }
+      const int off = hl.bnd + (((DIR * X::kMaxW + up) * kHaloSlots + ((n - 1) & (kHaloSlots - 1))) * kHfHalo + (lane & (kHfHalo - 1))) * kLane4;
+      if constexpr (X::kF32) {
+        const h_f4 v = *(lds_f4*)(L0 + off);
+        if (halo) { Bc.x = v.x; Lc.x = v.y; Bc.y = v.z; Lc.y = v.w; }
+      } else {
+        const h_d2 u = *(lds_d2*)(L0 + off), v = *(lds_d2*)(L0 + off + 16);
+        if (halo) { Bc.x = u.x; Lc.x = u.y; Bc.y = v.x; Lc.y = v.y; }
+      }
     }
     const int tbase = block_time(DIR, n, 0, T);
     int xw = 0;
 #pragma unroll
     for (int tt = 0; tt < kBlk; tt++) {
       const int t = DIR == 0 ? tbase + tt : tbase - tt;
-      const float yb = ywraw[tt >> 1][2 * (tt & 1)], wb = ywraw[tt >> 1][2 * (tt & 1) + 1];
-      const h_f2 E = {e0raw[tt >> 2][tt & 3], e1raw[tt >> 2][tt & 3]};
+      const CT yb = ybw[2 * tt], wb = ybw[2 * tt + 1];
+      const V2 E = {e0[tt], e1[tt]};
       if (tt == 4) {
         xw = *(volatile lds_int*)(exw + 4 * (n & (kHaloSlots - 1)));
         if (want_next) need_blocks(n + 2);
@@ -1070,15 +1130,15 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
       }
       if (STEADY || t < T) {
         const bool first = !STEADY && (DIR == 0 ? t == 0 : t == T - 1);
-        const h_f2 YB = {yb_prev, yb_prev}, WB = {wb_prev, wb_prev};
+        const V2 YB = {yb_prev, yb_prev}, WB = {wb_prev, wb_prev};
         if (DIR == 0) {
           // alpha_t[j] = (alpha[j] + r*alpha[j-1] + r^2*skip*alpha[j-2]) * y_t[l_j], ctc_loss.cpp:47-60
           if (first) {
-            if (p0 == 0) { Bc.x = cond ? kOne : 0.f; Lc.x = kOne * rr2 * E.x; }     // ctc_loss.cpp:39-42
+            if (p0 == 0) { Bc.x = cond ? kOne : (CT)0; Lc.x = kOne * rr2 * E.x; }   // ctc_loss.cpp:39-42
           } else {
-            const h_f2 PL = {from_prev_lane(Lc.y), Lc.x};       // the label cell just below each pair's blank
-            const h_f2 Bn = __builtin_elementwise_fma(Bc, YB, PL);
-            h_f2 tl = __builtin_elementwise_fma(Bc, WB, Lc);
+            const V2 PL = {from_prev_lane(Lc.y), Lc.x};         // the label cell just below each pair's blank
+            const V2 Bn = __builtin_elementwise_fma(Bc, YB, PL);
+            V2 tl = __builtin_elementwise_fma(Bc, WB, Lc);
             tl = __builtin_elementwise_fma(SK, PL, tl);
             Lc = tl * E; Bc = Bn;
           }
@@ -1089,9 +1149,9 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
             if (p0 == S - 1) Lc.x = kOne * rr2 * E.x;                               // ctc_loss.cpp:78
             if (p0 + 1 == S - 1) Lc.y = kOne * rr2 * E.y;
           } else {
-            const h_f2 G = __builtin_elementwise_fma(WB, Bc, SK * Lc);      // what the label cell of the pair below takes
-            const h_f2 TK = {G.y, from_next_lane(G.x)};
-            const h_f2 Lo = Lc;
+            const V2 G = __builtin_elementwise_fma(WB, Bc, SK * Lc);        // what the label cell of the pair below takes
+            const V2 TK = {G.y, from_next_lane(G.x)};
+            const V2 Lo = Lc;
             Lc = (Lo + TK) * E;
             Bc = __builtin_elementwise_fma(Bc, YB, Lo);
           }
@@ -1099,8 +1159,8 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
         yb_prev = yb; wb_prev = wb;
         if (tt == 7) {
           // the frame (see the section's header): leave the high word of the largest cell, remove what the frame wave decided
-          const int m01 = max(__float_as_int(Bc.x), __float_as_int(Lc.x)), m23 = max(__float_as_int(Bc.y), __float_as_int(Lc.y));
-          *(volatile lds_int*)(mxl + (n & (kHaloSlots - 1)) * (kHfMaxW * 256)) = max(m01, m23);    // positive floats order like ints
+          const int m01 = max(X::top(Bc.x), X::top(Lc.x)), m23 = max(X::top(Bc.y), X::top(Lc.y));
+          *(volatile lds_int*)(mxl + (n & (kHaloSlots - 1)) * (X::kMaxW * 256)) = max(m01, m23);
           xw = __builtin_amdgcn_readfirstlane(xw);
           if ((xw >> 12) != n) {
             PROF_SPIN_BEGIN
@@ -1113,7 +1173,7 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
             PROF_SPIN_END(prof_lag)
           }
           const int ex = (xw & 0xfff) - 2048;
-          Bc.x = ldexpf(Bc.x, -ex); Bc.y = ldexpf(Bc.y, -ex); Lc.x = ldexpf(Lc.x, -ex); Lc.y = ldexpf(Lc.y, -ex);
+          Bc.x = X::scale(Bc.x, -ex); Bc.y = X::scale(Bc.y, -ex); Lc.x = X::scale(Lc.x, -ex); Lc.y = X::scale(Lc.y, -ex);
           e_total += ex;
           const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
           if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
@@ -1121,19 +1181,17 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
             // (two buffers: the checkpoint wave has 16 steps for each and is normally long done with the row before last)
             if (nck >= 2) HALO_WAIT(__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(L0 + hl.ckdone + 4 * DIR)) >= nck - 1);
             nck++;
-            const h_f2 cb = Bc * yb_prev, cl = Lc * inv_rr;
-            h_f4 o; o.x = cb.x; o.y = cl.x; o.z = cb.y; o.w = cl.y;
-            *(lds_f4*)(L0 + hl.ckb + ((((DIR * 2 + ((kk / kSeg) & 1)) * kHfMaxW + w) * 64 + lane) * 16)) = o;
+            const V2 cb = Bc * yb_prev, cl = Lc * inv_rr;
+            store4(hl.ckb + (((DIR * 2 + ((kk / kSeg) & 1)) * X::kMaxW + w) * 64 + lane) * kLane4, cb.x, cl.x, cb.y, cl.y);
           }
         }
       }
     }
     if ((n & 1) && has_down) {
       const bool edge = DIR == 0 ? lane >= 64 - kHfHalo : lane < kHfHalo;
-      if (edge) {
-        h_f4 v; v.x = Bc.x; v.y = Lc.x; v.z = Bc.y; v.w = Lc.y;
-        *(lds_f4*)(L0 + hl.bnd + (((DIR * kHfMaxW + w) * kHaloSlots + (n & (kHaloSlots - 1))) * kHfHalo + (lane & (kHfHalo - 1))) * 16) = v;
-      }
+      if (edge)
+        store4(hl.bnd + (((DIR * X::kMaxW + w) * kHaloSlots + (n & (kHaloSlots - 1))) * kHfHalo + (lane & (kHfHalo - 1))) * kLane4,
+               Bc.x, Lc.x, Bc.y, Lc.y);
     }
     *(volatile lds_int*)(prog + 4 * w) = n + 1;
   };
@@ -1185,8 +1243,10 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
 // exponent of every group of F2PPL pairs (the segment kernel's lanes), scales, and stores cells and exponents.  (First
 // given to the frame wave: that one is on the chains' critical path -- they wait for its word every block -- and the
 // extra work showed up as 20-35 cycles per step of waiting.)
-template <int DIR, int F2PPL>
+template <int DIR, int F2PPL, typename X>
 __device__ __forceinline__ void hf_ckpt_wave(const FastParams& p, int b, int T, int S, lds_u8* L0, const HfLds hl, int lane, int W, int bias) {
+  typedef typename X::T CT;
+  constexpr int kLane4 = 4 * X::kElem;
   const int nblk = (T + kBlk - 1) / kBlk;
   const int nres = DIR == 0 ? T / kBlk : nblk;       // blocks whose step 7 is live (alpha's last block may be short)
   const int M = (T - 1) >> 3;
@@ -1201,25 +1261,31 @@ __device__ __forceinline__ void hf_ckpt_wave(const FastParams& p, int b, int T, 
     if (!((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T)) continue;
     HALO_WAIT(__builtin_amdgcn_readfirstlane(lds_min8(prog)) >= n + 1);
     const int slot = kk / kSeg;
-    h_f4 cw[kHfMaxW];
+    CT cw[X::kMaxW][4];
 #pragma unroll
-    for (int w = 0; w < kHfMaxW; w++)
-      if (w < W) cw[w] = *(lds_f4*)(L0 + hl.ckb + ((((DIR * 2 + (slot & 1)) * kHfMaxW + w) * 64 + lane) * 16));
+    for (int w = 0; w < X::kMaxW; w++) {
+      if (w < W) {
+        const int off = hl.ckb + (((DIR * 2 + (slot & 1)) * X::kMaxW + w) * 64 + lane) * kLane4;
+        if constexpr (X::kF32) { const h_f4 v = *(lds_f4*)(L0 + off); cw[w][0] = v.x; cw[w][1] = v.y; cw[w][2] = v.z; cw[w][3] = v.w; }
+        else { const h_d2 u = *(lds_d2*)(L0 + off), v = *(lds_d2*)(L0 + off + 16); cw[w][0] = u.x; cw[w][1] = u.y; cw[w][2] = v.x; cw[w][3] = v.y; }
+      }
+    }
     *(volatile lds_int*)(L0 + hl.ckdone + 4 * DIR) = ++done;       // (LDS runs this wave's operations in order: the reads are done)
 #pragma unroll
-    for (int w = 0; w < kHfMaxW; w++) {
+    for (int w = 0; w < X::kMaxW; w++) {
       if (w >= W) break;
-      const h_f4 c = cw[w];
+      const CT* c = cw[w];
       const int p0 = kHfOwn * w + 2 * idx;
-      const int ma = max(__float_as_int(c.x), __float_as_int(c.y)), mb = max(__float_as_int(c.z), __float_as_int(c.w));
+      const int ma = max(X::top(c[0]), X::top(c[1])), mb = max(X::top(c[2]), X::top(c[3]));
       int m0 = ma, m1 = mb;                                           // exponent source of pair p0 / p0 + 1
       if (F2PPL >= 2) { m0 = max(ma, mb); m1 = m0; }
       if (F2PPL >= 4) { m0 = max(m0, dpp_i<0xB1>(0, m0)); m1 = m0; }  // quad_perm [1,0,3,2]: the lane pair
-      const int own0 = ((m0 >> 23) & 0xff) - 127, own1 = ((m1 >> 23) & 0xff) - 127;
+      const int own0 = X::expo(m0), own1 = X::expo(m1);
       const int st0 = m0 > 0 ? own0 - bias : -30000, st1 = m1 > 0 ? own1 - bias : -30000;     // relative to the frame
       if (own_lane && p0 < 64 * F2PPL && (p0 & ~(F2PPL - 1)) <= S) {      // (groups past the lattice are not read)
         h_f4 o;                                                       // (cells of an all-zero group stay zero whatever the exponent)
-        o.x = ldexpf(c.x, -own0); o.y = ldexpf(c.y, -own0); o.z = ldexpf(c.z, -own1); o.w = ldexpf(c.w, -own1);
+        o.x = m0 > 0 ? (float)X::scale(c[0], -own0) : 0.f; o.y = m0 > 0 ? (float)X::scale(c[1], -own0) : 0.f;
+        o.z = m1 > 0 ? (float)X::scale(c[2], -own1) : 0.f; o.w = m1 > 0 ? (float)X::scale(c[3], -own1) : 0.f;
         *reinterpret_cast<h_f4*>(ck + (size_t)slot * p.CELLS + 2 * p0) = o;
         short* cke = p.ckE + (((size_t)b * p.NS + slot) * 2 + DIR) * 64;
         if (F2PPL == 1) { cke[p0] = (short)st0; cke[p0 + 1] = (short)st1; }
@@ -1229,14 +1295,15 @@ __device__ __forceinline__ void hf_ckpt_wave(const FastParams& p, int b, int T, 
   }
 }
 
-// Waves: 0-3 = alpha0, beta0, alpha1, beta1 (SIMDs 0,2,1,3), 4,5 = alpha2, beta2, 6,7 = the frame waves, 8-13 = probability
-// rows (even: alpha side, odd: beta side), 14,15 = the checkpoint waves (15 writes the lattice description first).
-template <int PPL>
-__global__ __launch_bounds__(1024) void ctc_fast_chain_hf_kernel(FastParams p) {
+// Waves, in this order: 2 x kMaxW chain waves (alpha0, beta0, alpha1, beta1, ...: the first four on SIMDs 0,2,1,3), the two
+// frame waves, 2 x kProducers probability-row waves (alternating alpha side / beta side), the two checkpoint waves (the
+// second writes the lattice description first).
+template <int PPL, typename X>
+__global__ __launch_bounds__(X::kWaves * 64) void ctc_fast_chain_hf_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V;
-  const HfLds hl(V);
+  const HfLds hl = HfLds::of<X>(V);
 
   if (b == 0 && tid < 4) p.ctl[tid] = 0;
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
@@ -1246,45 +1313,46 @@ __global__ __launch_bounds__(1024) void ctc_fast_chain_hf_kernel(FastParams p) {
     return;
   }
   const int T = (int)Tq, S = (int)Sq;
-  constexpr int MAXW = (64 * PPL + kHfOwn - 1) / kHfOwn;          // waves that can hold a cell at this row width
+  constexpr int MAXW = (64 * PPL + kHfOwn - 1) / kHfOwn < X::kMaxW ? (64 * PPL + kHfOwn - 1) / kHfOwn : X::kMaxW;
   const int W = min(S / kHfOwn + 1, MAXW);                        // waves that hold a cell: pairs 0..S (pair S = the last blank)
   if (tid == 0) p.flags[b] = 0;
-  if (tid < 2 * kRingBlks) reinterpret_cast<int*>(smem + hl.filled)[tid] = (tid & (kRingBlks - 1)) < kHfProducers ? (tid & (kRingBlks - 1)) : 0;
+  if (tid < 2 * kRingBlks) reinterpret_cast<int*>(smem + hl.filled)[tid] = (tid & (kRingBlks - 1)) < X::kProducers ? (tid & (kRingBlks - 1)) : 0;
   if (tid < 16) reinterpret_cast<int*>(smem + hl.prog)[tid] = (tid & 7) < W ? 0 : kHaloIdle;
   if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHfLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;
   if (tid < 8) reinterpret_cast<double*>(smem + hl.zacc)[tid] = 0.0;
   if (tid < 2) reinterpret_cast<int*>(smem + hl.ckdone)[tid] = 0;
   for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
-    reinterpret_cast<float*>(smem + hl.ring + (i / kBlk) * hl.blk_bytes)[V * kRow32 + (i % kBlk)] = 0.f;
+    reinterpret_cast<typename X::T*>(smem + hl.ring + (i / kBlk) * hl.blk_bytes)[V * X::kRowElems + (i % kBlk)] = 0;
   __syncthreads();
 
+  constexpr int kChains = 2 * X::kMaxW, kFrame = kChains, kProd = kChains + 2, kCkpt = kProd + 2 * X::kProducers;
   const int wave = __builtin_amdgcn_readfirstlane(wid);
   lds_u8* L0 = (lds_u8*)smem;
-  if (wave < 6) {
+  const int bias = X::bias(fast_tilt(S, T));
+  if (wave < kChains) {
     const int d = wave & 1, w = wave >> 1;
-    if (w >= MAXW) return;
     if (w >= W) return;              // (holds no cell of this utterance; the segment kernel does not read past the lattice)
-    if (d == 0) hf_chain_wave<0, PPL>(p, b, T, S, smem, hl, lane, w, W);
-    else hf_chain_wave<1, PPL>(p, b, T, S, smem, hl, lane, w, W);
-  } else if (wave == 6) halo_frame_wave<0, true, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W, hf_bias(fast_tilt(S, T)));
-  else if (wave == 7) halo_frame_wave<1, true, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, kHfMaxW, lane, W, hf_bias(fast_tilt(S, T)));
-  else if (wave == 14) hf_ckpt_wave<0, PPL>(p, b, T, S, L0, hl, lane, W, hf_bias(fast_tilt(S, T)));
-  else if (wave == 15) {
+    if (d == 0) hf_chain_wave<0, PPL, X>(p, b, T, S, smem, hl, lane, w, W);
+    else hf_chain_wave<1, PPL, X>(p, b, T, S, smem, hl, lane, w, W);
+  } else if (wave == kFrame) halo_frame_wave<0, X::kF32, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, X::kMaxW, lane, W, bias);
+  else if (wave == kFrame + 1) halo_frame_wave<1, X::kF32, kHfLag, true>(p, b, T, L0, hl.prog, hl.exw, hl.mxl, X::kMaxW, lane, W, bias);
+  else if (wave == kCkpt) hf_ckpt_wave<0, PPL, X>(p, b, T, S, L0, hl, lane, W, bias);
+  else if (wave == kCkpt + 1) {
     cellinfo_wave<PPL>(p, b, T, S, reinterpret_cast<int*>(smem + hl.sortcnt), lane);
-    hf_ckpt_wave<1, PPL>(p, b, T, S, L0, hl, lane, W, hf_bias(fast_tilt(S, T)));
+    hf_ckpt_wave<1, PPL, X>(p, b, T, S, L0, hl, lane, W, bias);
   } else {
-    const int d = (wave - 8) & 1;                        // waves 8,10,12 -> alpha rows, 9,11,13 -> beta rows
-    const int first = (wave - 8) >> 1;                   // the producers of a direction take every kHfProducers-th block
+    const int d = (wave - kProd) & 1;                    // alternating: alpha rows, beta rows
+    const int first = (wave - kProd) >> 1;               // the producers of a direction take every kProducers-th block
     lds_u8* prog = L0 + hl.prog + d * 32;
-    const float r_tilt = fast_tilt(S, T);
-    const double rr2 = (double)(r_tilt * r_tilt);        // (the chain waves' own expression, in f32)
+    const double rr2 = (double)X::tilt2(fast_tilt(S, T));        // (the chain waves' own expression)
     unsigned char* ring = smem + hl.ring + d * kRingBlks * hl.blk_bytes;
     volatile int* fl = reinterpret_cast<int*>(smem + hl.filled) + d * kRingBlks;
-    if (V <= 16) prep_wave<2, 2>(p, b, T, d, first, kHfProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 32) prep_wave<4, 2>(p, b, T, d, first, kHfProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 48) prep_wave<6, 2>(p, b, T, d, first, kHfProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 64) prep_wave<8, 2>(p, b, T, d, first, kHfProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else prep_wave<12, 2>(p, b, T, d, first, kHfProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    constexpr int MODE = X::kF32 ? 2 : 1;
+    if (V <= 16) prep_wave<2, MODE>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 32) prep_wave<4, MODE>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 48) prep_wave<6, MODE>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else if (V <= 64) prep_wave<8, MODE>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+    else prep_wave<12, MODE>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
   }
 }
 
@@ -1807,13 +1875,27 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   // worth it there); E2E_F1_F32=1 forces them everywhere (tests)
   static const bool force_f32_chains = getenv("E2E_F1_F32") != nullptr;
   if (force_f32_chains || (p.chains == E2E_CHAINS_F32 && PPL == 4)) {
-    const HfLds hl(p.V);
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL>),
+    const HfLds hl = HfLds::of<ChainF32>(p.V);
+    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL, ChainF32>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_fast_chain_hf_kernel<PPL>, dim3(p.B), dim3(1024), hl.total, stream, p);
+    hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<PPL, ChainF32>), dim3(p.B), dim3(ChainF32::kWaves * 64), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
     FastParams q = p; q.ztol = kZTolF32;                          // (trkA / trkB: written by the frame waves)
     hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
+    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
+    return E2E_OK;
+  }
+  // f64 halo chains: two waves per direction hold 224 label pairs.  Where they win: the widest rows (158 against 166 us per
+  // step at S <= 200; at S <= 127 the single wave carries two pairs per lane itself and wins, 120 against 131 us).
+  // E2E_F1_SINGLE=1: the single-wave chains everywhere, E2E_F1_HALO=1: the halo chains wherever they fit (A/B, tests)
+  static const bool force_single = getenv("E2E_F1_SINGLE") != nullptr, force_halo = getenv("E2E_F1_HALO") != nullptr;
+  if (!force_single && (PPL == 4 || (force_halo && PPL >= 1)) && p.Smax + 1 <= ChainF64::kMaxW * kHfOwn) {
+    const HfLds hl = HfLds::of<ChainF64>(p.V);
+    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL, ChainF64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
+    hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<PPL, ChainF64>), dim3(p.B), dim3(ChainF64::kWaves * 64), hl.total, stream, p);
+    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
+    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);     // (trkA / trkB: the frame waves')
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
     return E2E_OK;
   }

@@ -132,6 +132,16 @@ def test_f32_chains_forced_for_every_row_width_match_exact():
     _variant_in_child("E2E_F1_F32", F32_CHAINS_GRAD_ATOL)
 
 
+def test_single_wave_chains_forced_for_every_row_width_match_exact():
+    """E2E_F1_SINGLE=1: the single-wave f64 chains also where the halo chains are the default (targets of 128..223 labels)."""
+    _variant_in_child("E2E_F1_SINGLE", 2e-6)
+
+
+def test_f64_halo_chains_forced_wherever_they_fit_match_exact():
+    """E2E_F1_HALO=1: the f64 halo chains for every row width up to 223 labels (default only for the widest rows)."""
+    _variant_in_child("E2E_F1_HALO", 2e-6)
+
+
 def test_flagged_utterances_are_settled_by_the_segment_redo_not_by_the_exact_kernel():
     """The headline shape with emissions that contradict the targets (logits x3): a third of the utterances leave the
     f32 segment kernel's range.  They must be redone from the chains' checkpoints in f64 (~1 ms for the batch), not by
