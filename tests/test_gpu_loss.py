@@ -415,3 +415,22 @@ def test_full_c5_shape_properties():
         g_o[k, xl[b]:] = 0.0
     U.assert_same(losses[idx], l_o, F32_RTOL, F32_ATOL, "losses")
     U.assert_same(grads[idx], g_o, F32_RTOL, 5e-7, "grads")
+
+
+@pytest.mark.parametrize("shape", [(2, 400, 500, 150), (2, 700, 29, 300), (1, 650, 3000, 300), (2, 300, 97, 120)],
+                         ids=lambda s: "B%d_T%d_V%d_S%d" % s)
+def test_shapes_outside_the_fast_paths_are_still_served(shape):
+    """Targets longer than 255 labels, or more than 95 distinct labels at an alphabet beyond 96 columns: neither the
+    small-alphabet lattice kernels nor the wide-alphabet compaction take these; the exact kernel must (no
+    E2E_ERR_UNSUPPORTED, the reference has no such bounds)."""
+    B, T, V, S = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl = torch.full((B,), T)
+    tl = torch.tensor([S] + [S // 2] * (B - 1))
+    losses, grads = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_AUTO)
+    lp = torch.log_softmax(x.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
