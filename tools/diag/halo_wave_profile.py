@@ -1,5 +1,6 @@
-# per-wave cycle accounts of the f32 halo chain kernel (instrumented library: tools/diag/build_profile_lib.sh, taken off
-# .gpurunignore for the call; run with E2E_F1_F32=1).  The wave-count classes printed are S // 56 + 1.
+# per-wave cycle accounts of the halo chain kernel (instrumented library: tools/diag/build_profile_lib.sh).  Default: the
+# f64 form at this shape; E2E_F1_F32=1: the packed-f32 form.  The wave-count classes printed are S // 56 + 1 (a wave owns
+# 112 pairs: classes 1-2 run one wave per direction, 3-4 two).
 import sys, ctypes as C, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
