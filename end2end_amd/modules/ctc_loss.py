@@ -56,13 +56,16 @@ class CTCLoss(ForwardBackwardLossBase):
     :param time_major: inputs are ``(time, batch, alphabet)``
     :param blank_idx: index of the blank label
     :param fused: fuse log-softmax into the kernel when ``after_logsoftmax`` is False
+    :param f32_chains: (extension, default off) let the lattice chains of long-target batches run in packed f32:
+        ~10 % faster at B=256, T=1000, V=29, S<=200; gradient elements within 2e-5 absolute of the reference's
+        instead of 2e-6 (``e2e_ctc_loss_opts.chains`` in include/e2e_ctc.h)
     """
 
     def __init__(self, size_average=None, reduce=None, after_logsoftmax=False, time_major=False, blank_idx=0,
-                 fused=True):
+                 fused=True, f32_chains=False):
         super().__init__(size_average, reduce, after_logsoftmax, time_major, blank_idx)
         self._fused = fused
-        self._engine = CTCLossEngine(self._blank_idx)
+        self._engine = CTCLossEngine(self._blank_idx, f32_chains=f32_chains)
 
 
 class GramCTCLoss(CTCLoss):

@@ -214,3 +214,18 @@ def test_engine_with_f32_chains_keeps_the_interface_and_the_stated_tolerance():
     U.assert_same(l1.numpy(), l0.numpy(), 2e-6, 1e-6, "losses")
     U.assert_same(g1.numpy(), g0.numpy(), 1e-4, 2e-5, "grads")
     assert not torch.equal(g0, g1)          # (a different kernel did run)
+
+
+def test_module_with_f32_chains_trains_like_the_default():
+    g = torch.Generator().manual_seed(21)
+    B, T, V, S = 3, 320, 29, 150
+    x0 = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl, tl = torch.tensor([T, T - 5, T]), torch.tensor([S, 140, 129])
+    xa = x0.clone().cuda().requires_grad_()
+    xb = x0.clone().cuda().requires_grad_()
+    la = CTCLoss(reduce=True, size_average=True)(xa, tg, xl, tl)
+    lb = CTCLoss(reduce=True, size_average=True, f32_chains=True)(xb, tg, xl, tl)
+    la.backward(); lb.backward()
+    assert abs(la.item() - lb.item()) <= 2e-6 * abs(la.item())
+    U.assert_same(xb.grad.cpu().numpy() * B, xa.grad.cpu().numpy() * B, 1e-4, 2e-5, "input grad")
