@@ -34,6 +34,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # f32 lane-operations per second (157.3 TFLOP/s / 2 flops per fma)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 WORKLOAD = dict(name="ctc_fwd_bwd_B256_T1000_V29_S200_f32", B=256, T=1000, V=29, S=200)
@@ -268,10 +269,15 @@ def decode_numbers(dev, with_cpu):
     xl = torch.full((1024,), 1500, dtype=torch.long, device=dev)
     eng = CTCDecoder(beam_width=1, blank_idx=0, keep_on_device=True)._decoder    # no labels: ids only; results stay in HBM
     dt = timed(lambda: eng.decode_greedy(x, xl), 10)
+    kms = time_events(torch, lambda: eng.decode_greedy(x, xl), 20)          # HIP events on the launch stream
     bytes_alg = 1024 * 1500 * (29 * 4 + 8)
     out["greedy"] = {"workload": "B=1024 T=1500 V=29", "utterances_per_s": 1024 / dt, "frames_per_s": 1024 * 1500 / dt,
-                     "ms": dt * 1e3, "hbm_frac_algorithmic": bytes_alg / dt / 1e9 / HBM_PEAK_GBS,
-                     "note": "wall time of the Python engine call, results left on the device"}
+                     "ms": dt * 1e3, "kernel_ms": kms,
+                     "roofline": {"bound": "hbm", "achieved": bytes_alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": bytes_alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_launch": bytes_alg,
+                                  "note": "HIP events around each engine call on its stream (mean of 20)"},
+                     "note": "ms = wall time of the Python engine call, results left on the device"}
     if with_cpu:
         xd = xh.double().numpy()
         out["greedy"]["cpu_baseline"] = cpu_timed(lambda: O.ctc_greedy(xd, None, 0, n_threads=0), 1024,
@@ -340,7 +346,7 @@ def fallback_regime_numbers(dev):
 
 def recorded_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -438,6 +444,16 @@ def main():
     # kernels only, so that the mean/all-reduce tail is not attributed to them)
     kernel_ms = time_events(torch, lambda: hp.call(hp.means[0, :1]), args.steps)
 
+    # ---- SURVEY.md 8(d)'s ragged-length variant of the same shape: x_len = randint(T//2, T+1) ------------------------------
+    gr = torch.Generator().manual_seed(2000 + rank)
+    xl_r = torch.randint(w["T"] // 2, w["T"] + 1, (w["B"],), generator=gr)
+    hpr = HotPath((dev_batch[0], dev_batch[1], xl_r.to(dev), dev_batch[3]))
+    for _ in range(max(2, args.warmup)):
+        hpr.call(hpr.means[0, :1])
+    ragged_ms = time_events(torch, lambda: hpr.call(hpr.means[0, :1]), args.steps)
+    ragged_frames = int(xl_r.sum().item())
+    del hpr
+
     # ---- the caller's option e2e_ctc_loss_opts.chains = E2E_CHAINS_F32 (not the headline: looser gradient tolerance) ---
     from end2end_amd import _lib as _lib_mod
     hp32 = HotPath(dev_batch, chains=_lib_mod.CHAINS_F32)
@@ -509,6 +525,10 @@ def main():
         algo_bytes = 2.0 * w["V"] * 4 * frames          # per launch (one GPU's batch)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         copy_gbs = measured_copy_gbs(torch, dev)
+        # the VALU bound of the recurrence: every lattice cell costs >= 4 lane-operations per direction in
+        # the chains and the same again in the segment kernel's recompute
+        cells = float((host_batch[2].double() * (2.0 * host_batch[3].double() + 1.0)).sum().item())
+        lane_ops = cells * 2 * 4 * 2
         out = {
             "metric": "ctc_fwd_bwd_frames_per_sec", "value": total_frames * args.steps / wall, "unit": "frames/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -522,13 +542,20 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": recorded_traffic(w["name"]),
                          "peak_measured": copy_gbs, "frac_of_measured": achieved / copy_gbs,
                          "kernel": "e2e_ctc_loss_fwd_bwd: every kernel of the call counted",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "valu_frac": lane_ops / (kernel_ms * 1e-3) / VALU_PEAK_LANE_OPS,
+                         "valu_note": "minimal lane-operations (lattice cells x 2 directions x 4 x 2 for the recompute = %.3g) "
+                                      "/ kernel time / %.3g lane-ops/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz, the f32 "
+                                      "vector peak of MI355X_MICROARCH.md; f64 runs at half of it)" % (lane_ops, VALU_PEAK_LANE_OPS)},
             "event_ms_per_step": ev0.elapsed_time(ev1) / args.steps,
             "module_ms_per_step": module_wall * 1e3 / args.steps,
             "module_frames_per_s": total_frames * args.steps / module_wall,
             "module_api": "loss = end2end_amd.CTCLoss(reduce=True, size_average=True)(logits, targets, lengths...); "
                           "loss.backward()  (same batch; loss %.6f vs C-ABI %.6f)" % (module_loss, c_abi_loss),
         }
+        out["ragged_lengths"] = {
+            "workload": "the headline batch with x_len = randint(T//2, T+1) (SURVEY.md 8d's ragged variant)",
+            "kernel_ms": ragged_ms, "frames": ragged_frames, "frames_per_s_per_gpu": ragged_frames / (ragged_ms * 1e-3)}
         out["f32_chains_option"] = {
             "what": "the same call with e2e_ctc_loss_opts.chains = E2E_CHAINS_F32 (lattice chains in packed f32); an option, "
                     "not the headline: gradient elements are promised to 2e-5 absolute instead of 2e-6",

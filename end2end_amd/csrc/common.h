@@ -6,6 +6,7 @@
 #include <math.h>
 
 #include "../../include/e2e_ctc.h"
+#include "../../include/e2e_ctc_debug.h"
 
 namespace e2e {
 

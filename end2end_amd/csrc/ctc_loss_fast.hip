@@ -1859,8 +1859,14 @@ __device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char*
 // the wave has to wait for its outstanding gradient stores instead of retiring under them, 65 -> 97 us for the kernel;
 // with a release fence at agent scope, which is an L2 write-back on this multi-XCD part, 411 us.  An empty launch costs
 // ~4.5 us here whatever it does, so the scan stays in the fallback launch, which also writes the optional reduction.)
+#ifndef E2E_F2_MINW                 // (both overridable for tools/diag occupancy experiments)
+#define E2E_F2_MINW 2
+#endif
+#ifndef E2E_F2_LDSPAD
+#define E2E_F2_LDSPAD 0
+#endif
 template <int PPL>
-__global__ __launch_bounds__(64, 2) void ctc_fast_segment_kernel(FastParams p) {
+__global__ __launch_bounds__(64, E2E_F2_MINW) void ctc_fast_segment_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   segment_wave<PPL>(p, smem);
 }
@@ -1870,7 +1876,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds1 = F1Lds::bytes(p.V);
   E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute");
-  const size_t lds2 = F2Lds<PPL>::bytes(p.V);
+  const size_t lds2 = F2Lds<PPL>::bytes(p.V) + E2E_F2_LDSPAD;
   // f32 chains: where the caller allows them (e2e_ctc_loss_opts.chains) and they are faster, i.e. at the widest rows
   // (145 against 165 us per step at S <= 200, but 115 / 93 against 120 / 94 us at S <= 127 / 63, with looser gradients: not
   // worth it there); E2E_F1_F32=1 forces them everywhere (tests)

@@ -16,6 +16,7 @@ which can then take it as `.grad` without a copy.  Upstream the kept gradient su
 a graph retained with `retain_graph=True` can be walked again; here a second walk finds the buffer given
 away and asks the engine for it again (same inputs, same result) -- rare, and exact.
 """
+import torch
 from torch.autograd import Function
 
 
@@ -47,9 +48,11 @@ class ForwardBackwardLossFunction(Function):
         if grads is None:          # a retained graph walked again: the first walk gave the buffer to autograd
             grads = ForwardBackwardLossFunction._compute(ctx.engine, ctx.args, ctx.fused_logits, ctx.reduction)[1]
         ctx.grads = None
-        if grads.is_cuda and grads.is_contiguous() and hasattr(ctx.engine, "scale_grads_"):
+        if (grads.is_cuda and grads.is_contiguous() and grads.dtype in (torch.float32, torch.float64)
+                and hasattr(ctx.engine, "scale_grads_")):
             ctx.engine.scale_grads_(grads, grad_output)
-        else:                      # results that were moved back to a CPU source tensor
+        else:                      # results moved back to a CPU source tensor, or to a half / bf16 source dtype (the
+                                   # in-place kernel takes f32 / f64; upstream multiplies in the source dtype as well)
             go = grad_output.contiguous().to(device=grads.device, dtype=grads.dtype)
             grads = grads * (go.view(-1, 1, 1) if go.numel() > 1 else go)
         if grads.device != grad_output.device:

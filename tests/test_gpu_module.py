@@ -229,3 +229,30 @@ def test_module_with_f32_chains_trains_like_the_default():
     la.backward(); lb.backward()
     assert abs(la.item() - lb.item()) <= 2e-6 * abs(la.item())
     U.assert_same(xb.grad.cpu().numpy() * B, xa.grad.cpu().numpy() * B, 1e-4, 2e-5, "input grad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("reduce", [False, True])
+def test_half_precision_logits_go_forward_and_backward(dtype, reduce):
+    """Raw autocast outputs: the reference casts to double and back (src/losses/forward_backward.cpp:15,55-56); here the
+    lattice runs in f32 on the up-cast logits and loss / gradient come back in the source dtype."""
+    g = torch.Generator().manual_seed(31)
+    B, T, V, S = 3, 40, 11, 7
+    x0 = torch.randn(B, T, V, generator=g).to(dtype)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl, tl = torch.tensor([T, T - 6, T]), torch.tensor([S, 4, 5])
+    x = x0.clone().cuda().requires_grad_()
+    loss = CTCLoss(reduce=reduce, size_average=True)(x, tg, xl, tl)
+    assert loss.dtype == dtype
+    w = torch.tensor([0.5, 1.0, -2.0], device="cuda", dtype=dtype)
+    (loss * 2.0 if reduce else (loss * w).sum()).backward()
+    assert x.grad.dtype == dtype and x.grad.shape == x.shape
+    lp = torch.log_softmax(x0.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0
+    want = g_o * (2.0 / B if reduce else w.float().cpu().numpy()[:, None, None])
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10            # the source dtype's rounding, twice
+    U.assert_same(x.grad.float().cpu().numpy(), want, 4 * eps, 4 * eps, "input grad")
+    got_l = loss.float().cpu().numpy()
+    U.assert_same(got_l, l_o.mean() if reduce else l_o, 4 * eps, 4 * eps, "loss")

@@ -12,7 +12,7 @@ def bind(path):
     return L
 libs = {os.path.basename(p): bind(os.path.join(root, p)) for p in sys.argv[1:]}
 d = torch.device("cuda", 0)
-B, T, V, S = 256, 1000, 29, 200
+B, T, V, S = 256, 1000, 29, int(os.environ.get("AB_S", "200"))
 gen = torch.Generator().manual_seed(0)
 x = torch.randn(B, T, V, generator=gen).to(d); tg = torch.randint(1, V, (B, S), generator=gen).to(d)
 tl = torch.randint(S // 2, S + 1, (B,), generator=gen).to(d); xl = torch.full((B,), T).to(d)

@@ -3,7 +3,7 @@ root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, root)
 import torch
 import end2end_amd._lib as _lib
-_lib.LIB_PATH = os.path.join(root, "gpurun_out_prof_lib.so")
+_lib.LIB_PATH = os.path.join(root, "build/diag/prof_lib.so")
 from end2end_amd import CTCDecoder
 d = torch.device("cuda", 0)
 labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]

@@ -1,10 +1,10 @@
-"""Per-phase cycle sums of the fast path's segment kernel (instrumented build gpurun_out_prof_lib.so)."""
+"""Per-phase cycle sums of the fast path's segment kernel (instrumented build build/diag/prof_lib.so)."""
 import sys, ctypes as C, os
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
 import numpy as np, torch
 import end2end_amd._lib as _lib
-_lib.LIB_PATH = os.path.join(root, "gpurun_out_prof_lib.so")
+_lib.LIB_PATH = os.path.join(root, "build/diag/prof_lib.so")
 L = _lib.load()
 d = torch.device("cuda", 0)
 gen = torch.Generator().manual_seed(0)

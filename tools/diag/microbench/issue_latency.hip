@@ -1,7 +1,7 @@
 // Microbenchmark (diagnostic, not part of the library): cycles per instruction of ONE wave64 on gfx950 for dependent and
 // independent streams of the instruction kinds the CTC chain kernels are made of.  Build and run on the GPU box:
-//   hipcc -O3 --offload-arch=gfx950 tools/diag/microbench/issue_latency.hip -o gpurun_out_issue_latency   (here; the binary
-//   travels with gpurun when it is taken off .gpurunignore), then on the box: ./gpurun_out_issue_latency
+//   hipcc -O3 --offload-arch=gfx950 tools/diag/microbench/issue_latency.hip -o build/diag/issue_latency   (here; the binary
+//   travels with gpurun when it is taken off .gpurunignore), then on the box: ./build/diag/issue_latency
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
