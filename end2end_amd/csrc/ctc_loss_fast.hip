@@ -421,25 +421,31 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
   bool col_live[NV];
   int64_t col_off[NV];
 #pragma unroll
-  for (int k = 0; k < NV; k++) { col_live[k] = l8 + 8 * k < V; col_off[k] = (int64_t)(l8 + 8 * k) * p.sV; }
+  for (int k = 0; k < NV; k++) { col_live[k] = l8 + 8 * k < V; col_off[k] = (int64_t)(col_live[k] ? l8 + 8 * k : 0) * p.sV; }
   unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime();
   (void)prof_spin; (void)prof_t0;
-  // the logits of block n+stride are requested before block n is worked on: an HBM miss (~1 us) would otherwise
-  // sit in front of every block
+  // The logits of a block are requested two of this wave's blocks before they are worked on: an HBM miss under load
+  // (2-4 thousand cycles) would otherwise sit in front of every block, and a chain takes ~1 000 cycles per block.  The
+  // loads are unconditional (clamped addresses; what a dead row or column reads is replaced when it is used): a
+  // conditional load becomes a branch per element and a full wait behind it.  Three register sets rotate through a loop
+  // unrolled three times, so that no set is ever copied (a copy waits for the load it copies).
   auto load_block = [&](int n, float (&out)[NV]) {
     const int t = block_time(dir, n, tt, T);
     const bool row_live = n < nblk && t < T;
     const float* xr = x + (int64_t)(row_live ? t : 0) * p.sT;
 #pragma unroll
-    for (int k = 0; k < NV; k++) out[k] = (row_live && col_live[k]) ? xr[col_off[k]] : ninf;
+    for (int k = 0; k < NV; k++) out[k] = xr[col_off[k]];
   };
-  float xv[NV];
   int consumed = 0;                 // blocks the ring's readers are known to have finished with (HALO)
   float lpmin = 0.f;                // smallest FINITE log-probability this wave has seen (alpha-side producers)
-  load_block(first, xv);
-  for (int n = first; n < nblk; n += stride) {       // this wave fills every `stride`-th block
-    float xn[NV];
-    load_block(n + stride, xn);
+  auto process = [&](int n, const float (&xraw)[NV]) {
+    if (n >= nblk) return;
+    float xv[NV];
+    {
+      const bool row_in = block_time(dir, n, tt, T) < T;
+#pragma unroll
+      for (int k = 0; k < NV; k++) xv[k] = (row_in && col_live[k]) ? xraw[k] : ninf;
+    }
     const int slot = n % kRingBlks;
     if (n >= kRingBlks) {
       PROF_SPIN_BEGIN
@@ -507,8 +513,16 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     // are there" -- the readers keep the minimum of the two in a scalar and look again only when they catch up.)
     if (MODE != 0) publish(&myfilled[first], n + stride);
     else publish(&myfilled[slot], n + 1);
-#pragma unroll
-    for (int k = 0; k < NV; k++) xv[k] = xn[k];
+  };
+  {
+    float xa[NV], xb[NV], xc[NV];
+    load_block(first, xa);
+    load_block(first + stride, xb);
+    for (int n = first; n < nblk; n += 3 * stride) {       // this wave fills every `stride`-th block
+      load_block(n + 2 * stride, xc); process(n, xa);
+      load_block(n + 3 * stride, xa); process(n + stride, xb);
+      load_block(n + 4 * stride, xb); process(n + 2 * stride, xc);
+    }
   }
   // Probabilities are f32: below ~2^-126 they are flushed, and a chain that ran through such frames carries a loss that
   // is off by the flushed amount (a symbol with log-probability -inf is exactly impossible and does not count).  Reason bit 64 ("emissions near the end of f32"): such an utterance is recomputed
@@ -947,8 +961,9 @@ typedef __attribute__((address_space(3))) h_f4 lds_f4;
 
 // The two arithmetics of the halo chains.  Both hold two label pairs per lane as B = (B0, B1), L = (L0, L1).
 //   ChainF32: packed instructions, 3 waves per direction at most (any S <= 255), 3 producers per direction, 16 waves.
-//   ChainF64: the same structure in f64 -- the default for targets of 64..223 labels: every result as the single-wave
-//             chains give it (same recurrence, same f64 cells; powers of two apart), 2 waves per direction, 14 waves.
+//   ChainF64: the same structure in f64 -- the default for targets of 128..223 labels: every result as the single-wave
+//             chains give it (same recurrence, same f64 cells; powers of two apart), 2 waves per direction, 2 producers
+//             per direction, 12 waves.
 struct ChainF32 {
   typedef float T; typedef h_f2 V2;
   static constexpr bool kF32 = true;
@@ -963,7 +978,10 @@ struct ChainF32 {
 struct ChainF64 {
   typedef double T; typedef h_d2 V2;
   static constexpr bool kF32 = false;
-  static constexpr int kMaxW = 2, kProducers = 3, kRowElems = kRow, kElem = 8;      // (three waves per direction: 174
+#ifndef E2E_F64_PRODUCERS             // Two producers per direction: 12 waves, i.e. three per SIMD and 168 registers for the chain
+#define E2E_F64_PRODUCERS 2           // waves' paired interior loop (with three producers -- 14 waves, 128 registers -- that loop
+#endif                                // spills in the beta wave: 155 against 131 us per step at the headline shape)
+  static constexpr int kMaxW = 2, kProducers = E2E_F64_PRODUCERS, kRowElems = kRow, kElem = 8;      // (three waves per direction: 174
                                                                                        //  against 167 us at S in [200, 255] -- six chain waves on four SIMDs)
   static constexpr int kWaves = 2 * kMaxW + 2 + 2 * kProducers + 2;
   __device__ static int top(double v) { return __double2hiint(v); }
@@ -1102,11 +1120,16 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
     else { h_d2 u, v; u.x = x0; u.y = x1; v.x = x2; v.y = x3; *(lds_d2*)(L0 + off) = u; *(lds_d2*)(L0 + off + 16) = v; }
   };
 
-  auto run_block = [&](int n, auto steady_tag) {
+  // PAR / CK: the block's parity and whether it ends in a checkpoint row, where the caller knows them at compile time
+  // (the interior loop below: an in-order wave pays ~5 cycles for every scalar test and index computation as well, and
+  // there were a hundred of those per block); -1: decided here.
+  int ckbuf = 0;                                   // which of the two checkpoint buffers the next row goes to
+  auto run_block = [&](int n, auto steady_tag, auto par_tag, auto ck_tag) {
     constexpr bool STEADY = decltype(steady_tag)::value;
+    constexpr int PAR = decltype(par_tag)::value, CK = decltype(ck_tag)::value;
     load_half(n, std::integral_constant<int, 1>{});
-    const bool want_next = n + 1 < nblk;
-    if (n > 0 && (n & 1) == 0 && has_up) {          // the halo lasts two blocks
+    const bool want_next = PAR >= 0 ? true : n + 1 < nblk;
+    if (PAR >= 0 ? (PAR == 0 && has_up) : (n > 0 && (n & 1) == 0 && has_up)) {          // the halo lasts two blocks
       { PROF_SPIN_BEGIN HALO_WAIT(__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(prog + 4 * up)) >= n); PROF_SPIN_END(prof_nb) }
       const int off = hl.bnd + (((DIR * X::kMaxW + up) * kHaloSlots + ((n - 1) & (kHaloSlots - 1))) * kHfHalo + (lane & (kHfHalo - 1))) * kLane4;
       if constexpr (X::kF32) {
@@ -1177,18 +1200,20 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
           Bc.x = X::scale(Bc.x, -ex); Bc.y = X::scale(Bc.y, -ex); Lc.x = X::scale(Lc.x, -ex); Lc.y = X::scale(Lc.y, -ex);
           e_total += ex;
           const int kk = DIR == 0 ? (t + 1) : t;            // alpha row 16k-1 / beta row 16k -> slot k
-          if ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T) {
+          if (CK >= 0 ? CK == 1 : ((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T)) {
             // the true cells (blank with its emission, label without the tilt); the frame wave converts and stores them
             // (two buffers: the checkpoint wave has 16 steps for each and is normally long done with the row before last)
             if (nck >= 2) HALO_WAIT(__builtin_amdgcn_readfirstlane(*(volatile lds_int*)(L0 + hl.ckdone + 4 * DIR)) >= nck - 1);
             nck++;
             const V2 cb = Bc * yb_prev, cl = Lc * inv_rr;
-            store4(hl.ckb + (((DIR * 2 + ((kk / kSeg) & 1)) * X::kMaxW + w) * 64 + lane) * kLane4, cb.x, cl.x, cb.y, cl.y);
+            if (CK < 0) ckbuf = (kk / kSeg) & 1;
+            store4(hl.ckb + (((DIR * 2 + ckbuf) * X::kMaxW + w) * 64 + lane) * kLane4, cb.x, cl.x, cb.y, cl.y);
+            ckbuf ^= 1;
           }
         }
       }
     }
-    if ((n & 1) && has_down) {
+    if (PAR >= 0 ? (PAR == 1 && has_down) : ((n & 1) && has_down)) {
       const bool edge = DIR == 0 ? lane >= 64 - kHfHalo : lane < kHfHalo;
       if (edge)
         store4(hl.bnd + (((DIR * X::kMaxW + w) * kHaloSlots + (n & (kHaloSlots - 1))) * kHfHalo + (lane & (kHfHalo - 1))) * kLane4,
@@ -1197,13 +1222,33 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
     *(volatile lds_int*)(prog + 4 * w) = n + 1;
   };
   {
+    typedef std::integral_constant<int, -1> Any;
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
     need_blocks(1);
     load_half(0, std::integral_constant<int, 0>{});
     const int steady_end = DIR == 0 ? T / kBlk : nblk;         // blocks [1, steady_end) are steady
-    run_block(0, std::false_type{});
+    run_block(0, std::false_type{}, Any{}, Any{});
     int n = 1;
-    for (; n < steady_end; n++) run_block(n, std::true_type{});
-    for (; n < nblk; n++) run_block(n, std::false_type{});
+#ifndef E2E_F1_FAST_DIRS             // bit 0: alpha, bit 1: beta (tools/diag A/B)
+#define E2E_F1_FAST_DIRS 3
+#endif
+#ifndef E2E_F1_PLAIN_LOOP
+    // Interior blocks in pairs (even block, odd block) with everything that depends on the block's parity resolved at
+    // compile time.  alpha: blocks 1 .. (T-1)/8 - 1, a checkpoint row (t = 16k-1) ends every odd block; beta: blocks
+    // 1 .. M-1, M = (T-1)/8, a checkpoint row (t = 16k) ends the blocks of M's parity.
+    const int fast_end = (T - 1) >> 3;
+    if (fast_end - n >= 3 && ((E2E_F1_FAST_DIRS >> DIR) & 1)) {
+      run_block(n, std::true_type{}, Any{}, Any{}); n++;      // (n = 2 now)
+      if (DIR == 0 || (((T - 1) >> 3) & 1)) {
+        for (; n + 1 < fast_end; n += 2) { run_block(n, std::true_type{}, I0{}, I0{}); run_block(n + 1, std::true_type{}, I1{}, I1{}); }
+      } else {
+        for (; n + 1 < fast_end; n += 2) { run_block(n, std::true_type{}, I0{}, I1{}); run_block(n + 1, std::true_type{}, I1{}, I0{}); }
+      }
+    }
+#endif
+    for (; n < steady_end; n++) run_block(n, std::true_type{}, Any{}, Any{});
+    for (; n < nblk; n++) run_block(n, std::false_type{}, Any{}, Any{});
   }
 #ifdef E2E_FAST_PROFILE
   if (lane == 0 && b < 256) { unsigned long long* g = g_prof3 + ((size_t)b * 16 + DIR * 8 + w) * 4;
@@ -1360,7 +1405,20 @@ __global__ __launch_bounds__(X::kWaves * 64) void ctc_fast_chain_hf_kernel(FastP
 // ============================================================================================
 // F2: one wave per (utterance, 16-step segment)
 // ============================================================================================
+#ifndef E2E_F2_ABL                  // tools/diag: timing builds with parts of the segment kernel switched off (results meaningless)
+#define E2E_F2_ABL 0
+#endif
 constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before they are summed and written out
+// Between the segment wave's LDS phases (scatter -> scan -> per-label reads -> next half's scatter).  The LDS executes one
+// wave's operations in order, so a read issued after a write of the same wave sees it without a wait; only the compiler has
+// to keep the order.  (E2E_F2_DRAIN: the full drain this used to be, for A/B.)
+#if defined(E2E_F2_DRAIN)
+#define F2_LDS_ORDER asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#elif defined(E2E_F2_NOFENCE)
+#define F2_LDS_ORDER
+#else
+#define F2_LDS_ORDER asm volatile("" ::: "memory");
+#endif
 #ifndef E2E_SMIN                    // (both overridable for tools/diag experiments)
 #define E2E_SMIN 0x1p-120f         // smallest row sum sum_j alpha*beta the gradient rows are trusted with
 #endif
@@ -1388,7 +1446,7 @@ struct F2Lds {
     ys = Ps + kHalf * PROW;
     starts = reinterpret_cast<int*>(ys + kYs * (V + 1));
   }
-  static size_t bytes(int V) { return sizeof(float) * (4 + kHalf * PROW + kYs * (V + 1)) + sizeof(int) * 130; }
+  __host__ __device__ static size_t bytes(int V) { return sizeof(float) * (4 + kHalf * PROW + kYs * (V + 1)) + sizeof(int) * 130; }
 };
 
 // The gradient rows are written one lane per label (two labels per lane beyond 64 columns): what a lane needs about
@@ -1416,12 +1474,15 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
   constexpr int PROW = F2Lds<PPL>::PROW;
   const int V = p.V;
   const int rows = FULL ? kHalf : min(kHalf, n - h * kHalf);      // live rows of this half (>= 1)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  F2_LDS_ORDER
   // prefix sums over the label-sorted cells, totals, s_t = sum_j alpha_t[j]*beta_t[j]
   float btot8[kHalf];                     // blank cells: the lanes' partial sums never went through the LDS
   wave_sum8(pb, btot8, lane);
   float st8[kHalf];                       // (wave-uniform)
-  {
+  if (E2E_F2_ABL & 1) {
+#pragma unroll
+    for (int k = 0; k < kHalf; k++) st8[k] = btot8[k] + 1.f;
+  } else {
     float c[kHalf][PPL], inc[kHalf];
 #pragma unroll
     for (int k = 0; k < kHalf; k++) {
@@ -1449,7 +1510,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
   // part): log2(st) + u must equal zt2's fraction.  Cells that mattered but were flushed -- too few bits in the f32
   // checkpoints, a recomputed row sinking below the lane's unit -- only ever LOWER the sum, so the deviation bounds
   // the posterior mass the row lost.  (Rounding alone: < 1e-6, measured over the fuzz sweeps.)  Lane k checks row k.
-  {
+  if (!(E2E_F2_ABL & 4)) {
     float my_st = 1.f;
 #pragma unroll
     for (int k = 0; k < kHalf; k++) my_st = lane == k ? st8[k] : my_st;
@@ -1465,7 +1526,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
     if (__any(bad)) smin = 0.f;
     if (__any(live && !(my_st < __builtin_huge_valf()))) smax = __builtin_huge_valf();
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  F2_LDS_ORDER
   F2_STAMP(5)
   // gradient rows: y - posterior (d loss/d logits in fused mode; exp(lp) - posterior otherwise).  Lane v writes column
   // v of every row: its label's slots, its row of the probability tile and whether it is the blank are the same for
@@ -1474,7 +1535,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
   const int nsets = V > 64 ? 2 : 1;
 #pragma unroll
   for (int s = 0; s < 2; s++) {
-    if (s < nsets) {
+    if (s < nsets && !(E2E_F2_ABL & 2)) {
       const int v = lane + 64 * s;
       const float* pre_hi = lds.Ps + gl.hi[s];
       const float* pre_lo = lds.Ps + gl.lo[s];
@@ -1489,7 +1550,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
       }
     }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Ps is rewritten by the next half
+  F2_LDS_ORDER   // Ps is rewritten by the next half
 }
 
 // what a segment needs from F1's workspace besides the probabilities; requested before the tile is staged so that
@@ -1749,6 +1810,181 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
   }
 }
 
+
+// The segment body for four pairs per lane with the recurrences in PACKED f32 (v_pk_fma_f32 / v_pk_mul_f32).  A lane's
+// pairs 0..3 are held as two groups, A = pairs (0, 2) and B = pairs (1, 3), each as packed registers of blank and label
+// cells: BA = (B0, B2), LA = (L0, L2), BB = (B1, B3), LB = (L1, L3).  With that split the neighbour a pair takes from is,
+// for one of the groups, simply the other group's register (alpha: pairs 1, 3 take from pairs 0, 2; beta: pairs 0, 2 take
+// from pairs 1, 3), and for the other group one DPP move and one plain move assemble it.  The emission factors stay
+// scalar multiplies (a lane's labels sit in different rows of the probability tile).  Same arithmetic as segment_body,
+// cell for cell; 14 + 21 vector instructions per row instead of 22 + 30.
+template <bool FULL>
+__device__ __forceinline__ void segment_body_pk(const FastParams& p, int b, int seg, int T, int S, int n,
+                                                const LaneCells<4>& lc, const int (&rank)[4], const SegIn<4>& in,
+                                                const F2Lds<4>& lds, const GradLanes& gl, int lane, float& smin, float& smax) {
+  constexpr int PPL = 4, NC = 8;
+  constexpr int kSlope = 3 * NC;
+  constexpr int PROW = F2Lds<PPL>::PROW;
+  const int blank = p.blank, L = 2 * S + 1, t0 = seg * kSeg;
+  const float* ys = lds.ys;
+  float* Ps = lds.Ps;
+  const float rr = lc.r;
+  const bool cond = (T > 1 || L == 1);
+  const int eA7 = in.eA7, eA15 = in.eA15, eB0 = in.eB0, eB8 = in.eB8;
+  const h_f2 RR = {rr, rr};
+  const h_f2 SKPA = {lc.skp[0], lc.skp[2]}, SKPB = {lc.skp[1], lc.skp[3]};
+  const h_f2 SKNA = {lc.skn[0], lc.skn[2]}, SKNB = {lc.skn[1], lc.skn[3]};
+  // a power-of-two rescale of the lane's eight cells: one packed multiply per register while the factor is a normal f32
+  // (branch-free, so that a half's rows stay one basic block: 2^-e as two factors, exact for every |e| <= 252 -- beyond
+  //  that an f32 cell is 0 or infinite either way)
+  auto rescale = [](h_f2& x0, h_f2& x1, h_f2& x2, h_f2& x3, int e) {
+    e = max(min(e, 252), -252);
+    const int e1 = e / 2, e2 = e - e1;
+    const float f1 = __int_as_float((127 - e1) << 23), f2 = __int_as_float((127 - e2) << 23);
+    const h_f2 F1 = {f1, f1}, F2 = {f2, f2};
+    x0 = (x0 * F1) * F2; x1 = (x1 * F1) * F2; x2 = (x2 * F1) * F2; x3 = (x3 * F1) * F2;
+  };
+
+  // ---- alpha rows of the segment, kept in registers ----
+  h_f2 ABA[kSeg], ALA[kSeg], ABB[kSeg], ALB[kSeg];
+  h_f2 BA = {0.f, 0.f}, LA = {0.f, 0.f}, BB = {0.f, 0.f}, LB = {0.f, 0.f};
+  int eA = 0;
+  if (seg != 0) {
+    const int own = in.ownA;
+    const bool nz = own > -30000;                       // (see segment_body for the slope-limited lane units)
+    const int pmax = wave_scan_max(nz ? own + kSlope * lane : -0x20000000);
+    const int mstar = wave_scan_max(nz ? lane : -1);
+    eA = mstar >= 0 ? pmax - kSlope * mstar : own;
+    const int sh = max(own - eA, -200);
+    BA.x = ldexpf(in.a[0], sh); LA.x = ldexpf(in.a[1], sh); BB.x = ldexpf(in.a[2], sh); LB.x = ldexpf(in.a[3], sh);
+    BA.y = ldexpf(in.a[4], sh); LA.y = ldexpf(in.a[5], sh); BB.y = ldexpf(in.a[6], sh); LB.y = ldexpf(in.a[7], sh);
+  }
+  float fA, fB;
+  {
+    const int ep = __shfl_up(eA, 1, 64), en = __shfl_down(eA, 1, 64);
+    fA = lane > 0 ? ldexpf(1.f, max(min(ep - eA, 126), -126)) : 0.f;
+    fB = lane < 63 ? ldexpf(1.f, max(min(eA - en, 126), -126)) : 0.f;
+  }
+  F2_STAMP(1)
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4* ylab[PPL];
+#pragma unroll
+  for (int r = 0; r < PPL; r++) ylab[r] = reinterpret_cast<const f4*>(ys + lc.lab[r] * kYs);
+  const f4* yblank = reinterpret_cast<const f4*>(ys + blank * kYs);
+  f4 e4[PPL], b4;
+
+#pragma unroll
+  for (int tt = 0; tt < kSeg; tt++) {
+    if ((tt & 3) == 0) {
+      b4 = yblank[tt >> 2];
+#pragma unroll
+      for (int r = 0; r < PPL; r++) e4[r] = ylab[r][tt >> 2];
+    }
+    if ((FULL || tt < n) && !(E2E_F2_ABL & 16)) {
+      const float yb = b4[tt & 3];
+      if (!FULL && t0 + tt == 0) {
+        BA = h_f2{0.f, 0.f}; LA = BA; BB = BA; LB = BA;
+        if (lane == 0) { BA.x = cond ? yb : 0.f; LA.x = rr * e4[0][tt & 3]; }
+      } else {
+        h_f2 PLA;                                        // the label cell below pairs 0 and 2
+        PLA.x = from_prev_lane(LB.y) * fA; PLA.y = LB.x;
+        const h_f2 YB = {yb, yb};
+        const h_f2 nBA = (BA + RR * PLA) * YB;
+        const h_f2 uA = LA + RR * BA + SKPA * PLA;
+        const h_f2 nBB = (BB + RR * LA) * YB;             // (pairs 1, 3 take from pairs 0, 2)
+        const h_f2 uB = LB + RR * BB + SKPB * LA;
+        BA = nBA; BB = nBB;
+        LA.x = uA.x * e4[0][tt & 3]; LA.y = uA.y * e4[2][tt & 3];
+        LB.x = uB.x * e4[1][tt & 3]; LB.y = uB.y * e4[3][tt & 3];
+      }
+      if ((tt & 7) == 7) rescale(BA, LA, BB, LB, tt == 7 ? eA7 : eA15);
+    }
+    ABA[tt] = BA; ALA[tt] = LA; ABB[tt] = BB; ALB[tt] = LB;
+  }
+
+  F2_STAMP(2)
+  // ---- beta backwards through the segment, posteriors, per-label accumulation (see segment_body) ----
+  h_f2 qBA = {0.f, 0.f}, qLA = qBA, qBB = qBA, qLB = qBA;
+  const bool last_seg = (t0 + n == T);
+  float end_unit = 1.f;
+  int unit_exp = 0;
+  if (FULL || !last_seg) {
+    const int ownB = in.ownB;
+    float a_end = fmaxf(fmaxf(fmaxf(ABA[kSeg - 1].x, ABA[kSeg - 1].y), fmaxf(ALA[kSeg - 1].x, ALA[kSeg - 1].y)),
+                        fmaxf(fmaxf(ABB[kSeg - 1].x, ABB[kSeg - 1].y), fmaxf(ALB[kSeg - 1].x, ALB[kSeg - 1].y)));
+    const int e_end = a_end >= 0x1p-120f ? (int)((__float_as_uint(a_end) >> 23) & 0xffu) - 127 : -200;
+    const int emax = wave_max(eA + ownB + e_end);
+    unit_exp = emax;
+    const int want = eA + ownB - emax;
+    const int sh = min(max(want, -200), 120);
+    float q_any = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; k++) q_any = fmaxf(q_any, in.q[k]);
+    if (__any(want > 120 && q_any > 0.f)) smax = __builtin_huge_valf();
+    qBA.x = ldexpf(in.q[0], sh); qLA.x = ldexpf(in.q[1], sh); qBB.x = ldexpf(in.q[2], sh); qLB.x = ldexpf(in.q[3], sh);
+    qBA.y = ldexpf(in.q[4], sh); qLA.y = ldexpf(in.q[5], sh); qBB.y = ldexpf(in.q[6], sh); qLB.y = ldexpf(in.q[7], sh);
+  } else {
+    const int eA_ref = __shfl(eA, (L - 1) / NC, 64);          // lane holding cell L-1
+    end_unit = ldexpf(1.f, max(min(eA - eA_ref, 126), -126));
+    unit_exp = eA_ref;
+  }
+  F2_STAMP(3)
+#pragma unroll
+  for (int h = kSeg / kHalf - 1; h >= 0; h--) {
+    if (!FULL && h * kHalf >= n) continue;
+    float pb[kHalf];
+#pragma unroll
+    for (int k = 0; k < kHalf; k++) pb[k] = 0.f;
+#pragma unroll
+    for (int k = kHalf - 1; k >= 0; k--) {
+      const int tt = h * kHalf + k;
+      if ((tt & 3) == 3) {
+        b4 = yblank[tt >> 2];
+#pragma unroll
+        for (int r = 0; r < PPL; r++) e4[r] = ylab[r][tt >> 2];
+      }
+      if (FULL || tt < n) {
+        const int t = t0 + tt;
+        const float yb = b4[tt & 3];
+        h_f2 bsBA, bsLA, bsBB, bsLB;                     // beta_t[j] (no emission at t)
+        if (E2E_F2_ABL & 8) { bsBA = qBA; bsLA = qLA; bsBB = qBB; bsLB = qLB; }
+        else if (!FULL && t == T - 1) {
+          const int i0 = PPL * lane;
+          bsBA.x = (2 * i0 == L - 1 && cond) ? end_unit : 0.f;           bsLA.x = (2 * i0 + 1 == L - 2) ? rr * end_unit : 0.f;
+          bsBB.x = (2 * (i0 + 1) == L - 1 && cond) ? end_unit : 0.f;     bsLB.x = (2 * (i0 + 1) + 1 == L - 2) ? rr * end_unit : 0.f;
+          bsBA.y = (2 * (i0 + 2) == L - 1 && cond) ? end_unit : 0.f;     bsLA.y = (2 * (i0 + 2) + 1 == L - 2) ? rr * end_unit : 0.f;
+          bsBB.y = (2 * (i0 + 3) == L - 1 && cond) ? end_unit : 0.f;     bsLB.y = (2 * (i0 + 3) + 1 == L - 2) ? rr * end_unit : 0.f;
+        } else {
+          h_f2 NB, NL;                                   // the pair above pairs 1 and 3: pair 2, the next lane's pair 0
+          NB.x = qBA.y; NB.y = from_next_lane(qBA.x) * fB;
+          NL.x = qLA.y; NL.y = from_next_lane(qLA.x) * fB;
+          bsLA = qLA + RR * qBB + SKNA * qLB;             // (pairs 0, 2 take from pairs 1, 3)
+          bsBA = qBA + RR * qLA;
+          bsLB = qLB + RR * NB + SKNB * NL;
+          bsBB = qBB + RR * qLB;
+        }
+        // alpha*beta of this lane's cells: label cells go to their label-sorted slot, blank cells are pre-summed
+        const h_f2 pbl = ABA[tt] * bsBA + ABB[tt] * bsBB;
+        pb[k] = pbl.x + pbl.y;
+        const h_f2 PA = ALA[tt] * bsLA, PB = ALB[tt] * bsLB;
+        Ps[k * PROW + rank[0]] = PA.x; Ps[k * PROW + rank[1]] = PB.x;
+        Ps[k * PROW + rank[2]] = PA.y; Ps[k * PROW + rank[3]] = PB.y;
+        // q_t = beta_t * y_t
+        const h_f2 YB = {yb, yb};
+        qBA = bsBA * YB; qBB = bsBB * YB;
+        qLA.x = bsLA.x * e4[0][tt & 3]; qLA.y = bsLA.y * e4[2][tt & 3];
+        qLB.x = bsLB.x * e4[1][tt & 3]; qLB.y = bsLB.y * e4[3][tt & 3];
+        if ((tt & 7) == 0) rescale(qBA, qLA, qBB, qLB, tt == 0 ? eB0 : eB8);
+      }
+    }
+    F2_STAMP(4)
+    const int ea_lo = in.EA0 + (h ? eA7 : 0), eb = in.EB16 + (h ? 0 : eB8);
+    const int u_lo = unit_exp + ea_lo + eb - in.zint, u_hi = u_lo + (h ? eA15 : eA7);
+    finish_rows<PPL, FULL>(p, b, t0, n, h, lds, gl, pb, lane, smin, smax, u_lo, u_hi, in.zfrac);
+    F2_STAMP(6)
+  }
+}
+
 template <int PPL>
 __device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char* smem) {
   const int b = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
@@ -1808,7 +2044,7 @@ __device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char*
   if (lane < kYs) lds.ys[V * kYs + lane] = 0.f;                           // the zero row V
   if (n < kSeg)
     for (int i = lane; i < kYs * V; i += 64) lds.ys[i] = 0.f;            // dead steps of a short last segment
-  {
+  if (!(E2E_F2_ABL & 32)) {
     // scatter the rows into the transposed tile
     const int count = n * V;
     const unsigned magic = (1u << 20) / (unsigned)V + 1u;                // idx / V for idx < 2^20 / V
@@ -1827,12 +2063,18 @@ __device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char*
     }
   }
   if (lane < kHalf) lds.Ps[lane * F2Lds<PPL>::PROW - 1] = 0.f;           // the rows' zero guards
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged rows visible to this (single) wave
+  F2_LDS_ORDER   // staged rows visible to this (single) wave
   GradLanes gl;
   gl.init(lds, V, p.blank, lane);
   F2_STAMP(0)
   float smin = __builtin_huge_valf(), smax = 0.f;
   const bool full = __builtin_amdgcn_readfirstlane((seg > 0 && n == kSeg && t0 + n < T) ? 1 : 0) != 0;
+#ifndef E2E_F2_SCALAR                // (the scalar body for every width: tools/diag A/B)
+  if constexpr (PPL == 4) {
+    if (full) segment_body_pk<true>(p, b, seg, T, S, n, lc, rank, in, lds, gl, lane, smin, smax);
+    else segment_body_pk<false>(p, b, seg, T, S, n, lc, rank, in, lds, gl, lane, smin, smax);
+  } else
+#endif
   if (full) segment_body<PPL, true>(p, b, seg, T, S, n, lc, rank, in, lds, gl, lane, smin, smax);
   else segment_body<PPL, false>(p, b, seg, T, S, n, lc, rank, in, lds, gl, lane, smin, smax);
 #ifdef E2E_FAST_PROFILE
@@ -1871,6 +2113,230 @@ __global__ __launch_bounds__(64, E2E_F2_MINW) void ctc_fast_segment_kernel(FastP
   segment_wave<PPL>(p, smem);
 }
 
+// The segment kernel for four pairs per lane as PERSISTENT waves: G waves per utterance, wave g takes segments g, g+G, ...
+// A one-segment wave spends a third of its life waiting for its inputs (the launch, the kernel arguments, one memory round
+// trip: ~2.5 us of ~8, with only two such waves on a SIMD to cover for each other -- tools/diag ablation builds: the kernel
+// with all arithmetic removed still takes 20 of its 57 us).  Here the utterance's lattice description is read once per
+// wave, and a segment's inputs -- probability rows, both checkpoint rows, their exponents, the rescale exponents -- are
+// requested one segment AHEAD by LDS-DMA (global_load_lds: no destination registers; a register prefetch needs ~40 on top
+// of a kernel that runs at 240 and spills -- tried twice).  The staging buffer is single: a segment moves its inputs from
+// the buffer to registers / the transposed tile first, then the next segment's loads are issued into the same bytes.
+struct F2Stage {                    // byte offsets inside the staging buffer (1 KiB = one 16-byte wave-instruction)
+  static constexpr int kA = 0, kQ = 2048, kE = 4096, kI = 4352, kTile = 4608;
+  __host__ __device__ static int tile_chunks(int V) { return (kSeg * V + 3 + 255) / 256; }
+  __host__ __device__ static int bytes(int V) { return kTile + 1024 * tile_chunks(V); }
+};
+typedef __attribute__((address_space(1))) const void gl_cvoid;
+__device__ __forceinline__ void glds16(const void* g, lds_u8* l) { __builtin_amdgcn_global_load_lds((gl_cvoid*)g, l, 16, 0, 0); }
+__device__ __forceinline__ void glds4(const void* g, lds_u8* l) { __builtin_amdgcn_global_load_lds((gl_cvoid*)g, l, 4, 0, 0); }
+
+template <int NT>
+__device__ __forceinline__ void segment_wave_persistent(const FastParams& p, unsigned char* smem) {
+  constexpr int PPL = 4;
+  const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x, lane = threadIdx.x;
+  const int V = p.V, Tmax = p.T;
+  const F2Lds<PPL> lds(smem, V);
+  lds_u8* stage = (lds_u8*)smem + ((F2Lds<PPL>::bytes(V) + 15) & ~(size_t)15);
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) f4 lds_f4v;
+  F2_STAMP(-1)
+  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
+  unsigned w[PPL];
+  {
+    const unsigned* ci = p.cinfo + (size_t)b * (p.CELLS / 2) + PPL * lane;
+#pragma unroll
+    for (int r = 0; r < PPL; r++) w[r] = ci[r];
+  }
+  const int* ls = p.lstart + (size_t)b * 130;
+  const int s0 = ls[lane], s1 = ls[64 + lane], s2 = ls[128 + (lane & 1)];
+  const double zt2 = p.zt2[b];
+  // LDS-DMA requests for one segment's inputs (addresses depend on nothing that is loaded: they can go out at once)
+  auto request = [&](int seg) {
+    const int t0 = seg * kSeg;
+    const size_t g0 = ((size_t)b * Tmax + t0) * V;
+    const float* src = p.ytab + (g0 & ~(size_t)3);
+    const int skew = (int)(g0 & 3);
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+      if (4 * 64 * j < kSeg * V + skew) glds16(src + 4 * (64 * j + lane), stage + F2Stage::kTile + 1024 * j);     // (uniform test)
+    const float* ra = p.ckA + ((size_t)b * p.NS + seg) * p.CELLS + lane * 2 * PPL;           // (row 0: never used)
+    glds16(ra, stage + F2Stage::kA); glds16(ra + 4, stage + F2Stage::kA + 1024);
+    const int segq = seg + 1 < p.NS ? seg + 1 : seg;                                          // (no row past the last: unused)
+    const float* rq = p.ckQ + ((size_t)b * p.NS + segq) * p.CELLS + lane * 2 * PPL;
+    glds16(rq, stage + F2Stage::kQ); glds16(rq + 4, stage + F2Stage::kQ + 1024);
+    // exponents of the two rows: 64 shorts each, lanes 0..31 fetch the alpha row's, lanes 32..63 the beta row's
+    const short* re = p.ckE + (lane < 32 ? (((size_t)b * p.NS + seg) * 2 + 0) * 64 : (((size_t)b * p.NS + segq) * 2 + 1) * 64) + 2 * (lane & 31);
+    glds4(re, stage + F2Stage::kE);
+    // the eight rescale words: cumA[i], cumB[i+2], trkA[i..i+2], trkB[i..i+2], i = t0/8 (lanes 8.. fetch copies)
+    const int k = lane & 7;
+    const int* base = k == 0 ? p.cumA : k == 1 ? p.cumB : k < 5 ? p.trkA : p.trkB;
+    const int off = k == 0 ? 0 : k == 1 ? 2 : k < 5 ? k - 2 : k - 5;
+    glds4(base + (size_t)b * p.NB + (t0 >> 3) + off, stage + F2Stage::kI);
+  };
+  // This wave's segments are g, g+G, ...  Interior ones (16 live steps, neither t = 0 nor t = T-1 inside: segments
+  // 1 .. (T-17)/16) go through the prefetching loop below with the guard-free body; the utterance's first and last live
+  // segments and the frames past its end are done first, one at a time with plain loads (at most a few per utterance, and
+  // kept out of the loop: with both bodies inside it the kernel spills).
+  if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
+  const int T = (int)Tq, S = (int)Sq;
+  const int last_full = T >= 33 ? (T - 17) / kSeg : 0;          // (0: none)
+  int seg = g >= 1 ? g : G;                                      // this wave's first interior segment, if <= last_full
+  if (seg <= last_full) request(seg);
+
+  LaneCells<PPL> lc;
+  int rank[PPL];
+  lc.unpack(w, S, T, rank);
+  lds.starts[lane] = s0; lds.starts[64 + lane] = s1; if (lane < 2) lds.starts[128 + lane] = s2;
+  if (lane < kYs) lds.ys[V * kYs + lane] = 0.f;                           // the zero row V
+  if (lane < kHalf) lds.Ps[lane * F2Lds<PPL>::PROW - 1] = 0.f;           // the rows' zero guards
+  F2_LDS_ORDER
+  GradLanes gl;
+  gl.init(lds, V, p.blank, lane);
+  float smin = __builtin_huge_valf(), smax = 0.f;
+  const unsigned magic = (1u << 20) / (unsigned)V + 1u;                  // idx / V for idx < 2^20 / V
+  const bool in_lattice = lane * 2 * PPL <= 2 * S;                       // (the chains store no cells past the lattice's 2S+1)
+
+  // ---- the edge segments of this wave: 0 (if g == 0) and those from (T-1)/16 on ----
+  for (int es = g; es < p.NS; es += G) {
+    if (es >= 1 && es <= last_full) continue;
+    const int t0 = es * kSeg;
+    if (t0 < T) {
+      const int n = min(t0 + kSeg, T) - t0;
+      f4 tile[NT];
+      const size_t g0 = ((size_t)b * Tmax + t0) * V;
+      const int skew = (int)(g0 & 3);
+      {
+        const f4* src = reinterpret_cast<const f4*>(p.ytab + (g0 & ~(size_t)3));
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+          if (4 * 64 * j < kSeg * V + skew) tile[j] = src[64 * j + lane];
+      }
+      SegIn<PPL> ein;
+      ein.load(p, b, es, S, lane);
+      for (int i = lane; i < kYs * V; i += 64) lds.ys[i] = 0.f;             // (dead steps of a short segment)
+      {
+        const int count = n * V;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+          if (4 * 64 * j < kSeg * V + skew) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+              const int idx = 4 * (64 * j + lane) + c - skew;
+              if (idx >= 0 && idx < count) {
+                const int tt = (int)(((unsigned)idx * magic) >> 20);
+                lds.ys[(idx - tt * V) * kYs + tt] = tile[j][c];
+              }
+            }
+          }
+        }
+      }
+      F2_LDS_ORDER
+      segment_body_pk<false>(p, b, es, T, S, n, lc, rank, ein, lds, gl, lane, smin, smax);
+    }
+    if (t0 + kSeg > T) {
+      // frames past the utterance's end: exp(lp) in log-prob mode (quirk Q1), zero for fused logits
+      float* grads = p.grads + (size_t)b * Tmax * V;
+      const float* x = p.x + (int64_t)b * p.sB;
+      const int tend = min(t0 + kSeg, Tmax);
+      for (int t = max(t0, T); t < tend; t++)
+        for (int v = lane; v < V; v += 64)
+          grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) * p.gscale : 0.f;
+    }
+  }
+
+  // ---- the interior segments, inputs one segment ahead ----
+  SegIn<PPL> in;
+  { const double zi = floor(zt2); in.zfrac = (float)(zt2 - zi);
+    in.zint = (int)fmax(fmin(zi, 1e9), -1e9); if (!(zt2 == zt2)) in.zfrac = zt2; }      // (infeasible: -inf; never passes the check)
+  for (; seg <= last_full; seg += G) {
+    const int t0 = seg * kSeg;
+    // Everything this wave has requested so far must have landed.  (vmcnt(0) also waits for the acknowledgement of the
+    // gradient rows stored since; a counted wait would not -- the requests are older -- but needs the count of those
+    // stores as an immediate.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- inputs: staging buffer -> registers ----
+    f4 tile[NT];
+    const int skew = (int)((((size_t)b * Tmax + t0) * V) & 3);
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+      if (4 * 64 * j < kSeg * V + skew) tile[j] = *(lds_f4v*)(stage + F2Stage::kTile + 1024 * j + 16 * lane);
+    {
+      const f4 a0 = *(lds_f4v*)(stage + F2Stage::kA + 16 * lane), a1 = *(lds_f4v*)(stage + F2Stage::kA + 1024 + 16 * lane);
+      const f4 q0 = *(lds_f4v*)(stage + F2Stage::kQ + 16 * lane), q1 = *(lds_f4v*)(stage + F2Stage::kQ + 1024 + 16 * lane);
+      const int ea = *(__attribute__((address_space(3))) short*)(stage + F2Stage::kE + 2 * lane);
+      const int eb = *(__attribute__((address_space(3))) short*)(stage + F2Stage::kE + 128 + 2 * lane);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        in.a[k] = in_lattice ? a0[k] : 0.f; in.a[4 + k] = in_lattice ? a1[k] : 0.f;
+        in.q[k] = in_lattice ? q0[k] : 0.f; in.q[4 + k] = in_lattice ? q1[k] : 0.f;
+      }
+      in.ownA = in_lattice ? ea : -30000;
+      in.ownB = in_lattice ? eb : -30000;
+      const __attribute__((address_space(3))) int* wi = (const __attribute__((address_space(3))) int*)(stage + F2Stage::kI);
+      const int a0i = wi[0], b2 = wi[1], ta0 = wi[2], ta1 = wi[3], ta2 = wi[4], tb0 = wi[5], tb1 = wi[6], tb2 = wi[7];
+      in.eA7 = __builtin_amdgcn_readfirstlane(ta1 - ta0); in.eA15 = __builtin_amdgcn_readfirstlane(ta2 - ta1);
+      in.eB0 = __builtin_amdgcn_readfirstlane(tb0 - tb1); in.eB8 = __builtin_amdgcn_readfirstlane(tb1 - tb2);
+      in.EA0 = __builtin_amdgcn_readfirstlane(a0i); in.EB16 = __builtin_amdgcn_readfirstlane(b2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer has been read: it can take the next segment's inputs
+    if (seg + G <= last_full) request(seg + G);
+    {
+      // scatter the rows into the transposed tile
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        if (4 * 64 * j < kSeg * V + skew) {
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const int idx = 4 * (64 * j + lane) + c - skew;
+            if (idx >= 0 && idx < kSeg * V) {
+              const int tt = (int)(((unsigned)idx * magic) >> 20);
+              lds.ys[(idx - tt * V) * kYs + tt] = tile[j][c];
+            }
+          }
+        }
+      }
+    }
+    F2_LDS_ORDER
+    F2_STAMP(0)
+    segment_body_pk<true>(p, b, seg, T, S, kSeg, lc, rank, in, lds, gl, lane, smin, smax);
+  }
+  F2_FLUSH
+  // range check: everything that carries posterior mass was representable (see segment_wave)
+  const bool finite_ok = smax < __builtin_huge_valf();
+  if (!(smin > 0.f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
+  if (g == 0 && lane == 0) {
+    const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
+    if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64, 2) void ctc_fast_segment_persistent_kernel(FastParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  segment_wave_persistent<NT>(p, smem);
+}
+
+// waves per utterance of the persistent segment kernel: all of them resident at once (two per SIMD: 2048 on the chip) when
+// the batch allows, never more than there are segments
+inline int persistent_waves_per_utterance(int B, int NS) {
+  static const int forced = getenv("E2E_F2_G") ? atoi(getenv("E2E_F2_G")) : 0;
+  int G = forced > 0 ? forced : (2048 + B - 1) / B;
+  if (forced <= 0 && G < 8) G = 8;
+  return G < NS ? G : NS;
+}
+inline int launch_segments_ppl4(const FastParams& q, hipStream_t stream) {
+  const size_t lds2 = F2Lds<4>::bytes(q.V) + E2E_F2_LDSPAD, lds2p = ((lds2 + 15) & ~(size_t)15) + F2Stage::bytes(q.V);
+  static const bool one_shot = getenv("E2E_F2_PERSISTENT") == nullptr;   // (the persistent form: not faster; kept for A/B)
+  if (one_shot) { hipLaunchKernelGGL(ctc_fast_segment_kernel<4>, dim3(q.NS, q.B), dim3(64), lds2, stream, q); }
+  else {
+    const int G = persistent_waves_per_utterance(q.B, q.NS);
+    if (q.V <= 32) hipLaunchKernelGGL(ctc_fast_segment_persistent_kernel<3>, dim3(G, q.B), dim3(64), lds2p, stream, q);
+    else hipLaunchKernelGGL(ctc_fast_segment_persistent_kernel<(kSeg * kMaxSmallV + 3 + 255) / 256>, dim3(G, q.B), dim3(64), lds2p, stream, q);
+  }
+  E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
+  return E2E_OK;
+}
+
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds1 = F1Lds::bytes(p.V);
@@ -1888,6 +2354,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<PPL, ChainF32>), dim3(p.B), dim3(ChainF32::kWaves * 64), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
     FastParams q = p; q.ztol = kZTolF32;                          // (trkA / trkB: written by the frame waves)
+    if constexpr (PPL == 4) return launch_segments_ppl4(q, stream);
     hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
     return E2E_OK;
@@ -1902,13 +2369,15 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
     hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<PPL, ChainF64>), dim3(p.B), dim3(ChainF64::kWaves * 64), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
-    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);     // (trkA / trkB: the frame waves')
+    if constexpr (PPL == 4) return launch_segments_ppl4(p, stream);                                // (trkA / trkB: the frame waves')
+    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
     return E2E_OK;
   }
   hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
   FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB;          // (its frame follows the maximum itself)
+  if constexpr (PPL == 4) return launch_segments_ppl4(q, stream);
   hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
   return E2E_OK;

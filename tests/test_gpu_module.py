@@ -254,5 +254,5 @@ def test_half_precision_logits_go_forward_and_backward(dtype, reduce):
     want = g_o * (2.0 / B if reduce else w.float().cpu().numpy()[:, None, None])
     eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10            # the source dtype's rounding, twice
     U.assert_same(x.grad.float().cpu().numpy(), want, 4 * eps, 4 * eps, "input grad")
-    got_l = loss.float().cpu().numpy()
+    got_l = loss.detach().float().cpu().numpy()
     U.assert_same(got_l, l_o.mean() if reduce else l_o, 4 * eps, 4 * eps, "loss")

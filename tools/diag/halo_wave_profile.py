@@ -5,7 +5,7 @@ import sys, ctypes as C, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import end2end_amd._lib as _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "build/diag/prof_lib.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), os.environ.get("E2E_PROF_LIB", "build/diag/prof_lib.so"))
 L = _lib.load()
 d = torch.device("cuda", 0)
 gen = torch.Generator().manual_seed(0)
