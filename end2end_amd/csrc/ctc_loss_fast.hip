@@ -1449,19 +1449,28 @@ struct F2Lds {
   __host__ __device__ static size_t bytes(int V) { return sizeof(float) * (4 + kHalf * PROW + kYs * (V + 1)) + sizeof(int) * 130; }
 };
 
-// The gradient rows are written one lane per label (two labels per lane beyond 64 columns): what a lane needs about
-// its labels is the same for all 16 rows of the segment and is looked up once.
+// The gradient rows are written one lane per (row, label): with V <= 32 columns the 64 lanes cover two rows per pass (four
+// with V <= 16), beyond 64 columns a lane takes two labels.  What a lane needs about its label is the same for all 16
+// rows of the segment and is looked up once.
 struct GradLanes {
-  int hi[2], lo[2];     // float index into a Ps row of the label's last sorted slot / of the slot before its first
-  int y[2];             // float index of the label's row in the transposed probability tile
+  int hi[2], lo[2];     // float index into Ps of the label's last sorted slot / of the slot before its first (+ the lane's row)
+  int y[2];             // float index of the label's row in the transposed probability tile (+ the lane's row)
   float isblank[2];     // 1 for the blank column (it takes the pre-summed blank cells), else 0
+  int rpp;              // rows per pass: 1, 2 or 4 (wave-uniform)
+  int rsel;             // this lane's row inside a pass
+  int goff;             // rsel * V + v: the lane's offset inside a pass's rows of the gradient; -1: the lane writes nothing
   template <int PPL>
   __device__ void init(const F2Lds<PPL>& lds, int V, int blank, int lane) {
+    rpp = V <= 16 ? 4 : V <= 32 ? 2 : 1;
+    const int vp = 64 / rpp;
+    rsel = rpp == 1 ? 0 : lane / vp;
+    const int v0 = rpp == 1 ? lane : lane & (vp - 1);
+    goff = v0 < V ? rsel * V + v0 : -1;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-      const int v = min(lane + 64 * s, V - 1);
-      hi[s] = lds.starts[v + 1] - 1; lo[s] = lds.starts[v] - 1;
-      y[s] = v * kYs; isblank[s] = v == blank ? 1.f : 0.f;
+      const int v = min(v0 + 64 * s, V - 1);
+      hi[s] = lds.starts[v + 1] - 1 + rsel * F2Lds<PPL>::PROW; lo[s] = lds.starts[v] - 1 + rsel * F2Lds<PPL>::PROW;
+      y[s] = v * kYs + rsel; isblank[s] = v == blank ? 1.f : 0.f;
     }
   }
 };
@@ -1532,20 +1541,44 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
   // v of every row: its label's slots, its row of the probability tile and whether it is the blank are the same for
   // all rows (GradLanes); per row that leaves three LDS reads at constant offsets, three VALU operations and a store.
   float* grads = p.grads + ((size_t)b * p.T + t0 + h * kHalf) * V;
-  const int nsets = V > 64 ? 2 : 1;
+  if (!(E2E_F2_ABL & 2)) {
+    // RPP rows per pass: the lane's row is k + rsel; the rows' normalisers and blank sums are wave-uniform, the lane picks its row's
+    auto pass = [&](auto rpp_tag) {
+      constexpr int RPP = decltype(rpp_tag)::value;
+      const float* pre_hi = lds.Ps + gl.hi[0];
+      const float* pre_lo = lds.Ps + gl.lo[0];
+      const float* yrow = lds.ys + gl.y[0] + h * kHalf;
 #pragma unroll
-  for (int s = 0; s < 2; s++) {
-    if (s < nsets && !(E2E_F2_ABL & 2)) {
-      const int v = lane + 64 * s;
-      const float* pre_hi = lds.Ps + gl.hi[s];
-      const float* pre_lo = lds.Ps + gl.lo[s];
-      const float* yrow = lds.ys + gl.y[s] + h * kHalf;
-#pragma unroll
-      for (int k = 0; k < kHalf; k++) {
+      for (int k = 0; k < kHalf; k += RPP) {
         if (FULL || k < rows) {
-          const float pv = (pre_hi[k * PROW] - pre_lo[k * PROW]) + gl.isblank[s] * btot8[k];
-          const float g = (yrow[k] - pv * __builtin_amdgcn_rcpf(st8[k])) * p.gscale;
-          if (v < V) grads[(size_t)k * V + v] = g;
+          float st = st8[k], bt = btot8[k];
+#pragma unroll
+          for (int j = 1; j < RPP; j++) { st = gl.rsel == j ? st8[k + j] : st; bt = gl.rsel == j ? btot8[k + j] : bt; }
+          const float pv = (pre_hi[k * PROW] - pre_lo[k * PROW]) + gl.isblank[0] * bt;
+          const float g = (yrow[k] - pv * __builtin_amdgcn_rcpf(st)) * p.gscale;
+          if (gl.goff >= 0 && (FULL || k + gl.rsel < rows)) grads[(size_t)k * V + gl.goff] = g;
+        }
+      }
+    };
+    if (gl.rpp == 2) pass(std::integral_constant<int, 2>{});
+    else if (gl.rpp == 4) pass(std::integral_constant<int, 4>{});
+    else {
+      const int nsets = V > 64 ? 2 : 1;
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        if (s < nsets) {
+          const int v = lane + 64 * s;
+          const float* pre_hi = lds.Ps + gl.hi[s];
+          const float* pre_lo = lds.Ps + gl.lo[s];
+          const float* yrow = lds.ys + gl.y[s] + h * kHalf;
+#pragma unroll
+          for (int k = 0; k < kHalf; k++) {
+            if (FULL || k < rows) {
+              const float pv = (pre_hi[k * PROW] - pre_lo[k * PROW]) + gl.isblank[s] * btot8[k];
+              const float g = (yrow[k] - pv * __builtin_amdgcn_rcpf(st8[k])) * p.gscale;
+              if (v < V) grads[(size_t)k * V + v] = g;
+            }
+          }
         }
       }
     }
@@ -2113,230 +2146,10 @@ __global__ __launch_bounds__(64, E2E_F2_MINW) void ctc_fast_segment_kernel(FastP
   segment_wave<PPL>(p, smem);
 }
 
-// The segment kernel for four pairs per lane as PERSISTENT waves: G waves per utterance, wave g takes segments g, g+G, ...
-// A one-segment wave spends a third of its life waiting for its inputs (the launch, the kernel arguments, one memory round
-// trip: ~2.5 us of ~8, with only two such waves on a SIMD to cover for each other -- tools/diag ablation builds: the kernel
-// with all arithmetic removed still takes 20 of its 57 us).  Here the utterance's lattice description is read once per
-// wave, and a segment's inputs -- probability rows, both checkpoint rows, their exponents, the rescale exponents -- are
-// requested one segment AHEAD by LDS-DMA (global_load_lds: no destination registers; a register prefetch needs ~40 on top
-// of a kernel that runs at 240 and spills -- tried twice).  The staging buffer is single: a segment moves its inputs from
-// the buffer to registers / the transposed tile first, then the next segment's loads are issued into the same bytes.
-struct F2Stage {                    // byte offsets inside the staging buffer (1 KiB = one 16-byte wave-instruction)
-  static constexpr int kA = 0, kQ = 2048, kE = 4096, kI = 4352, kTile = 4608;
-  __host__ __device__ static int tile_chunks(int V) { return (kSeg * V + 3 + 255) / 256; }
-  __host__ __device__ static int bytes(int V) { return kTile + 1024 * tile_chunks(V); }
-};
-typedef __attribute__((address_space(1))) const void gl_cvoid;
-__device__ __forceinline__ void glds16(const void* g, lds_u8* l) { __builtin_amdgcn_global_load_lds((gl_cvoid*)g, l, 16, 0, 0); }
-__device__ __forceinline__ void glds4(const void* g, lds_u8* l) { __builtin_amdgcn_global_load_lds((gl_cvoid*)g, l, 4, 0, 0); }
-
-template <int NT>
-__device__ __forceinline__ void segment_wave_persistent(const FastParams& p, unsigned char* smem) {
-  constexpr int PPL = 4;
-  const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x, lane = threadIdx.x;
-  const int V = p.V, Tmax = p.T;
-  const F2Lds<PPL> lds(smem, V);
-  lds_u8* stage = (lds_u8*)smem + ((F2Lds<PPL>::bytes(V) + 15) & ~(size_t)15);
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) f4 lds_f4v;
-  F2_STAMP(-1)
-  const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
-  unsigned w[PPL];
-  {
-    const unsigned* ci = p.cinfo + (size_t)b * (p.CELLS / 2) + PPL * lane;
-#pragma unroll
-    for (int r = 0; r < PPL; r++) w[r] = ci[r];
-  }
-  const int* ls = p.lstart + (size_t)b * 130;
-  const int s0 = ls[lane], s1 = ls[64 + lane], s2 = ls[128 + (lane & 1)];
-  const double zt2 = p.zt2[b];
-  // LDS-DMA requests for one segment's inputs (addresses depend on nothing that is loaded: they can go out at once)
-  auto request = [&](int seg) {
-    const int t0 = seg * kSeg;
-    const size_t g0 = ((size_t)b * Tmax + t0) * V;
-    const float* src = p.ytab + (g0 & ~(size_t)3);
-    const int skew = (int)(g0 & 3);
-#pragma unroll
-    for (int j = 0; j < NT; j++)
-      if (4 * 64 * j < kSeg * V + skew) glds16(src + 4 * (64 * j + lane), stage + F2Stage::kTile + 1024 * j);     // (uniform test)
-    const float* ra = p.ckA + ((size_t)b * p.NS + seg) * p.CELLS + lane * 2 * PPL;           // (row 0: never used)
-    glds16(ra, stage + F2Stage::kA); glds16(ra + 4, stage + F2Stage::kA + 1024);
-    const int segq = seg + 1 < p.NS ? seg + 1 : seg;                                          // (no row past the last: unused)
-    const float* rq = p.ckQ + ((size_t)b * p.NS + segq) * p.CELLS + lane * 2 * PPL;
-    glds16(rq, stage + F2Stage::kQ); glds16(rq + 4, stage + F2Stage::kQ + 1024);
-    // exponents of the two rows: 64 shorts each, lanes 0..31 fetch the alpha row's, lanes 32..63 the beta row's
-    const short* re = p.ckE + (lane < 32 ? (((size_t)b * p.NS + seg) * 2 + 0) * 64 : (((size_t)b * p.NS + segq) * 2 + 1) * 64) + 2 * (lane & 31);
-    glds4(re, stage + F2Stage::kE);
-    // the eight rescale words: cumA[i], cumB[i+2], trkA[i..i+2], trkB[i..i+2], i = t0/8 (lanes 8.. fetch copies)
-    const int k = lane & 7;
-    const int* base = k == 0 ? p.cumA : k == 1 ? p.cumB : k < 5 ? p.trkA : p.trkB;
-    const int off = k == 0 ? 0 : k == 1 ? 2 : k < 5 ? k - 2 : k - 5;
-    glds4(base + (size_t)b * p.NB + (t0 >> 3) + off, stage + F2Stage::kI);
-  };
-  // This wave's segments are g, g+G, ...  Interior ones (16 live steps, neither t = 0 nor t = T-1 inside: segments
-  // 1 .. (T-17)/16) go through the prefetching loop below with the guard-free body; the utterance's first and last live
-  // segments and the frames past its end are done first, one at a time with plain loads (at most a few per utterance, and
-  // kept out of the loop: with both bodies inside it the kernel spills).
-  if (Tq < 1 || Tq > Tmax || Sq < 0 || Sq > p.Smax) return;    // flagged by F1, the exact kernel poisons it
-  const int T = (int)Tq, S = (int)Sq;
-  const int last_full = T >= 33 ? (T - 17) / kSeg : 0;          // (0: none)
-  int seg = g >= 1 ? g : G;                                      // this wave's first interior segment, if <= last_full
-  if (seg <= last_full) request(seg);
-
-  LaneCells<PPL> lc;
-  int rank[PPL];
-  lc.unpack(w, S, T, rank);
-  lds.starts[lane] = s0; lds.starts[64 + lane] = s1; if (lane < 2) lds.starts[128 + lane] = s2;
-  if (lane < kYs) lds.ys[V * kYs + lane] = 0.f;                           // the zero row V
-  if (lane < kHalf) lds.Ps[lane * F2Lds<PPL>::PROW - 1] = 0.f;           // the rows' zero guards
-  F2_LDS_ORDER
-  GradLanes gl;
-  gl.init(lds, V, p.blank, lane);
-  float smin = __builtin_huge_valf(), smax = 0.f;
-  const unsigned magic = (1u << 20) / (unsigned)V + 1u;                  // idx / V for idx < 2^20 / V
-  const bool in_lattice = lane * 2 * PPL <= 2 * S;                       // (the chains store no cells past the lattice's 2S+1)
-
-  // ---- the edge segments of this wave: 0 (if g == 0) and those from (T-1)/16 on ----
-  for (int es = g; es < p.NS; es += G) {
-    if (es >= 1 && es <= last_full) continue;
-    const int t0 = es * kSeg;
-    if (t0 < T) {
-      const int n = min(t0 + kSeg, T) - t0;
-      f4 tile[NT];
-      const size_t g0 = ((size_t)b * Tmax + t0) * V;
-      const int skew = (int)(g0 & 3);
-      {
-        const f4* src = reinterpret_cast<const f4*>(p.ytab + (g0 & ~(size_t)3));
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-          if (4 * 64 * j < kSeg * V + skew) tile[j] = src[64 * j + lane];
-      }
-      SegIn<PPL> ein;
-      ein.load(p, b, es, S, lane);
-      for (int i = lane; i < kYs * V; i += 64) lds.ys[i] = 0.f;             // (dead steps of a short segment)
-      {
-        const int count = n * V;
-#pragma unroll
-        for (int j = 0; j < NT; j++) {
-          if (4 * 64 * j < kSeg * V + skew) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-              const int idx = 4 * (64 * j + lane) + c - skew;
-              if (idx >= 0 && idx < count) {
-                const int tt = (int)(((unsigned)idx * magic) >> 20);
-                lds.ys[(idx - tt * V) * kYs + tt] = tile[j][c];
-              }
-            }
-          }
-        }
-      }
-      F2_LDS_ORDER
-      segment_body_pk<false>(p, b, es, T, S, n, lc, rank, ein, lds, gl, lane, smin, smax);
-    }
-    if (t0 + kSeg > T) {
-      // frames past the utterance's end: exp(lp) in log-prob mode (quirk Q1), zero for fused logits
-      float* grads = p.grads + (size_t)b * Tmax * V;
-      const float* x = p.x + (int64_t)b * p.sB;
-      const int tend = min(t0 + kSeg, Tmax);
-      for (int t = max(t0, T); t < tend; t++)
-        for (int v = lane; v < V; v += 64)
-          grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) * p.gscale : 0.f;
-    }
-  }
-
-  // ---- the interior segments, inputs one segment ahead ----
-  SegIn<PPL> in;
-  { const double zi = floor(zt2); in.zfrac = (float)(zt2 - zi);
-    in.zint = (int)fmax(fmin(zi, 1e9), -1e9); if (!(zt2 == zt2)) in.zfrac = zt2; }      // (infeasible: -inf; never passes the check)
-  for (; seg <= last_full; seg += G) {
-    const int t0 = seg * kSeg;
-    // Everything this wave has requested so far must have landed.  (vmcnt(0) also waits for the acknowledgement of the
-    // gradient rows stored since; a counted wait would not -- the requests are older -- but needs the count of those
-    // stores as an immediate.)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ---- inputs: staging buffer -> registers ----
-    f4 tile[NT];
-    const int skew = (int)((((size_t)b * Tmax + t0) * V) & 3);
-#pragma unroll
-    for (int j = 0; j < NT; j++)
-      if (4 * 64 * j < kSeg * V + skew) tile[j] = *(lds_f4v*)(stage + F2Stage::kTile + 1024 * j + 16 * lane);
-    {
-      const f4 a0 = *(lds_f4v*)(stage + F2Stage::kA + 16 * lane), a1 = *(lds_f4v*)(stage + F2Stage::kA + 1024 + 16 * lane);
-      const f4 q0 = *(lds_f4v*)(stage + F2Stage::kQ + 16 * lane), q1 = *(lds_f4v*)(stage + F2Stage::kQ + 1024 + 16 * lane);
-      const int ea = *(__attribute__((address_space(3))) short*)(stage + F2Stage::kE + 2 * lane);
-      const int eb = *(__attribute__((address_space(3))) short*)(stage + F2Stage::kE + 128 + 2 * lane);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        in.a[k] = in_lattice ? a0[k] : 0.f; in.a[4 + k] = in_lattice ? a1[k] : 0.f;
-        in.q[k] = in_lattice ? q0[k] : 0.f; in.q[4 + k] = in_lattice ? q1[k] : 0.f;
-      }
-      in.ownA = in_lattice ? ea : -30000;
-      in.ownB = in_lattice ? eb : -30000;
-      const __attribute__((address_space(3))) int* wi = (const __attribute__((address_space(3))) int*)(stage + F2Stage::kI);
-      const int a0i = wi[0], b2 = wi[1], ta0 = wi[2], ta1 = wi[3], ta2 = wi[4], tb0 = wi[5], tb1 = wi[6], tb2 = wi[7];
-      in.eA7 = __builtin_amdgcn_readfirstlane(ta1 - ta0); in.eA15 = __builtin_amdgcn_readfirstlane(ta2 - ta1);
-      in.eB0 = __builtin_amdgcn_readfirstlane(tb0 - tb1); in.eB8 = __builtin_amdgcn_readfirstlane(tb1 - tb2);
-      in.EA0 = __builtin_amdgcn_readfirstlane(a0i); in.EB16 = __builtin_amdgcn_readfirstlane(b2);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer has been read: it can take the next segment's inputs
-    if (seg + G <= last_full) request(seg + G);
-    {
-      // scatter the rows into the transposed tile
-#pragma unroll
-      for (int j = 0; j < NT; j++) {
-        if (4 * 64 * j < kSeg * V + skew) {
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            const int idx = 4 * (64 * j + lane) + c - skew;
-            if (idx >= 0 && idx < kSeg * V) {
-              const int tt = (int)(((unsigned)idx * magic) >> 20);
-              lds.ys[(idx - tt * V) * kYs + tt] = tile[j][c];
-            }
-          }
-        }
-      }
-    }
-    F2_LDS_ORDER
-    F2_STAMP(0)
-    segment_body_pk<true>(p, b, seg, T, S, kSeg, lc, rank, in, lds, gl, lane, smin, smax);
-  }
-  F2_FLUSH
-  // range check: everything that carries posterior mass was representable (see segment_wave)
-  const bool finite_ok = smax < __builtin_huge_valf();
-  if (!(smin > 0.f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
-  if (g == 0 && lane == 0) {
-    const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
-    if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
-  }
-}
-
-template <int NT>
-__global__ __launch_bounds__(64, 2) void ctc_fast_segment_persistent_kernel(FastParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  segment_wave_persistent<NT>(p, smem);
-}
-
-// waves per utterance of the persistent segment kernel: all of them resident at once (two per SIMD: 2048 on the chip) when
-// the batch allows, never more than there are segments
-inline int persistent_waves_per_utterance(int B, int NS) {
-  static const int forced = getenv("E2E_F2_G") ? atoi(getenv("E2E_F2_G")) : 0;
-  int G = forced > 0 ? forced : (2048 + B - 1) / B;
-  if (forced <= 0 && G < 8) G = 8;
-  return G < NS ? G : NS;
-}
-inline int launch_segments_ppl4(const FastParams& q, hipStream_t stream) {
-  const size_t lds2 = F2Lds<4>::bytes(q.V) + E2E_F2_LDSPAD, lds2p = ((lds2 + 15) & ~(size_t)15) + F2Stage::bytes(q.V);
-  static const bool one_shot = getenv("E2E_F2_PERSISTENT") == nullptr;   // (the persistent form: not faster; kept for A/B)
-  if (one_shot) { hipLaunchKernelGGL(ctc_fast_segment_kernel<4>, dim3(q.NS, q.B), dim3(64), lds2, stream, q); }
-  else {
-    const int G = persistent_waves_per_utterance(q.B, q.NS);
-    if (q.V <= 32) hipLaunchKernelGGL(ctc_fast_segment_persistent_kernel<3>, dim3(G, q.B), dim3(64), lds2p, stream, q);
-    else hipLaunchKernelGGL(ctc_fast_segment_persistent_kernel<(kSeg * kMaxSmallV + 3 + 255) / 256>, dim3(G, q.B), dim3(64), lds2p, stream, q);
-  }
-  E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
-  return E2E_OK;
-}
-
+// (Persistent segment waves -- G waves per utterance, each walking every G-th segment with the next segment's inputs
+// requested one segment ahead by LDS-DMA (global_load_lds, no destination registers) and a counted vmcnt wait that lets the
+// gradient stores drain under the next segment -- were built, parity-green, and measured: 137 against 131 us per step.  The
+// one-segment waves already overlap each other's load latency and store tails; a register prefetch spills (tried twice).)
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds1 = F1Lds::bytes(p.V);
@@ -2354,7 +2167,6 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<PPL, ChainF32>), dim3(p.B), dim3(ChainF32::kWaves * 64), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
     FastParams q = p; q.ztol = kZTolF32;                          // (trkA / trkB: written by the frame waves)
-    if constexpr (PPL == 4) return launch_segments_ppl4(q, stream);
     hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
     return E2E_OK;
@@ -2369,15 +2181,13 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
     hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<PPL, ChainF64>), dim3(p.B), dim3(ChainF64::kWaves * 64), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
-    if constexpr (PPL == 4) return launch_segments_ppl4(p, stream);                                // (trkA / trkB: the frame waves')
-    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);
+    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);     // (trkA / trkB: the frame waves')
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
     return E2E_OK;
   }
   hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
   FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB;          // (its frame follows the maximum itself)
-  if constexpr (PPL == 4) return launch_segments_ppl4(q, stream);
   hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
   return E2E_OK;
