@@ -28,8 +28,11 @@ struct ExactParams {
   void* losses; void* grads;
   double* ws_alpha;   // [B][T][Lmax]
   double* ws_lse;     // [B][T] row log-sum-exp (logits mode)
-  const int* flags;   // per-utterance "redo me" words written by the fast path (mode != 0)
+  int* flags;         // per-utterance "redo me" words written by the fast path (mode != 0); mode 1 adds bit 512: the f64
+                      // redo of a segment could not settle the utterance
   int mode;           // 0: every utterance; 1: only flagged ones; 2: poison flagged ones, compute nothing
+  int nslabs;         // alpha slabs in the workspace (mode 1: workgroups 0 .. nslabs-1 run the full recomputation)
+  int redo_waves;     // waves of a workgroup that take part in the f64 redo of the segments (their LDS must fit: <= 8)
   int* ctl;           // flagged modes: the fast path's control words (0: tickets of this launch's workgroups)
   double gscale;      // every gradient element is multiplied by this as it is written
   void* reduced; int reduction;   // flagged modes: optional sum / mean of the losses, written by the last workgroup
@@ -56,12 +59,15 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// f64 redo of the fast path's segment kernel for one utterance (flag bits 8 / 16: the f32 recompute left its range).
-// The chains' work stands -- loss, probabilities, alpha / beta checkpoints every 16 steps, all from f64 state -- so
-// only the 16-step segments are done again, in doubles: each of the 8 waves takes every 8th segment, recomputes its
-// alpha rows from the checkpoint into this workgroup's alpha slab, walks beta back through it, adds alpha*beta per
-// label with LDS f64 atomics and writes the gradient rows.  ~0.3 ms per utterance instead of the ~7 ms of the full
-// log-domain recomputation.  Returns false (-> exact path) if a row sum is still not a positive finite number.
+// f64 redo of ONE 16-step segment of the fast path's segment kernel (flag bits 8 / 16: the f32 recompute left its range).
+// The chains' work stands -- loss, probabilities, alpha / beta checkpoints every 16 steps, all from f64 state -- so only
+// the segments are done again, in doubles, ONE WAVE PER (flagged utterance, segment): every wave of the launch takes the
+// segments whose running index is its own modulo the number of waves, so a batch with 73 flagged utterances is 4 600
+// independent pieces of ~10 us on the whole chip instead of 73 workgroups walking 63 segments each (0.75 ms).
+// Nothing is staged in HBM: a wave keeps the alpha rows entering steps 4, 8, 12 from one forward sweep (and the
+// checkpoint for step 0), then takes the segment four rows at a time from the back -- recompute the four alpha rows from
+// the kept one, walk beta through them -- 28 alpha steps for 16 rows.  Per-label sums by LDS f64 atomics, one row at a time.
+// Returns false if a row sum is not a positive finite number or does not reproduce the chains' log Z (-> exact path).
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double lane_shift_up(double v) {      // lane n <- lane n-1, lane 0 <- 0
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, true);
@@ -74,27 +80,31 @@ __device__ __forceinline__ double lane_shift_down(double v) {    // lane n <- la
   return __hiloint2double(hi, lo);
 }
 
+constexpr int kRetryGroup = 4;      // rows recomputed and held at a time
+
+// per-wave LDS of the redo: the segment's probability rows [16][V] (floats), post[V] per-label sums of the row at hand,
+// and the three kept alpha rows [3][8 cells][64 lanes] (registers hold the four rows in work, beta and the row being
+// stepped: with the kept rows on top the kernel spilled 82 registers into its hot loops)
+__host__ __device__ inline size_t retry_wave_lds_bytes(int V) {
+  return ((sizeof(float) * kFastSeg * (size_t)V + sizeof(double) * ((size_t)V + 2) + 15) & ~(size_t)15) + sizeof(double) * 3 * 8 * 64;
+}
+
 template <typename IO, int PPL>
-__device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, int b, int slot) {
-  constexpr int NC = 2 * PPL, kSeg = kFastSeg;
+__device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned char* wsmem, int b, int seg, int lane) {
+  constexpr int NC = 2 * PPL, kSeg = kFastSeg, G = kRetryGroup;
   const FastRetry& rt = p.retry;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int V = p.V, blank = p.blank, Lmax = p.Lmax, Tmax = p.T;
+  const int V = p.V, blank = p.blank, Tmax = p.T;
   const int T = (int)p.x_len[b], S = (int)p.t_len[b], L = 2 * S + 1;
+  const int t0 = seg * kSeg, n = min(kSeg, T - t0);
   const bool cond = (T > 1 || L == 1);
   const double rr = (double)fast_tilt(S, T);
-  double* wa = p.ws_alpha + (size_t)slot * (size_t)Tmax * (size_t)Lmax;
   IO* grads = reinterpret_cast<IO*>(p.grads) + (size_t)b * (size_t)Tmax * (size_t)V;
-  // per-wave LDS: post[16][V] per-label sums, then 16 row sums, 16 blank sums
-  double* post = reinterpret_cast<double*>(smem) + (size_t)wid * (kSeg * (V + 2));
-  double* rowsum = post + kSeg * V;
-  double* blanksum = rowsum + kSeg;
-  __shared__ int s_bad;
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
+  float* ys = reinterpret_cast<float*>(wsmem);                                  // [16][V]
+  double* post = reinterpret_cast<double*>(wsmem + ((sizeof(float) * kSeg * (size_t)V + 7) & ~(size_t)7));   // [V], then row sum, blank sum
 
   // this lane's pairs i = PPL*lane + r: label, skip permissions (ctc_loss.cpp:53-57, 91-96) -- as LaneCells::load
-  int lab[PPL]; double skp[PPL], skn[PPL];
+  int lab[PPL]; float skp[PPL], skn[PPL];      // (1 where the skip is allowed: its weight is r^2)
+  const double rr2 = rr * rr;
   const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
 #pragma unroll
   for (int r = 0; r < PPL; r++) {
@@ -102,94 +112,140 @@ __device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, in
     const int li = i < S ? (int)tg[i] : -1;
     const int lp_ = (i >= 1 && i - 1 < S) ? (int)tg[i - 1] : -1;
     const int ln = (i + 1 < S) ? (int)tg[i + 1] : -1;
-    lab[r] = i < S ? li : -1;
-    skp[r] = (i < S && i >= 1 && li != blank && lp_ != li) ? rr * rr : 0.0;
-    skn[r] = (i + 1 < S && li != blank && ln != li) ? rr * rr : 0.0;
+    lab[r] = (i < S && li >= 0 && li < V) ? li : -1;
+    skp[r] = (i < S && i >= 1 && li != blank && lp_ != li) ? 1.f : 0.f;
+    skn[r] = (i + 1 < S && li != blank && ln != li) ? 1.f : 0.f;
   }
-  const float* ytab = rt.ytab + (size_t)b * Tmax * V;
-  auto y = [&](int t, int v) -> double { return v >= 0 ? (double)ytab[(size_t)t * V + v] : 0.0; };
-  const int* cumA = rt.cumA + (size_t)b * rt.NB;       // see FastParams in ctc_loss_fast.hip
-  const int* cumB = rt.cumB + (size_t)b * rt.NB;
-  bool bad = false;
+  {
+    const float* src = rt.ytab + ((size_t)b * Tmax + t0) * V;
+    for (int i = lane; i < n * V; i += 64) ys[i] = src[i];
+  }
+  auto y = [&](int tt, int v) -> double { return v >= 0 ? (double)ys[tt * V + v] : 0.0; };
+  // the exponents the chains had removed around this segment (see FastParams in ctc_loss_fast.hip): blocks i .. i+2 of 8
+  // steps, i = t0 / 8 -- read once (a load per row on the rows' critical path cost more than the arithmetic)
+  int cA[3], cB[3];
+  {
+    const int* cumA = rt.cumA + (size_t)b * rt.NB + (t0 >> 3);
+    const int* cumB = rt.cumB + (size_t)b * rt.NB + (t0 >> 3);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { cA[k] = cumA[k]; cB[k] = cumB[k]; }
+  }
+  auto cumA_at = [&](int blk) -> int { const int k = blk - (t0 >> 3); return k <= 0 ? cA[0] : k == 1 ? cA[1] : cA[2]; };
+  auto cumB_at = [&](int blk) -> int { const int k = blk - (t0 >> 3); return k <= 0 ? cB[0] : k == 1 ? cB[1] : cB[2]; };
   // Every row must reproduce the chains' log Z: sum_j alpha_t[j] beta_t[j] = Z r^(L-1) 2^-(EA(t) + EB(t)), with EA / EB
   // the exponents the chains had removed by then.  It does not if the f32 checkpoints could not hold what mattered (their
   // cells share one exponent per lane: a cell 2^-149 below its lane's largest is stored as zero) -- then the exact kernel.
+  // (in log2, split like the segment kernel's self-check: the integer part is compared exactly, the fraction through an f32
+  //  logarithm of the row sum's mantissa -- a double-precision log per row was a fifth of the redo's instructions)
   const double logz = rt.logz[2 * b];
-  const double lz_tilt = (double)(L - 1) * log(rr);
+  const double z2 = (logz + (double)(L - 1) * log(rr)) * 1.4426950408889634074;
+  const double z2i = floor(z2);
+  const float z2f = (float)(z2 - z2i);
+  const bool in_lattice = lane * NC < L;               // (the chains store no cells past the lattice's 2S+1)
+  bool bad = false;
 
-  for (int seg = wid; seg * kSeg < T; seg += kThreads / 64) {
-    const int t0 = seg * kSeg, n = min(kSeg, T - t0);
-    for (int i = lane; i < kSeg * (V + 2); i += 64) post[i] = 0.0;
-    // ---- alpha rows of the segment into the slab (tilted cells, F1's units and rescales) ----
-    double a[NC];
+  // one alpha step into row t = t0 + tt (tilted cells, F1's units and rescales)
+  auto alpha_step = [&](double (&a)[NC], int tt) {
+    const int t = t0 + tt;
+    const double yb = y(tt, blank);
+    if (t == 0) {
+#pragma unroll
+      for (int k = 0; k < NC; k++) a[k] = 0.0;
+      if (lane == 0) { a[0] = cond ? yb : 0.0; a[1] = rr * y(0, lab[0]); }
+    } else {
+      double pl = lane_shift_up(a[NC - 1]);
+#pragma unroll
+      for (int r = 0; r < PPL; r++) {
+        const double ob = a[2 * r], ol = a[2 * r + 1];
+        a[2 * r] = (ob + rr * pl) * yb;
+        a[2 * r + 1] = (ol + rr * ob + (skp[r] != 0.f ? rr2 : 0.0) * pl) * y(tt, lab[r]);
+        pl = ol;
+      }
+    }
+    if ((t & 7) == 7) {
+      const int e = cumA_at((t >> 3) + 1) - cumA_at(t >> 3);
+      if (e != 0) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) a[k] = ldexp(a[k], -e);
+      }
+    }
+  };
+
+  // ---- forward sweep: the rows entering steps 0 (the checkpoint), 4, 8, 12 ----
+  // kept rows 1..3 live in LDS as [row][cell][lane] (the checkpoint, row 0, is read again when its turn comes)
+  double* keep = reinterpret_cast<double*>(wsmem + (((sizeof(float) * kSeg * (size_t)V + sizeof(double) * ((size_t)V + 2)) + 15) & ~(size_t)15));
+  auto checkpoint = [&](double (&a)[NC]) {
     if (seg == 0) {
 #pragma unroll
       for (int k = 0; k < NC; k++) a[k] = 0.0;
     } else {
-      // (the chains store no cells past the lattice's 2S+1: lanes beyond it hold zeros)
-      const bool in_lattice = lane * NC < L;
       const float* src = rt.ckA + ((size_t)b * rt.NS + seg) * rt.CELLS + lane * NC;
       const int own = in_lattice ? rt.ckE[(((size_t)b * rt.NS + seg) * 2 + 0) * 64 + lane] : -30000;
 #pragma unroll
       for (int k = 0; k < NC; k++) a[k] = own > -30000 ? ldexp((double)src[k], own) : 0.0;
     }
-    for (int tt = 0; tt < n; tt++) {
-      const int t = t0 + tt;
-      const double yb = y(t, blank);
-      if (t == 0) {
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    double a[NC];
+    checkpoint(a);
 #pragma unroll
-        for (int k = 0; k < NC; k++) a[k] = 0.0;
-        if (lane == 0) { a[0] = cond ? yb : 0.0; a[1] = rr * y(0, lab[0]); }
-      } else {
-        double pl = lane_shift_up(a[NC - 1]);
+    for (int g = 1; g < kSeg / G; g++) {
 #pragma unroll
-        for (int r = 0; r < PPL; r++) {
-          const double ob = a[2 * r], ol = a[2 * r + 1];
-          a[2 * r] = (ob + rr * pl) * yb;
-          a[2 * r + 1] = (ol + rr * ob + skp[r] * pl) * y(t, lab[r]);
-          pl = ol;
-        }
-      }
-      if ((t & 7) == 7) {
-        const int e = cumA[(t >> 3) + 1] - cumA[t >> 3];
-        if (e != 0) {
+      for (int i = 0; i < G; i++) if ((g - 1) * G + i < n) alpha_step(a, (g - 1) * G + i);
 #pragma unroll
-          for (int k = 0; k < NC; k++) a[k] = ldexp(a[k], -e);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < NC; k++) { const int j = NC * lane + k; if (j < Lmax) wa[(size_t)t * Lmax + j] = a[k]; }
+      for (int k = 0; k < NC; k++) keep[((g - 1) * 8 + k) * 64 + lane] = a[k];
     }
-    // ---- beta back through the segment ----
-    double q[NC];
-    const bool last_seg = (t0 + n == T);
-    if (!last_seg) {
-      const bool in_lattice = lane * NC < L;
-      const float* src = rt.ckQ + ((size_t)b * rt.NS + seg + 1) * rt.CELLS + lane * NC;
-      const int own = in_lattice ? rt.ckE[(((size_t)b * rt.NS + seg + 1) * 2 + 1) * 64 + lane] : -30000;
+  }
+  // ---- beta back through the segment, four rows at a time ----
+  double q[NC];
+  const bool last_seg = (t0 + n == T);
+  if (!last_seg) {
+    const float* src = rt.ckQ + ((size_t)b * rt.NS + seg + 1) * rt.CELLS + lane * NC;
+    const int own = in_lattice ? rt.ckE[(((size_t)b * rt.NS + seg + 1) * 2 + 1) * 64 + lane] : -30000;
 #pragma unroll
-      for (int k = 0; k < NC; k++) q[k] = own > -30000 ? ldexp((double)src[k], own) : 0.0;
-    } else {
+    for (int k = 0; k < NC; k++) q[k] = own > -30000 ? ldexp((double)src[k], own) : 0.0;
+  } else {
 #pragma unroll
-      for (int k = 0; k < NC; k++) q[k] = 0.0;
+    for (int k = 0; k < NC; k++) q[k] = 0.0;
+  }
+#pragma unroll
+  for (int g = kSeg / G - 1; g >= 0; g--) {
+    if (g * G >= n) continue;
+    double A[G][NC];
+    {
+      double a[NC];
+      if (g == 0) checkpoint(a);
+      else {
+#pragma unroll
+        for (int k = 0; k < NC; k++) a[k] = keep[((g - 1) * 8 + k) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < G; i++) {
+        if (g * G + i < n) alpha_step(a, g * G + i);
+#pragma unroll
+        for (int k = 0; k < NC; k++) A[i][k] = a[k];
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this wave's alpha rows (and the zeroed sums) first
-    __builtin_amdgcn_s_waitcnt(0);
-    for (int tt = n - 1; tt >= 0; tt--) {
+#pragma unroll
+    for (int i = G - 1; i >= 0; i--) {
+      const int tt = g * G + i;
+      if (tt >= n) continue;
       const int t = t0 + tt;
+      for (int v = lane; v < V + 2; v += 64) post[v] = 0.0;
       double bs[NC];
       if (t == T - 1) {
 #pragma unroll
         for (int r = 0; r < PPL; r++) {
-          const int i = PPL * lane + r;
-          bs[2 * r] = (2 * i == L - 1 && cond) ? 1.0 : 0.0;
-          bs[2 * r + 1] = (2 * i + 1 == L - 2) ? rr : 0.0;
+          const int pi = PPL * lane + r;
+          bs[2 * r] = (2 * pi == L - 1 && cond) ? 1.0 : 0.0;
+          bs[2 * r + 1] = (2 * pi + 1 == L - 2) ? rr : 0.0;
         }
       } else {
         double nb = lane_shift_down(q[0]), nl = lane_shift_down(q[1]);
 #pragma unroll
         for (int r = PPL - 1; r >= 0; r--) {
-          bs[2 * r + 1] = q[2 * r + 1] + rr * nb + skn[r] * nl;
+          bs[2 * r + 1] = q[2 * r + 1] + rr * nb + (skn[r] != 0.f ? rr2 : 0.0) * nl;
           bs[2 * r] = q[2 * r] + rr * q[2 * r + 1];
           nb = q[2 * r]; nl = q[2 * r + 1];
         }
@@ -197,59 +253,55 @@ __device__ bool retry_segments_f64(const ExactParams& p, unsigned char* smem, in
       double mine = 0.0, myblank = 0.0;
 #pragma unroll
       for (int r = 0; r < PPL; r++) {
-        const int j0 = NC * lane + 2 * r;
-        const double pa = j0 < Lmax ? wa[(size_t)t * Lmax + j0] * bs[2 * r] : 0.0;
-        const double pb = j0 + 1 < Lmax ? wa[(size_t)t * Lmax + j0 + 1] * bs[2 * r + 1] : 0.0;
+        const double pa = A[i][2 * r] * bs[2 * r];
+        const double pb = A[i][2 * r + 1] * bs[2 * r + 1];
         myblank += pa; mine += pa + pb;
-        if (lab[r] >= 0 && lab[r] < V && pb != 0.0) atomicAdd(&post[tt * V + lab[r]], pb);
+        if (lab[r] >= 0 && pb != 0.0) atomicAdd(&post[lab[r]], pb);
       }
       mine = wave_sum(mine); myblank = wave_sum(myblank);
-      if (lane == 0) { rowsum[tt] = mine; blanksum[tt] = myblank; }
-      const double yb = y(t, blank);
+      const double yb = y(tt, blank);
 #pragma unroll
       for (int r = 0; r < PPL; r++) {
         q[2 * r] = bs[2 * r] * yb;
-        q[2 * r + 1] = bs[2 * r + 1] * y(t, lab[r]);
+        q[2 * r + 1] = bs[2 * r + 1] * y(tt, lab[r]);
       }
       if ((t & 7) == 0) {
-        const int e = cumB[t >> 3] - cumB[(t >> 3) + 1];
+        const int e = cumB_at(t >> 3) - cumB_at((t >> 3) + 1);
         if (e != 0) {
 #pragma unroll
           for (int k = 0; k < NC; k++) q[k] = ldexp(q[k], -e);
         }
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-    // ---- gradient rows: y - posterior ----
-    for (int tt = 0; tt < n; tt++) {
-      const double st = rowsum[tt];
+      // ---- the row: check against the chains' log Z, then y - posterior ----
+      const double st = mine;
       if (!(st > 0.0) || !(st < __builtin_huge_val())) bad = true;
       {
-        const int t = t0 + tt;
-        const int EA = cumA[(t + 1) >> 3], EB = cumB[(t + 8) >> 3];
-        const double lz_row = log(st) + (double)(EA + EB) * 0.693147180559945309417 - lz_tilt;
-        // (absolute: a row sum off by more than 2e-6 relative means cells that mattered were stored with too few bits)
-        if (!(fabs(lz_row - logz) <= 2e-6 + 1e-12 * fabs(logz))) bad = true;
+        const int EA = cumA_at((t + 1) >> 3), EB = cumB_at((t + 8) >> 3);
+        int ex;
+        const double mant = frexp(st, &ex);                       // st = mant 2^ex, mant in [0.5, 1)
+        const float dev = __builtin_amdgcn_logf((float)mant) - z2f + (float)((double)(ex + EA + EB) - z2i);
+        // (a row sum off by more than 2e-6 relative means cells that mattered were stored with too few bits)
+        if (!(fabsf(dev) <= 3e-6f)) bad = true;
       }
-      const double inv = 1.0 / st;
+      double inv = __builtin_amdgcn_rcp(st);
+      inv = fma(fma(-st, inv, 1.0), inv, inv);                    // (one Newton step: 2^-40 relative)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the atomics have landed: one wave, in-order LDS)
       for (int v = lane; v < V; v += 64) {
-        double pv = post[tt * V + v];
-        if (v == blank) pv += blanksum[tt];
-        grads[(size_t)(t0 + tt) * V + v] = (IO)((y(t0 + tt, v) - pv * inv) * p.gscale);
+        double pv = post[v];
+        if (v == blank) pv += myblank;
+        grads[(size_t)t * V + v] = (IO)((y(tt, v) - pv * inv) * p.gscale);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
   }
-  if (__any(bad)) { if (lane == 0) atomicOr(&s_bad, 1); }
-  __syncthreads();
-  return s_bad == 0;
+  return !__any(bad);
 }
 
 // One utterance b, with the alpha slab `slot` of the workspace.
+// (forced inline: out of line the parameter block is handed over through scratch memory and every pointer in it becomes
+// a generic one -- flat loads behind scratch loads)
 template <typename IO>
-__device__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, int slot) {
+__device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, int slot) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int V = p.V, Tmax = p.T, Lmax = p.Lmax, Smax = p.Smax, blank = p.blank;
@@ -269,18 +321,7 @@ __device__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, 
   double* wa = p.ws_alpha + (size_t)slot * (size_t)Tmax * (size_t)Lmax;
   double* wl = p.ws_lse + (size_t)slot * (size_t)Tmax;
 
-  if (p.mode != 0 && p.flags[b] == 0) return;
-  if (p.mode == 1 && p.has_retry && (p.flags[b] & ~(8 | 16)) == 0) {
-    // only the f32 segment kernel's range gave out: redo that part in f64; the full recomputation below only if even
-    // that fails
-    bool ok = false;
-    if (p.retry.PPL == 1) ok = retry_segments_f64<IO, 1>(p, smem, b, slot);
-    else if (p.retry.PPL == 2) ok = retry_segments_f64<IO, 2>(p, smem, b, slot);
-    else if (p.retry.PPL == 4) ok = retry_segments_f64<IO, 4>(p, smem, b, slot);
-    __syncthreads();
-    if (ok) return;
-    if (tid == 0 && p.ctl) atomicAdd(&p.ctl[1], 1);      // (diagnostics: redone in full although only the segments' range gave out)
-  }
+  if (p.mode == 2 && p.flags[b] == 0) return;
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   if (p.mode == 2 || Tq < 1 || Tq > Tmax || Sq < 0 || Sq > Smax) {   // invalid lengths: poison, do not crash
     const double qnan = __builtin_nan("");
@@ -454,68 +495,170 @@ __device__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, 
   }
 }
 
-// Workgroups stride over the batch (gridDim.x slabs of workspace).  In flagged mode the grid is small: only the
-// utterances the fast path handed over are computed, one after the other per workgroup.
+constexpr int kFlagCache = 2048;    // utterances whose flag words and segment counts a workgroup keeps in LDS
+constexpr int kRedoFailed = 512;    // flag bit set by the segment redo
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+  return v;
+}
+
+// Every utterance (mode 0): workgroups stride over the batch, one alpha slab each.
+// Flagged modes (the tail of every fast-path call): in the usual case of nothing flagged the launch only writes the
+// optional sum / mean of the losses.  Otherwise (mode 1)
+//   1. utterances flagged for range only (bits 8 / 16) have their segments redone in f64, one wave per segment, spread over
+//      all waves of the launch (retry_segment_f64);
+//   2. utterances flagged for anything else are recomputed by the reference's arithmetic, one workgroup each, on the
+//      first `nslabs` workgroups (the alpha slabs of the workspace: 24 at most -- 77 MB at B=256, T=1000, S=200 -- instead
+//      of one per workgroup);
+//   3. the last workgroup to finish recomputes what step 1 could not settle (bit 512; rare) and writes the reduction.
 template <typename IO>
 __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  if (p.mode != 0) {
-    // flagged mode, the usual case of nothing to do: all of this workgroup's flags in ONE round trip instead of one per
-    // utterance of its stride (8 dependent loads and barriers at B = 256: 5 us of every call)
-    // flagged mode, the usual case of nothing to do: the whole flag vector in ONE round trip per workgroup (every
-    // workgroup looks at all of it, so that all of them agree on whether anything is flagged)
-    __shared__ int any;
-    if (threadIdx.x == 0) any = 0;
-    __syncthreads();
-    for (int b = threadIdx.x; b < p.B; b += kThreads)
-      if (p.flags[b] != 0) any = 1;
-    __syncthreads();
-    const bool reduce = p.reduced && p.reduction != E2E_REDUCE_NONE;
-    if (!any) {
-      // nothing flagged: the losses the fast path wrote are final; workgroup 0 writes their sum / mean (fixed order)
-      if (reduce && blockIdx.x == 0 && threadIdx.x < 64) {
-        const IO* losses = reinterpret_cast<const IO*>(p.losses);
-        double s = 0.0;
-        for (int b = threadIdx.x; b < p.B; b += 64) s += (double)losses[b];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (threadIdx.x == 0) *reinterpret_cast<IO*>(p.reduced) = (IO)(p.reduction == E2E_REDUCE_MEAN ? s / (double)p.B : s);
-      }
-      return;
+  if (p.mode == 0) {
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+      ctc_exact_one<IO>(p, smem, b, blockIdx.x);
+      __syncthreads();                       // LDS is reused by the next utterance
+    }
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // the whole flag vector in ONE round trip per workgroup (every workgroup looks at all of it, so that all of them agree
+  // on what is flagged); flag words and segment counts are kept in LDS for the walks below
+  __shared__ int any;
+  __shared__ unsigned short s_flag[kFlagCache], s_nseg[kFlagCache];
+  if (tid == 0) any = 0;
+  __syncthreads();
+  for (int b = tid; b < p.B; b += kThreads) {
+    const int f = p.flags[b] & (kRedoFailed - 1);
+    if (f != 0) any = 1;
+    if (b < kFlagCache) {
+      s_flag[b] = (unsigned short)f;
+      const int64_t Tq = f != 0 ? p.x_len[b] : 0;
+      s_nseg[b] = (unsigned short)((Tq >= 1 && Tq <= p.T) ? (Tq + kFastSeg - 1) / kFastSeg : 0);
     }
   }
-  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
-    ctc_exact_one<IO>(p, smem, b, blockIdx.x);
-    __syncthreads();                       // LDS is reused by the next utterance
-  }
-  if (p.mode != 0 && p.reduced && p.reduction != E2E_REDUCE_NONE) {
-    // flagged utterances have their final losses now: the last workgroup to get here reduces all B of them
-    // (release / acquire at agent scope: the losses other workgroups stored must have left their XCD's L2)
-    __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&p.ctl[0], 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (threadIdx.x < 64) {
+  __syncthreads();
+  const bool reduce = p.reduced && p.reduction != E2E_REDUCE_NONE;
+  auto write_reduction = [&](bool coherent) {
+    if (reduce && tid < 64) {
       const IO* losses = reinterpret_cast<const IO*>(p.losses);
       double s = 0.0;
-      for (int b = threadIdx.x; b < p.B; b += 64) s += (double)__hip_atomic_load(&losses[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int b = tid; b < p.B; b += 64)
+        s += coherent ? (double)__hip_atomic_load(&losses[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (double)losses[b];
       for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      if (threadIdx.x == 0) *reinterpret_cast<IO*>(p.reduced) = (IO)(p.reduction == E2E_REDUCE_MEAN ? s / (double)p.B : s);
+      if (tid == 0) *reinterpret_cast<IO*>(p.reduced) = (IO)(p.reduction == E2E_REDUCE_MEAN ? s / (double)p.B : s);
+    }
+  };
+  if (!any) {
+    // nothing flagged: the losses the fast path wrote are final; workgroup 0 writes their sum / mean (fixed order)
+    if (blockIdx.x == 0) write_reduction(false);
+    return;
+  }
+  auto flag_of = [&](int b) -> int { return b < kFlagCache ? (int)s_flag[b] : (p.flags[b] & (kRedoFailed - 1)); };
+  auto nseg_of = [&](int b) -> int {
+    if (b < kFlagCache) return (int)s_nseg[b];
+    const int64_t Tq = p.x_len[b];
+    return (Tq >= 1 && Tq <= p.T) ? (int)((Tq + kFastSeg - 1) / kFastSeg) : 0;
+  };
+  auto range_only = [&](int f) -> bool { return p.mode == 1 && p.has_retry && f != 0 && (f & ~(8 | 16)) == 0; };
+
+  if (p.mode == 2) {
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+      ctc_exact_one<IO>(p, smem, b, 0);      // (poisons flagged utterances, touches no slab)
+      __syncthreads();
+    }
+  } else {
+    // ---- 1. segments of the utterances flagged for range only: item i of the running list goes to wave i mod NW ----
+    const int NW = (int)gridDim.x * p.redo_waves, me = (int)blockIdx.x * p.redo_waves + wid;
+    unsigned char* wsmem = smem + (size_t)wid * retry_wave_lds_bytes(p.V);
+    int base = 0;
+    for (int c0 = 0; c0 < p.B && wid < p.redo_waves; c0 += 64) {
+      const int bb = c0 + lane;
+      const int f = bb < p.B ? flag_of(bb) : 0;
+      const int ns = range_only(f) ? nseg_of(bb) : 0;
+      const int incl = wave_incl_scan(ns, lane);
+      const int tot = __builtin_amdgcn_readlane(incl, 63);
+      if (tot != 0) {
+        const int start = base + incl - ns;
+        int first = (me - start) % NW; if (first < 0) first += NW;       // my first segment of this utterance, if < ns
+        unsigned long long work = __ballot(first < ns);
+        while (work) {
+          const int l = __builtin_ctzll(work); work &= work - 1;
+          const int ub = c0 + l;
+          const int sfirst = __builtin_amdgcn_readlane(first, l), uns = __builtin_amdgcn_readlane(ns, l);
+          for (int seg = sfirst; seg < uns; seg += NW) {
+            bool ok;
+            if (p.retry.PPL == 1) ok = retry_segment_f64<IO, 1>(p, wsmem, ub, seg, lane);
+            else if (p.retry.PPL == 2) ok = retry_segment_f64<IO, 2>(p, wsmem, ub, seg, lane);
+            else ok = retry_segment_f64<IO, 4>(p, wsmem, ub, seg, lane);
+            if (!ok && lane == 0) atomicOr(&p.flags[ub], kRedoFailed);
+          }
+        }
+      }
+      base += tot;
+    }
+    __syncthreads();                         // (the waves' LDS is taken over by the full recomputation)
+    // ---- 2. everything else that is flagged: the reference's arithmetic, utterance h on workgroup h mod nslabs ----
+    int h = 0;
+    for (int c0 = 0; c0 < p.B; c0 += 64) {
+      const int bb = c0 + lane;
+      const int f = bb < p.B ? flag_of(bb) : 0;
+      unsigned long long hard = __ballot(f != 0 && !range_only(f));
+      while (hard) {
+        const int l = __builtin_ctzll(hard); hard &= hard - 1;
+        if ((int)blockIdx.x < p.nslabs && h % p.nslabs == (int)blockIdx.x) {
+          ctc_exact_one<IO>(p, smem, c0 + l, blockIdx.x);
+          __syncthreads();
+        }
+        h++;
+      }
     }
   }
+  // ---- 3. the last workgroup to get here: what the segment redo could not settle, then the reduction ----
+  // (release / acquire at agent scope: what other workgroups stored must have left their XCD's L2)
+  __shared__ int s_last;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&p.ctl[0], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (p.mode == 1) {
+    for (int c0 = 0; c0 < p.B; c0 += 64) {
+      const int bb = c0 + lane;
+      const int f = bb < p.B ? __hip_atomic_load(&p.flags[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      unsigned long long failed = __ballot((f & kRedoFailed) != 0);
+      while (failed) {
+        const int l = __builtin_ctzll(failed); failed &= failed - 1;
+        if (tid == 0) atomicAdd(&p.ctl[1], 1);          // (diagnostics: redone in full although only the segments' range gave out)
+        ctc_exact_one<IO>(p, smem, c0 + l, 0);
+        __syncthreads();
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+  }
+  write_reduction(true);
 }
 
 size_t exact_lds_bytes(int V, int Smax) {
   const size_t Lmax = 2 * (size_t)Smax + 1, S1 = Smax > 0 ? Smax : 1;
   return sizeof(double) * (2 * Lmax + S1 + (size_t)V + 16) + sizeof(int) * (Lmax + 2 * S1);
 }
-size_t retry_lds_bytes(int V) { return sizeof(double) * (kThreads / 64) * kFastSeg * ((size_t)V + 2); }
+// waves per workgroup that fit the redo's LDS beside the kernel's static 8.5 KB (wide alphabets: fewer than 8)
+int retry_waves(int V) {
+  const size_t n = (160 * 1024 - 10 * 1024) / retry_wave_lds_bytes(V);
+  return n < 1 ? 0 : n > (size_t)(kThreads / 64) ? kThreads / 64 : (int)n;
+}
+size_t retry_lds_bytes(int V) { return retry_waves(V) * retry_wave_lds_bytes(V); }
 
 }  // namespace
 
-constexpr int kFallbackSlabs = 256;    // workgroups (= alpha slabs, 3.2 MB each at C2) of the flagged-utterance fallback launch
+constexpr int kFallbackSlabs = 24;     // alpha slabs (3.2 MB each at C2) of the flagged-utterance launch: the workgroups that may run the full
+                                       // recomputation at the same time.  (256 of them -- one per workgroup, 821 MB -- until the f64 redo
+                                       // of the segments moved to one wave per segment and needed none.)
+constexpr int kFallbackGrid = 256;     // workgroups of that launch: 2 048 waves for the redo of the segments
 
 static size_t exact_bytes_for(int slabs, int T, int Smax) {
   const size_t Lmax = 2 * (size_t)Smax + 1;
@@ -532,11 +675,11 @@ size_t exact_fallback_workspace_bytes(int B, int T, int V, int Smax) {
   return exact_bytes_for(B < kFallbackSlabs ? B : kFallbackSlabs, T, Smax);
 }
 
-int launch_exact_flagged(const LossArgs& a, const int* flags, int mode, const FastRetry* retry);
+int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetry* retry);
 
 int launch_exact(const LossArgs& a) { return launch_exact_flagged(a, nullptr, 0, nullptr); }
 
-int launch_exact_flagged(const LossArgs& a, const int* flags, int mode, const FastRetry* retry) {
+int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetry* retry) {
   size_t lds = exact_lds_bytes(a.V, a.Smax);
   if (mode == 1 && retry && retry_lds_bytes(a.V) > lds) lds = retry_lds_bytes(a.V);
   if (lds > 160 * 1024) {
@@ -553,16 +696,17 @@ int launch_exact_flagged(const LossArgs& a, const int* flags, int mode, const Fa
   p.x = a.x; p.sB = a.sB; p.sT = a.sT; p.sV = a.sV; p.logprobs = a.logprobs;
   p.targets = a.targets; p.tgt_stride = a.tgt_stride; p.x_len = a.x_len; p.t_len = a.t_len;
   p.B = a.B; p.T = a.T; p.V = a.V; p.Smax = a.Smax; p.Lmax = 2 * a.Smax + 1; p.blank = a.blank;
-  p.losses = a.losses; p.grads = a.grads; p.flags = flags; p.mode = mode;
+  p.losses = a.losses; p.grads = a.grads; p.flags = flags; p.mode = mode; p.nslabs = slabs;
   p.ctl = retry ? retry->ctl : nullptr;
   p.gscale = a.grad_scale; p.reduced = mode != 0 ? a.reduced : nullptr; p.reduction = a.reduction;
   if (mode != 0 && !p.ctl) { set_error("internal: flagged exact launch without control words"); return E2E_ERR_ARG; }
-  p.has_retry = (mode == 1 && retry && a.dtype == E2E_F32) ? 1 : 0;
+  p.has_retry = (mode == 1 && retry && a.dtype == E2E_F32 && retry_waves(a.V) > 0) ? 1 : 0;
+  p.redo_waves = retry_waves(a.V);
   if (p.has_retry) p.retry = *retry; else memset(&p.retry, 0, sizeof(p.retry));
   p.ws_alpha = reinterpret_cast<double*>(a.ws);
   p.ws_lse = reinterpret_cast<double*>(reinterpret_cast<char*>(a.ws) +
                                        align_up((size_t)slabs * a.T * p.Lmax * sizeof(double), 256));
-  const int grid = mode == 2 ? a.B : slabs;
+  const int grid = mode == 0 ? slabs : (a.B < kFallbackGrid ? a.B : kFallbackGrid);
   if (a.B == 0) return E2E_OK;
   if (a.dtype == E2E_F32) {
     E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_exact_kernel<float>),

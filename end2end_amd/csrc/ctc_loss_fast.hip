@@ -2242,7 +2242,7 @@ size_t fast_workspace_bytes(int B, int T, int V, int Smax) {
   return fast_layout(B, T, V, Smax).total;
 }
 
-int launch_exact_flagged(const LossArgs& a, const int* flags, int mode, const FastRetry* retry);
+int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetry* retry);
 
 int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   const FastLayout l = fast_layout(a.B, a.T, a.V, a.Smax);

@@ -434,3 +434,29 @@ def test_shapes_outside_the_fast_paths_are_still_served(shape):
     l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
     U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
     U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
+
+
+def test_more_fully_recomputed_utterances_than_alpha_slabs_and_a_mixed_batch():
+    """The flagged-utterance launch keeps 24 alpha slabs: 60 utterances that all need the reference's arithmetic (infeasible
+    alignments, a blank-valued target) are strided over them; range-flagged ones in the same batch have their segments
+    redone in f64 by the launch's other waves; the fused mean must be that of the final losses."""
+    rng = np.random.default_rng(11)
+    B, T, V, S = 96, 260, 29, 140
+    x = (rng.standard_normal((B, T, V))).astype(np.float32)
+    x[60:80] *= 8.0                                             # sharp, unrelated: the f32 segment rows leave their range
+    tg = rng.integers(1, V, size=(B, S)); tl = rng.integers(60, 100, size=B); xl = np.full(B, T)
+    xl[:50] = rng.integers(20, 56, size=50)                     # fewer frames than labels (>= 60): infeasible
+    tg[50:60, 3] = 0                                            # a target equal to the blank id
+    xt = torch.from_numpy(x)
+    lp = torch.log_softmax(xt.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg, xl, tl, 0)
+    for b in range(50, B):
+        g_o[b, xl[b]:] = 0                                      # fused logits: padded frames get 0
+    g_o[:50] = np.nan                                           # (quirk Q2: an infeasible utterance's whole slab)
+    la, ga, red = U.c_abi_loss(xt, tg, xl, tl, 0, False, _lib.ALGO_AUTO, opts=(1.0, _lib.REDUCE_SUM))
+    assert np.isinf(l_o[:50]).all() and np.isfinite(l_o[50:]).all()
+    U.assert_same(la, l_o, F32_RTOL, 2e-5, "losses")
+    U.assert_same(ga, g_o, F32_RTOL, F32_ATOL, "grads")
+    assert np.isinf(red) and red > 0
+    la2, _, red2 = U.c_abi_loss(xt[50:], tg[50:], xl[50:], tl[50:], 0, False, _lib.ALGO_AUTO, opts=(1.0, _lib.REDUCE_MEAN))
+    assert abs(red2 - l_o[50:].mean()) <= 1e-5 * abs(l_o[50:].mean())
