@@ -9,8 +9,10 @@
 // HBM layout: alpha rows go to the workspace as [b][t][j] doubles (row stride
 // Lmax = 2*Smax+1) so that a time step is one coalesced row write in the alpha
 // sweep and one coalesced row read in the beta sweep.  LDS holds the extended
-// label row, the previous lattice row (double-buffered), the per-label
-// posterior accumulator post[V] and the label-sorted cell order.
+// label row, the previous lattice row (double-buffered), the label-sorted cell
+// order with one posterior sum per distinct label, and one BIT per alphabet column
+// (is it one of the utterance's labels) -- nothing V-wide in doubles, so no alphabet
+// is too wide for the kernel (word-piece vocabularies: 32 000 columns = 4 KB).
 #include <string.h>
 
 #include "common.h"
@@ -309,11 +311,11 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
   double* buf0 = reinterpret_cast<double*>(smem);          // [Lmax]
   double* buf1 = buf0 + Lmax;                              // [Lmax]
   double* psorted = buf1 + Lmax;                           // [Smax] label-sorted posteriors
-  double* post = psorted + (Smax > 0 ? Smax : 1);          // [V]
-  double* red = post + V;                                  // [16]
+  double* red = psorted + (Smax > 0 ? Smax : 1);           // [16]
   int* ext = reinterpret_cast<int*>(red + 16);             // [Lmax]
   int* rank = ext + Lmax;                                  // [Smax] rank of target i in label order
   int* sorted_lab = rank + (Smax > 0 ? Smax : 1);          // [Smax] label at sorted position r
+  unsigned* is_label = reinterpret_cast<unsigned*>(sorted_lab + (Smax > 0 ? Smax : 1));   // [(V+31)/32] bit v: column v is a target label
 
   const IO* x = reinterpret_cast<const IO*>(p.x) + (int64_t)b * p.sB;
   IO* grads = reinterpret_cast<IO*>(p.grads) + (size_t)b * (size_t)Tmax * (size_t)V;
@@ -341,7 +343,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
     }
     ext[j] = (int)lab;
   }
-  for (int v = tid; v < V; v += kThreads) post[v] = 0.0;
+  for (int v = tid; v < (V + 31) / 32; v += kThreads) is_label[v] = 0u;
   if (tid == 0) red[8] = 0.0;
   if (__syncthreads_or(bad_label)) {
     // a target outside [0,V) would index the row and the per-label sums out of bounds (the reference reads garbage
@@ -363,6 +365,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
     }
     rank[i] = r;
     sorted_lab[r] = li;
+    if (li != blank) atomicOr(&is_label[li >> 5], 1u << (li & 31));       // (after the barrier above that cleared the map)
   }
   if (!p.logprobs) {
     for (int t = wid; t < Tmax; t += kThreads / 64) {
@@ -464,7 +467,12 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
         double s = psorted[r];
         for (int q = r + 1; q < S && sorted_lab[q] == lab; q++) s += psorted[q];
         // a target equal to the blank id shares the blank column (ctc_loss.cpp:109-113 keys on the label)
-        if (lab != blank) post[lab] = s; else red[8] = s;
+        if (lab != blank) {
+          // the label's column of the gradient row, written here by the thread that holds its sum (the dense pass below
+          // skips the columns that are labels)
+          const double rl_ = p.logprobs ? 0.0 : wl[t];
+          grads[(size_t)t * V + lab] = (IO)((exp((double)x[(int64_t)t * p.sT + (int64_t)lab * p.sV] - rl_) - s) * p.gscale);
+        } else red[8] = s;
       }
     }
     if (tid == kThreads - 1) {
@@ -478,12 +486,14 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
       const IO* xrow = x + (int64_t)t * p.sT;
       const double rl = p.logprobs ? 0.0 : wl[t];
       for (int v = tid; v < V; v += kThreads) {
-        // blank column = even cells (+ target cells whose label equals the blank id, red[8])
-        const double pv = (v == blank) ? red[9] + red[8] : post[v];
+        // blank column = even cells (+ target cells whose label equals the blank id, red[8]); every other column that is
+        // not a label has posterior 0
+        if ((is_label[v >> 5] >> (v & 31)) & 1u) continue;
+        const double pv = (v == blank) ? red[9] + red[8] : 0.0;
         grow[v] = (IO)((exp((double)xrow[(int64_t)v * p.sV] - rl) - pv) * p.gscale);
       }
     }
-    // next iteration's writes to psorted/red/post happen after its own first barrier or touch
+    // next iteration's writes to psorted/red happen after its own first barrier or touch
     // buffers nobody reads here (be_cur of t-1 is be_next of t, last read before the barrier above)
     __syncthreads();
   }
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
 
 size_t exact_lds_bytes(int V, int Smax) {
   const size_t Lmax = 2 * (size_t)Smax + 1, S1 = Smax > 0 ? Smax : 1;
-  return sizeof(double) * (2 * Lmax + S1 + (size_t)V + 16) + sizeof(int) * (Lmax + 2 * S1);
+  return sizeof(double) * (2 * Lmax + S1 + 16) + sizeof(int) * (Lmax + 2 * S1 + ((size_t)V + 31) / 32);
 }
 // waves per workgroup that fit the redo's LDS beside the kernel's static 8.5 KB (wide alphabets: fewer than 8)
 int retry_waves(int V) {

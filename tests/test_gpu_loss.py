@@ -417,7 +417,27 @@ def test_full_c5_shape_properties():
     U.assert_same(grads[idx], g_o, F32_RTOL, 5e-7, "grads")
 
 
-@pytest.mark.parametrize("shape", [(2, 400, 500, 150), (2, 700, 29, 300), (1, 650, 3000, 300), (2, 300, 97, 120)],
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_word_piece_vocabularies_are_served_whatever_the_dtype(dtype):
+    """V = 32 000 with more than 95 distinct labels (and f64 input at any target length): the exact kernel keeps one BIT per
+    alphabet column in LDS, not a double -- no (V, S, dtype) is refused (src/losses/ctc_loss.cpp:25-36 has no bounds)."""
+    g = torch.Generator().manual_seed(9)
+    B, T, V, S = 2, 150, 32000, 120
+    x = torch.randn(B, T, V, generator=g).to(dtype)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tg[0, 5] = tg[0, 4]; tg[1, 7] = 0                        # a repeat, and a target equal to the blank id
+    xl = torch.tensor([T, T - 13]); tl = torch.tensor([S, 70])
+    losses, grads = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_AUTO)
+    lp = torch.log_softmax(x.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    g_o[1, T - 13:] = 0
+    rt, at = (F32_RTOL, F32_ATOL) if dtype == torch.float32 else (1e-9, 1e-12)
+    U.assert_same(losses, l_o, rt, at * 10, "losses")
+    U.assert_same(grads, g_o, rt, at, "grads")
+
+
+@pytest.mark.parametrize("shape", [(2, 400, 500, 150), (2, 700, 29, 300), (1, 650, 3000, 300), (2, 300, 97, 120),
+                                   (2, 256, 8000, 200), (1, 2000, 29, 400)],
                          ids=lambda s: "B%d_T%d_V%d_S%d" % s)
 def test_shapes_outside_the_fast_paths_are_still_served(shape):
     """Targets longer than 255 labels, or more than 95 distinct labels at an alphabet beyond 96 columns: neither the
