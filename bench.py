@@ -313,6 +313,15 @@ def decode_numbers(dev, with_cpu):
     dt = timed(lambda: eng.decode(xw, xlw), 1)
     out["beam100_wide_alphabet"] = {"workload": "B=16 T=256 V=8000 beam=100, no LM (general kernel)",
                                     "utterances_per_s": 16 / dt, "ms": dt * 1e3}
+    if with_cpu:
+        # a bounded sample: 4 of the 16 utterances, first 64 frames (the restatement scores all V children of every prefix
+        # per frame as upstream does: ~0.2 s per utterance and 64 frames on one core)
+        xs = xw[:4, :64].double().cpu().numpy()
+        cb = cpu_timed(lambda: O.ctc_beam(xs, None, 0, 100, None, None, n_threads=0), 4,
+                       "4 of the 16 utterances, frames 0..63 of 256")
+        cb["value"] = cb["value"] * 64.0 / 256.0            # utterances/s at the full 256 frames (cost is linear in T)
+        cb["sample"] += "; value scaled by 64/256 to full-length utterances"
+        out["beam100_wide_alphabet"]["cpu_baseline"] = cb
     return out
 
 

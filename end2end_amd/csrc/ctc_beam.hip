@@ -1188,6 +1188,16 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
 constexpr int kGenMaxW = 256;
 constexpr int kGenThreads = 1024;
 
+// Character pre-selection of the general kernel (no language model): capacity of the per-step character list and words of
+// the character bitmap in LDS (alphabets beyond 2^16 columns take every character, as before).
+__host__ __device__ inline int gen_list_cap(int W) { return 4 * W + 64; }
+__host__ __device__ inline int gen_bitmap_words(int V) { return V <= 65536 ? (V + 31) / 32 : 1; }
+// order-preserving 32-bit key of a float (larger value -> larger key; -0 < +0 does not matter here)
+__device__ __forceinline__ unsigned okey32(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 struct GenParams {
   unsigned long long* gkey;      // [B][W + W*V]
   LmAnswer* lmc;                 // [B][2][W][V]   (null without a language model)
@@ -1234,9 +1244,12 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
   int* s_part = (int*)q8; q8 += sizeof(int) * 64;
   int* const sm0 = (int*)q8; q8 += sizeof(int) * 4 * p.HS;                  // [set][key | val][HS]  node -> position
   int* const cm0 = (int*)q8; q8 += sizeof(int) * 4 * g.CH;                  // [set][key | val][CH]  (position, char) -> child node
+  int* const s_lst = (int*)q8; q8 += sizeof(int) * gen_list_cap(W);         // this step's characters, ascending
+  unsigned* const s_bits = (unsigned*)q8; q8 += sizeof(unsigned) * gen_bitmap_words(V);   // one bit per character
   auto slot_map = [&](int set) { SlotMap m; m.key = sm0 + set * 2 * p.HS; m.val = m.key + p.HS; m.mask = p.HS - 1; return m; };
   auto child_map = [&](int set) { ChildMap m; m.key = cm0 + set * 2 * g.CH; m.val = m.key + g.CH; m.mask = g.CH - 1; return m; };
-  __shared__ int s_next_node, s_err, s_krem, s_done, s_total_new;
+  __shared__ int s_next_node, s_err, s_krem, s_done, s_total_new, s_nl;
+  __shared__ unsigned s_fmax, s_ckey;
   __shared__ unsigned s_hi, s_lo;
   __shared__ unsigned long long s_prefix;
   LabelTab lt; lt.off = p.lm.label_off; lt.bytes = p.lm.label_bytes;
@@ -1281,17 +1294,113 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
     if (tid == 0) { s_hi = 0u; s_lo = 0xffffffffu; s_total_new = 0; }
     for (int h = tid; h < kSelBins; h += kThreads) hist[h] = 0;
     __syncthreads();
+    // ---- which characters can matter this step (no language model) ----
+    // Without a language model the score of a would-be prefix (i, c) is lp[c] + full_i - wip * words, monotone in lp[c] for a
+    // given prefix except for c = the prefix's last character (it extends from ppb_i) and c = space (the word count).  A
+    // prefix has at most m_i <= W characters whose child already lives (no candidate), so its candidate of rank > 2W in
+    // lp order has >= W candidates of the same prefix before it in the reference's order (score desc, position asc: equal
+    // lp, lower c first) and cannot be among the W survivors.  The step therefore scores, for every prefix, only
+    // L = {the 2W largest lp[c], every c tied with the last of them} + {space} + {last_i}, in ascending c so that the order
+    // of the keys stays the reference's: |L| * n <= (3W + 1) * W keys instead of V * n (10 k instead of 800 k at V = 8000,
+    // W = 100).  Exact unless two DIFFERENT lp values could round to the same score, i.e. unless |full| is within 2^24 of
+    // their spacing: f32 inputs and |full| < 2^20 only; otherwise, with a language model, for tiny alphabets or if the ties
+    // overflow the list, every character is taken as before.
+    bool pre = LMK == 0 && sizeof(IO) == 4 && V <= 65536 && V - 1 > 3 * W + 2;
+    if (pre) {
+      if (tid == 0) s_fmax = 0u;
+      __syncthreads();
+      unsigned fm = 0u;
+      for (int i = tid; i < n; i += kThreads) fm = max(fm, __float_as_uint(fabsf((float)A.full[i])));
+      fm = (unsigned)wave_max_i((int)fm);
+      if (lane == 0 && fm) atomicMax(&s_fmax, fm);
+      __syncthreads();
+      pre = __uint_as_float(s_fmax) < 1048576.f;
+    }
+    int NL = V;
+    if (pre) {
+      // threshold: the key of the (2W)-th largest lp[c], c != blank -- radix select over V 32-bit keys, 11 bits per pass
+      const int want = 2 * W;
+      unsigned prefix = 0u, maskc = 0u;
+      int krem = want;
+      for (int pass = 0; pass < 3; pass++) {
+        const int shift = pass == 0 ? 21 : pass == 1 ? 10 : 0, width = pass == 2 ? 10 : 11;
+        for (int c = tid; c < V; c += kThreads) {
+          if (c == blank) continue;
+          const unsigned u = okey32((float)LP(c));
+          if ((u & maskc) == prefix) atomicAdd(&hist[(int)((u >> shift) & ((1u << width) - 1u))], 1);
+        }
+        __syncthreads();
+        constexpr int kPer = kSelBins / kThreads;
+        const int top = kSelBins - 1 - kPer * tid;
+        int cnt[kPer], mine = 0;
+#pragma unroll
+        for (int jj = 0; jj < kPer; jj++) { cnt[jj] = hist[top - jj]; mine += cnt[jj]; }
+        const int inc = wave_scan_i(mine);
+        if (lane == 63) s_part[wid] = inc;
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < kPer; jj++) hist[top - jj] = 0;
+        int above = inc - mine;
+        {
+          const int wtot = wave_scan_i(lane < kThreads / 64 ? s_part[lane] : 0);
+          if (wid > 0) above += __builtin_amdgcn_readlane(wtot, wid - 1);
+        }
+        if (above < krem && above + mine >= krem) {
+#pragma unroll
+          for (int jj = 0; jj < kPer; jj++) {
+            if (above + cnt[jj] >= krem) { s_krem = krem - above; s_ckey = prefix | ((unsigned)(top - jj) << shift); break; }
+            above += cnt[jj];
+          }
+        }
+        __syncthreads();
+        krem = s_krem; prefix = s_ckey; maskc |= ((1u << width) - 1u) << shift;
+        __syncthreads();
+      }
+      const unsigned Tk = prefix;                        // every c with key >= Tk is taken (ties with the 2W-th included)
+      const int words = (V + 31) / 32;
+      for (int wd = tid; wd < words; wd += kThreads) s_bits[wd] = 0u;
+      __syncthreads();
+      for (int c = tid; c < V; c += kThreads)
+        if (c != blank && okey32((float)LP(c)) >= Tk) atomicOr(&s_bits[c >> 5], 1u << (c & 31));
+      if (tid == 0 && p.space_id >= 0 && p.space_id < V && p.space_id != blank) atomicOr(&s_bits[p.space_id >> 5], 1u << (p.space_id & 31));
+      for (int i = tid; i < n; i += kThreads) { const int lc = A.last[i]; if (lc >= 0 && lc != blank) atomicOr(&s_bits[lc >> 5], 1u << (lc & 31)); }
+      __syncthreads();
+      // the list, ascending: word wd's characters start at the number of bits set before it
+      int run = 0;                                       // (bits set in the words of earlier rounds)
+      for (int w0 = 0; w0 < words; w0 += kThreads) {
+        const int wd = w0 + tid;
+        const unsigned bits = wd < words ? s_bits[wd] : 0u;
+        const int pc = __builtin_popcount(bits);
+        const int inc = wave_scan_i(pc);
+        if (lane == 63) s_part[wid] = inc;
+        __syncthreads();
+        int off = run + inc - pc, tot = 0;
+        for (int w2 = 0; w2 < kThreads / 64; w2++) { if (w2 < wid) off += s_part[w2]; tot += s_part[w2]; }
+        unsigned bb = bits;
+        while (bb) { const int bit = __builtin_ctz(bb); bb &= bb - 1; if (off < gen_list_cap(W)) s_lst[off] = wd * 32 + bit; off++; }
+        run += tot;
+        __syncthreads();
+      }
+      if (tid == 0) s_nl = run;
+      __syncthreads();
+      NL = s_nl;
+      if (NL > gen_list_cap(W)) { pre = false; NL = V; }        // (more ties than the list holds: every character)
+    }
+    auto CH = [&](int sidx) -> int { return pre ? s_lst[sidx] : sidx; };
     // ---- pairs: candidate q = c*n + i is the reference's order (character outer, prefix inner, :370-395) ----
-    const int npairs = n * V;
+    // (the blank creates no candidate: its share of every member is taken first)
+    for (int i = tid; i < n; i += kThreads) A.npb[i] = LP(blank) + A.full[i];      // :374-376 (prob_blank was -inf)
+    const int npairs = n * NL;
     int my_new = 0;
     unsigned key_hi = 0u, key_lo = 0xffffffffu;
     for (int e = tid; e < npairs; e += kThreads) {
-      const int ii = e / V, ci = e - ii * V;
+      const int si = e / n, ii = e - si * n;            // (slot si of the list outer, prefix inner: the reference's order)
+      const int ci = CH(si);
       const double full = A.full[ii], ppb = A.ppb[ii];
       const int last = A.last[ii];
       const double curp = LP(ci);
-      unsigned long long* const slot = gkey + n + (size_t)ci * n + ii;
-      if (ci == blank) { *slot = kNoCandKey; A.npb[ii] = curp + full; continue; }   // :374-376 (prob_blank was -inf)
+      unsigned long long* const slot = gkey + n + e;
+      if (ci == blank) { *slot = kNoCandKey; continue; }
       const double val = curp + (ci == last ? ppb : full);                     // :383-385 / :389-391
       const int k = cmA.find(ii * V + ci);
       unsigned long long uk = kNoCandKey;
@@ -1353,7 +1462,8 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
         mapB.insert(A.node[i], j);
       } else {
         const int q = d - n;
-        const int c = q / n, i = q - c * n;
+        const int si = q / n, i = q - si * n;
+        const int c = CH(si);
         const double val = LP(c) + (c == A.last[i] ? A.ppb[i] : A.full[i]);
         LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
         if (LM) ans = lmcA[(size_t)i * V + c];
@@ -1540,7 +1650,7 @@ GenLayout gen_layout(int B, int V, int W, int WP2, int HS, bool lm) {
   l.lmc = o; if (lm) o += align_up((size_t)B * 2 * (size_t)W * V * sizeof(LmAnswer), 256);
   l.total = o;
   l.lds = 2 * Members::bytes(W) + (sizeof(unsigned long long) + sizeof(double) + sizeof(int)) * (size_t)(WP2 + 8) +
-          sizeof(int) * (kSelBins + 64 + 4 * (size_t)HS + 4 * (size_t)l.CH) + 64;
+          sizeof(int) * (kSelBins + 64 + 4 * (size_t)HS + 4 * (size_t)l.CH + (size_t)gen_list_cap(W) + (size_t)gen_bitmap_words(V)) + 64;
   return l;
 }
 
