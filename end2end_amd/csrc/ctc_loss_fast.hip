@@ -2146,6 +2146,12 @@ __global__ __launch_bounds__(64, E2E_F2_MINW) void ctc_fast_segment_kernel(FastP
   segment_wave<PPL>(p, smem);
 }
 
+// (Two waves per segment -- a 128-thread workgroup, two label pairs per lane, the waves' lattice halves overlapping by 18
+// pairs so that nothing crosses between them inside the 16 steps, rows of a half split between the waves for the scan and
+// the gradient, 154 registers and three waves per SIMD -- was built, parity-green on the whole loss suite, and measured:
+// 145 against 133 us per step.  The waves split the lattice but not the bookkeeping: a wave of the pair executes ~80 % of
+// the one-wave kernel's instructions (its scalar work does not shrink at all), and this kernel's time is its instruction
+// count -- a SIMD issues one per ~4.3 cycles with two such waves and one per ~3.5 with three.)
 // (Persistent segment waves -- G waves per utterance, each walking every G-th segment with the next segment's inputs
 // requested one segment ahead by LDS-DMA (global_load_lds, no destination registers) and a counted vmcnt wait that lets the
 // gradient stores drain under the next segment -- were built, parity-green, and measured: 137 against 131 us per step.  The
