@@ -1184,8 +1184,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
 //   * the frame's log-probabilities are read from the input where they are needed (no staging).
 // Barriers are full (__syncthreads after a workgroup fence): data crosses threads through global memory here.
 // Not tuned: it exists so that an alphabet the fast kernel cannot hold is decoded at all, on the device, with
-// the same result (tests run the whole beam suite through it: E2E_BEAM_GENERAL=1).  beam_width <= kGenMaxW.
-constexpr int kGenMaxW = 256;
+// the same result (tests run the whole beam suite through it: E2E_BEAM_GENERAL=1).  beam_width <= kGenMaxW and what the
+// maps and the selection's arrays leave of one workgroup's LDS (the member sets move to the workspace beyond ~256): 512.
+constexpr int kGenMaxW = 1024;
 constexpr int kGenThreads = 1024;
 
 // Character pre-selection of the general kernel (no language model): capacity of the per-step character list and words of
@@ -1201,6 +1202,7 @@ __device__ __forceinline__ unsigned okey32(float f) {
 struct GenParams {
   unsigned long long* gkey;      // [B][W + W*V]
   LmAnswer* lmc;                 // [B][2][W][V]   (null without a language model)
+  unsigned char* gmem;           // [B][2][Members::bytes(W)]: both member sets, when they no longer fit LDS (else null)
   int CH;                        // child map slots (power of two >= 4W)
 };
 
@@ -1234,9 +1236,11 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
   const int V = p.V, W = p.W, blank = p.blank;
   // ---- LDS carve-up ----
   unsigned char* q8 = smem;
-  unsigned char* const mem0 = q8;
+  // the two member sets: LDS while they fit beside the rest, else the workspace (beams of several hundred hypotheses:
+  // every access to a member then goes to L2 -- slower per step, but upstream has no bound on the width at all)
   const size_t mbytes = Members::bytes(W);
-  q8 += 2 * mbytes;
+  unsigned char* const mem0 = g.gmem ? g.gmem + (size_t)blockIdx.x * 2 * mbytes : q8;
+  if (!g.gmem) q8 += 2 * mbytes;
   unsigned long long* uskey = (unsigned long long*)q8; q8 += sizeof(unsigned long long) * (p.WP2 + 8);
   double* fkey = (double*)q8; q8 += sizeof(double) * (p.WP2 + 8);          // final scores
   int* sidx = (int*)q8; q8 += sizeof(int) * (p.WP2 + 8);
@@ -1641,16 +1645,19 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
   }
 }
 
-struct GenLayout { size_t gkey, lmc, total, lds; int CH; };
+struct GenLayout { size_t gkey, lmc, gmem, total, lds; int CH; bool members_in_ws; };
 GenLayout gen_layout(int B, int V, int W, int WP2, int HS, bool lm) {
   GenLayout l;
   l.CH = 256; while (l.CH < 4 * W) l.CH <<= 1;
   size_t o = 0;
   l.gkey = o; o += align_up((size_t)B * ((size_t)W + (size_t)W * V) * sizeof(unsigned long long), 256);
   l.lmc = o; if (lm) o += align_up((size_t)B * 2 * (size_t)W * V * sizeof(LmAnswer), 256);
+  l.gmem = o; o += align_up((size_t)B * 2 * Members::bytes(W), 256);       // (used only when the member sets leave LDS)
   l.total = o;
-  l.lds = 2 * Members::bytes(W) + (sizeof(unsigned long long) + sizeof(double) + sizeof(int)) * (size_t)(WP2 + 8) +
+  const size_t rest = (sizeof(unsigned long long) + sizeof(double) + sizeof(int)) * (size_t)(WP2 + 8) +
           sizeof(int) * (kSelBins + 64 + 4 * (size_t)HS + 4 * (size_t)l.CH + (size_t)gen_list_cap(W) + (size_t)gen_bitmap_words(V)) + 64;
+  l.members_in_ws = rest + 2 * Members::bytes(W) > (size_t)kLdsBudget;
+  l.lds = rest + (l.members_in_ws ? 0 : 2 * Members::bytes(W));
   return l;
 }
 
@@ -1764,6 +1771,7 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
     GenParams g;
     g.gkey = reinterpret_cast<unsigned long long*>(ws + l.total + gl.gkey);
     g.lmc = lm ? reinterpret_cast<LmAnswer*>(ws + l.total + gl.lmc) : nullptr;
+    g.gmem = gl.members_in_ws ? reinterpret_cast<unsigned char*>(ws + l.total + gl.gmem) : nullptr;
     g.CH = gl.CH;
     const void* gfn;
     if (dtype == E2E_F32)

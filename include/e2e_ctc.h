@@ -173,15 +173,15 @@ double e2e_lm_score(const e2e_lm* lm, const uint32_t* ctx /* host */, int ctx_le
  *               out_len[b] == -1             the prefix-tree node pool ran out (cannot happen with a workspace
  *                                            of e2e_ctc_beam_workspace_bytes(); the row must not be used)
  *   workspace >= e2e_ctc_beam_workspace_bytes(...)
- * Limits (E2E_ERR_UNSUPPORTED beyond them; the reference has none): beam_width <= e2e_ctc_beam_max_width() = 256,
+ * Limits (E2E_ERR_UNSUPPORTED beyond them; the reference has none): beam_width <= e2e_ctc_beam_max_width() = 512,
  * language models of order <= 6.
  */
 size_t e2e_ctc_beam_workspace_bytes(int B, int T, int V, int beam_width);
-/* The largest beam_width e2e_ctc_beam accepts for an alphabet of V columns, with or without a language model: 256 for
+/* The largest beam_width e2e_ctc_beam accepts for an alphabet of V columns, with or without a language model: 512 for
  * any V.  Two kernels stand behind the call: the fast one keeps everything that scales with beam_width * V in one
  * workgroup's LDS (V = 29: widths up to 150, 103 with an LM; V = 80: 81 / 47); beyond that the general kernel keeps the
  * candidate keys and the LM's answers in the workspace (any V, e.g. the reference's default width 100 at V = 8000) --
- * same result, slower per step.  Host callers check the width at construction instead of failing at the first decode. */
+ * same result, slower per step; beyond ~256 hypotheses it also keeps the beam members' state there.  Host callers check the width at construction instead of failing at the first decode. */
 int e2e_ctc_beam_max_width(int V, int with_lm);
 
 int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, int64_t sV,

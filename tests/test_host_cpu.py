@@ -133,13 +133,13 @@ def test_decoder_wrapper_parameter_checks(tmp_path):
 def test_beam_width_limits_are_queryable_and_enforced_at_construction():
     from end2end_amd import _C
     from end2end_amd.engines import CTCDecoderEngine
-    # the fast kernel's range is bounded by the alphabet; beyond it the general kernel takes over, up to width 256
+    # the fast kernel's range is bounded by the alphabet; beyond it the general kernel takes over, up to width 512
     for V in (4, 29, 200, 8000):
-        assert _C.ctc_beam_max_width(V, False) == 256 and _C.ctc_beam_max_width(V, True) == 256
+        assert _C.ctc_beam_max_width(V, False) == 512 and _C.ctc_beam_max_width(V, True) == 512
     labels = ["_"] + ["l%d" % i for i in range(199)]
-    CTCDecoderEngine(0, 256, labels)
+    CTCDecoderEngine(0, 512, labels)
     with pytest.raises(ValueError, match="beam_width"):
-        CTCDecoderEngine(0, 257, labels)
+        CTCDecoderEngine(0, 513, labels)
     CTCDecoderEngine(0, 1, labels)           # greedy has no such limit
     assert _C.ctc_beam_workspace_bytes(8, 256, 8000, 100) > 8 * 100 * 8000 * 8
 
