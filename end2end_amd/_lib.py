@@ -77,6 +77,8 @@ def load():
         L.e2e_lm_score.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int, C.c_uint32]
         L.e2e_ctc_beam_workspace_bytes.restype = C.c_size_t
         L.e2e_ctc_beam_workspace_bytes.argtypes = [C.c_int] * 4
+        L.e2e_ctc_beam_workspace_bytes_lm.restype = C.c_size_t
+        L.e2e_ctc_beam_workspace_bytes_lm.argtypes = [C.c_int] * 5
         L.e2e_ctc_beam_max_width.restype = C.c_int
         L.e2e_ctc_beam_max_width.argtypes = [C.c_int, C.c_int]
         L.e2e_ctc_beam.restype = C.c_int

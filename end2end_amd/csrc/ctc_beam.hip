@@ -1705,12 +1705,26 @@ extern "C" int e2e_ctc_beam_max_width(int V, int with_lm) {
   return lo;
 }
 
-extern "C" size_t e2e_ctc_beam_workspace_bytes(int B, int T, int V, int beam_width) {
+// which kernel a call takes (same decision in the workspace query and in the call)
+static bool beam_takes_general(int V, int W, bool lm) {
+  static const bool force_general = getenv("E2E_BEAM_GENERAL") != nullptr;      // (tests: the whole suite through the general kernel)
+  const bool fast_ok = beam_fits(V, W, lm), gen_ok = gen_fits(V, W, lm);
+  return gen_ok && (!fast_ok || force_general);
+}
+
+extern "C" size_t e2e_ctc_beam_workspace_bytes_lm(int B, int T, int V, int beam_width, int with_lm) {
   if (B < 0 || T < 1 || V < 1 || beam_width < 1) return 0;
-  const BeamLayout l = beam_layout(B, T, V, beam_width, true);
-  // (sized for the general kernel with a language model: whether a model is used, and which kernel runs, is decided per call)
-  const size_t gen = gen_fits(V, beam_width, true) ? gen_layout(B, V, beam_width, l.WP2, l.HS, true).total : 0;
+  const BeamLayout l = beam_layout(B, T, V, beam_width, with_lm != 0);
+  // the general kernel's share (candidate keys, the LM's answer rows, member sets of very wide beams) only when that kernel
+  // will run, its LM rows only with a language model: 6.4 MB per utterance instead of 19 at V = 8000, W = 100 without one
+  const size_t gen = beam_takes_general(V, beam_width, with_lm != 0)
+                         ? gen_layout(B, V, beam_width, l.WP2, l.HS, with_lm != 0).total : 0;
   return l.total + gen + 256;
+}
+// (sized for a call with a language model, which every call without one fits as well)
+extern "C" size_t e2e_ctc_beam_workspace_bytes(int B, int T, int V, int beam_width) {
+  const size_t a = e2e_ctc_beam_workspace_bytes_lm(B, T, V, beam_width, 1), b = e2e_ctc_beam_workspace_bytes_lm(B, T, V, beam_width, 0);
+  return a > b ? a : b;
 }
 
 extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, int64_t sV,
@@ -1740,9 +1754,8 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
     }
   }
   const BeamLayout l = beam_layout(B, T, V, beam_width, lm != nullptr);
-  static const bool force_general = getenv("E2E_BEAM_GENERAL") != nullptr;      // (tests: the whole suite through the general kernel)
   const bool fast_ok = beam_fits(V, beam_width, lm != nullptr), gen_ok = gen_fits(V, beam_width, lm != nullptr);
-  const bool general = gen_ok && (!fast_ok || force_general);
+  const bool general = beam_takes_general(V, beam_width, lm != nullptr);
   if (!fast_ok && !gen_ok) {
     set_error("beam_width = %d over an alphabet of %d%s: at most %d (one workgroup's LDS holds the beam)", beam_width, V,
               lm ? " with a language model" : "", e2e_ctc_beam_max_width(V, lm != nullptr));

@@ -115,6 +115,9 @@ PYBIND11_MODULE(_C, m) {
 
   m.def("ctc_beam_workspace_bytes",
         [](int B, int T, int V, int beam_width) { return e2e_ctc_beam_workspace_bytes(B, T, V, beam_width); });
+  m.def("ctc_beam_workspace_bytes_lm", [](int B, int T, int V, int beam_width, bool with_lm) {
+    return e2e_ctc_beam_workspace_bytes_lm(B, T, V, beam_width, with_lm ? 1 : 0);
+  });
 
   m.def("ctc_beam_max_width", [](int V, bool with_lm) { return e2e_ctc_beam_max_width(V, with_lm ? 1 : 0); });
 

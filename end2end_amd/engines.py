@@ -226,7 +226,7 @@ class CTCDecoderEngine:
         if B:
             with torch.cuda.device(dev):
                 lm = self.lm.on(dev).handle if self.lm is not None else 0
-                nbytes = _C.ctc_beam_workspace_bytes(B, T, V, self.beam_width)
+                nbytes = _C.ctc_beam_workspace_bytes_lm(B, T, V, self.beam_width, self.lm is not None)
                 ws = R.workspace(dev, nbytes)
                 sB, sT, sV = x.stride()
                 _C.ctc_beam(x.data_ptr(), R.dtype_code(x.dtype), sB, sT, sV, xl.data_ptr(),

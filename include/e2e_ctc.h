@@ -177,6 +177,10 @@ double e2e_lm_score(const e2e_lm* lm, const uint32_t* ctx /* host */, int ctx_le
  * language models of order <= 6.
  */
 size_t e2e_ctc_beam_workspace_bytes(int B, int T, int V, int beam_width);
+/* The same for a caller that knows whether the call will carry a language model (with_lm 0 / 1): only what that call needs --
+ * without a model the general kernel's rows of LM answers are left out, and nothing of the general kernel's is counted where
+ * the one-workgroup kernel takes the call.  e2e_ctc_beam_workspace_bytes() is the larger of the two. */
+size_t e2e_ctc_beam_workspace_bytes_lm(int B, int T, int V, int beam_width, int with_lm);
 /* The largest beam_width e2e_ctc_beam accepts for an alphabet of V columns, with or without a language model: 512 for
  * any V.  Two kernels stand behind the call: the fast one keeps everything that scales with beam_width * V in one
  * workgroup's LDS (V = 29: widths up to 150, 103 with an LM; V = 80: 81 / 47); beyond that the general kernel keeps the

@@ -142,6 +142,10 @@ def test_beam_width_limits_are_queryable_and_enforced_at_construction():
         CTCDecoderEngine(0, 513, labels)
     CTCDecoderEngine(0, 1, labels)           # greedy has no such limit
     assert _C.ctc_beam_workspace_bytes(8, 256, 8000, 100) > 8 * 100 * 8000 * 8
+    # a call without a language model does not pay for the LM's answer rows, the one-workgroup kernel for nothing of the general one
+    no_lm, with_lm = _C.ctc_beam_workspace_bytes_lm(8, 256, 8000, 100, False), _C.ctc_beam_workspace_bytes_lm(8, 256, 8000, 100, True)
+    assert 8 * 100 * 8000 * 8 < no_lm < 0.45 * with_lm and with_lm == _C.ctc_beam_workspace_bytes(8, 256, 8000, 100)
+    assert _C.ctc_beam_workspace_bytes_lm(64, 1500, 29, 100, False) < 64 * 100 * 1503 * 8 + (1 << 20)
 
 
 def test_kenlm_binary_models_are_refused_with_a_clear_message(tmp_path):
