@@ -191,7 +191,8 @@ __device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned
   {
     double a[NC];
     checkpoint(a);
-#pragma unroll
+#pragma unroll 1                     // (rolled: fully unrolled the redo was ~10 k instructions per segment and no longer fitted
+                                     //  the instruction cache)
     for (int g = 1; g < kSeg / G; g++) {
 #pragma unroll
       for (int i = 0; i < G; i++) if ((g - 1) * G + i < n) alpha_step(a, (g - 1) * G + i);
@@ -211,7 +212,7 @@ __device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned
 #pragma unroll
     for (int k = 0; k < NC; k++) q[k] = 0.0;
   }
-#pragma unroll
+#pragma unroll 1
   for (int g = kSeg / G - 1; g >= 0; g--) {
     if (g * G >= n) continue;
     double A[G][NC];
