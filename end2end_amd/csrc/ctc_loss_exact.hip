@@ -711,7 +711,8 @@ int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetr
   p.ctl = retry ? retry->ctl : nullptr;
   p.gscale = a.grad_scale; p.reduced = mode != 0 ? a.reduced : nullptr; p.reduction = a.reduction;
   if (mode != 0 && !p.ctl) { set_error("internal: flagged exact launch without control words"); return E2E_ERR_ARG; }
-  p.has_retry = (mode == 1 && retry && a.dtype == E2E_F32 && retry_waves(a.V) > 0) ? 1 : 0;
+  // (eight pairs per lane -- targets beyond 255 labels -- have no f64 redo of the segments: the full recomputation takes them)
+  p.has_retry = (mode == 1 && retry && a.dtype == E2E_F32 && retry_waves(a.V) > 0 && retry->PPL <= 4) ? 1 : 0;
   p.redo_waves = retry_waves(a.V);
   if (p.has_retry) p.retry = *retry; else memset(&p.retry, 0, sizeof(p.retry));
   p.ws_alpha = reinterpret_cast<double*>(a.ws);

@@ -61,7 +61,7 @@ struct FastParams {
                    //           what sum_j alpha_t[j]*beta_t[j] * 2^(cumA + cumB) must equal at every t
   double* logz;    // [B][2]    alpha-side / beta-side log Z
   int* flags;      // [B]       != 0: redo with the exact kernel
-  unsigned* cinfo; // [B][CELLS/2]  per label pair: label | sorted slot << 8 | alpha skip << 16 | beta skip << 17
+  unsigned* cinfo; // [B][CELLS/2]  per label pair: label | sorted slot << 8 (10 bits) | alpha skip << 20 | beta skip << 21
   int* lstart;     // [B][130]  first label-sorted slot of every label (V+1 entries used)
   int* ctl;        // [4]  0: fallback workgroups that have finished (F1 clears it; the last one reduces the losses);
                    //      1: flagged utterances the f64 redo of the segments could not settle (diagnostics)
@@ -323,7 +323,7 @@ struct LaneCells {
   }
   // the packed form F1 leaves in the workspace for F2 (one word per label pair; `slot` = label-sorted position)
   __device__ static unsigned pack(int lab, int slot, float skp, float skn) {
-    return (unsigned)lab | ((unsigned)slot << 8) | (skp != 0.f ? 1u << 16 : 0u) | (skn != 0.f ? 1u << 17 : 0u);
+    return (unsigned)lab | ((unsigned)slot << 8) | (skp != 0.f ? 1u << 20 : 0u) | (skn != 0.f ? 1u << 21 : 0u);
   }
   __device__ void unpack(const unsigned* w, int S, int T, int (&slot)[PPL]) {
     set_tilt(S, T);
@@ -331,9 +331,9 @@ struct LaneCells {
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
       lab[q] = (int)(w[q] & 0xffu);
-      slot[q] = (int)((w[q] >> 8) & 0xffu);
-      skp[q] = (w[q] >> 16) & 1u ? r * r : 0.f;
-      skn[q] = (w[q] >> 17) & 1u ? r * r : 0.f;
+      slot[q] = (int)((w[q] >> 8) & 0x3ffu);
+      skp[q] = (w[q] >> 20) & 1u ? r * r : 0.f;
+      skn[q] = (w[q] >> 21) & 1u ? r * r : 0.f;
     }
   }
   __device__ void load(const int64_t* tg, int S, int T, int V, int blank, int lane) {
@@ -969,6 +969,7 @@ struct ChainF32 {
   static constexpr bool kF32 = true;
   static constexpr int kMaxW = 3, kProducers = 3, kRowElems = kRow32, kElem = 4;
   static constexpr int kWaves = 2 * kMaxW + 2 + 2 * kProducers + 2;
+  static constexpr bool kPairedLoop = true;
   __device__ static int top(float v) { return __float_as_int(v); }             // positive values order like these ints
   __device__ static int expo(int m) { return ((m >> 23) & 0xff) - 127; }
   __device__ static int bias(float r) { return hf_bias(r); }
@@ -984,11 +985,21 @@ struct ChainF64 {
   static constexpr int kMaxW = 2, kProducers = E2E_F64_PRODUCERS, kRowElems = kRow, kElem = 8;      // (three waves per direction: 174
                                                                                        //  against 167 us at S in [200, 255] -- six chain waves on four SIMDs)
   static constexpr int kWaves = 2 * kMaxW + 2 + 2 * kProducers + 2;
+  static constexpr bool kPairedLoop = true;
   __device__ static int top(double v) { return __double2hiint(v); }
   __device__ static int expo(int m) { return ((m >> 20) & 0x7ff) - 1023; }
   __device__ static int bias(float) { return 0; }                                // (f64 cells have the range for the lag)
   __device__ static double scale(double v, int e) { return ldexp(v, e); }
   __device__ static double tilt2(float r) { return (double)r * (double)r; }
+};
+
+//   ChainF64L: ChainF64 on four waves per direction -- targets of 256..447 labels (eight pairs per segment-kernel lane).  16
+//             waves leave 128 registers per wave: the plain block loop (the paired one spills there).  Not a tuned path: it
+//             exists so that long transcripts are not left to the exact kernel (~7 ms per 1000 frames).
+struct ChainF64L : ChainF64 {
+  static constexpr int kMaxW = 4, kProducers = 2;
+  static constexpr int kWaves = 2 * kMaxW + 2 + 2 * kProducers + 2;
+  static constexpr bool kPairedLoop = false;
 };
 
 struct HfLds {
@@ -1238,7 +1249,7 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
     // compile time.  alpha: blocks 1 .. (T-1)/8 - 1, a checkpoint row (t = 16k-1) ends every odd block; beta: blocks
     // 1 .. M-1, M = (T-1)/8, a checkpoint row (t = 16k) ends the blocks of M's parity.
     const int fast_end = (T - 1) >> 3;
-    if (fast_end - n >= 3 && ((E2E_F1_FAST_DIRS >> DIR) & 1)) {
+    if (X::kPairedLoop && fast_end - n >= 3 && ((E2E_F1_FAST_DIRS >> DIR) & 1)) {
       run_block(n, std::true_type{}, Any{}, Any{}); n++;      // (n = 2 now)
       if (DIR == 0 || (((T - 1) >> 3) & 1)) {
         for (; n + 1 < fast_end; n += 2) { run_block(n, std::true_type{}, I0{}, I0{}); run_block(n + 1, std::true_type{}, I1{}, I1{}); }
@@ -1326,6 +1337,7 @@ __device__ __forceinline__ void hf_ckpt_wave(const FastParams& p, int b, int T, 
       int m0 = ma, m1 = mb;                                           // exponent source of pair p0 / p0 + 1
       if (F2PPL >= 2) { m0 = max(ma, mb); m1 = m0; }
       if (F2PPL >= 4) { m0 = max(m0, dpp_i<0xB1>(0, m0)); m1 = m0; }  // quad_perm [1,0,3,2]: the lane pair
+      if (F2PPL >= 8) { m0 = max(m0, dpp_i<0x4E>(0, m0)); m1 = m0; }  // quad_perm [2,3,0,1]: the (aligned) four lanes
       const int own0 = X::expo(m0), own1 = X::expo(m1);
       const int st0 = m0 > 0 ? own0 - bias : -30000, st1 = m1 > 0 ? own1 - bias : -30000;     // relative to the frame
       if (own_lane && p0 < 64 * F2PPL && (p0 & ~(F2PPL - 1)) <= S) {      // (groups past the lattice are not read)
@@ -2140,8 +2152,9 @@ __device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char*
 #ifndef E2E_F2_LDSPAD
 #define E2E_F2_LDSPAD 0
 #endif
+// (eight pairs per lane: 16 alpha rows of 16 cells are 256 registers by themselves -- one wave per SIMD, no spills)
 template <int PPL>
-__global__ __launch_bounds__(64, E2E_F2_MINW) void ctc_fast_segment_kernel(FastParams p) {
+__global__ __launch_bounds__(64, PPL == 8 ? 1 : E2E_F2_MINW) void ctc_fast_segment_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   segment_wave<PPL>(p, smem);
 }
@@ -2156,6 +2169,18 @@ __global__ __launch_bounds__(64, E2E_F2_MINW) void ctc_fast_segment_kernel(FastP
 // requested one segment ahead by LDS-DMA (global_load_lds, no destination registers) and a counted vmcnt wait that lets the
 // gradient stores drain under the next segment -- were built, parity-green, and measured: 137 against 131 us per step.  The
 // one-segment waves already overlap each other's load latency and store tails; a register prefetch spills (tried twice).)
+// targets of 256..447 labels: the halo chains on four waves per direction, the segment kernel with eight pairs per lane
+int launch_fast_long(const FastParams& p, hipStream_t stream) {
+  const HfLds hl = HfLds::of<ChainF64L>(p.V);
+  E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<8, ChainF64L>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
+  hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<8, ChainF64L>), dim3(p.B), dim3(ChainF64L::kWaves * 64), hl.total, stream, p);
+  E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
+  hipLaunchKernelGGL(ctc_fast_segment_kernel<8>, dim3(p.NS, p.B), dim3(64), F2Lds<8>::bytes(p.V), stream, p);
+  E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
+  return E2E_OK;
+}
+
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds1 = F1Lds::bytes(p.V);
@@ -2204,6 +2229,7 @@ int ppl_for(int Smax) {
   if (Smax <= 63) return 1;
   if (Smax <= 127) return 2;
   if (Smax <= 255) return 4;
+  if (Smax + 1 <= ChainF64L::kMaxW * kHfOwn) return 8;      // 447: what four halo chain waves per direction hold
   return 0;
 }
 
@@ -2280,6 +2306,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
     case 1: rc = launch_fast_ppl<1>(p, a.stream); break;
     case 2: rc = launch_fast_ppl<2>(p, a.stream); break;
     case 4: rc = launch_fast_ppl<4>(p, a.stream); break;
+    case 8: rc = launch_fast_long(p, a.stream); break;
     default: set_error("fast CTC path: Smax=%d too long", a.Smax); return E2E_ERR_UNSUPPORTED;
   }
   if (rc != E2E_OK) return rc;

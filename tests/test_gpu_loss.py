@@ -480,3 +480,26 @@ def test_more_fully_recomputed_utterances_than_alpha_slabs_and_a_mixed_batch():
     assert np.isinf(red) and red > 0
     la2, _, red2 = U.c_abi_loss(xt[50:], tg[50:], xl[50:], tl[50:], 0, False, _lib.ALGO_AUTO, opts=(1.0, _lib.REDUCE_MEAN))
     assert abs(red2 - l_o[50:].mean()) <= 1e-5 * abs(l_o[50:].mean())
+
+
+@pytest.mark.parametrize("shape", [(3, 700, 29, 300), (2, 2000, 29, 400), (2, 1100, 48, 447)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)
+def test_long_transcripts_take_the_fast_path(shape):
+    """Targets of 256..447 labels: the halo chains on four waves per direction and the segment kernel with
+    eight pairs per lane -- served by the fast path itself (ALGO_FAST leaves no NaN), equal to the oracle at the default
+    tolerances, ragged lengths included."""
+    B, T, V, S = shape
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl = torch.tensor([T] + [T - 37 * (b + 1) for b in range(B - 1)])
+    tl = torch.tensor([S] + [257 + 11 * b for b in range(B - 1)])
+    lf, gf = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    assert np.isfinite(lf).all(), "the fast path flagged %d of %d utterances" % (int(np.isnan(lf).sum()), B)
+    la, ga = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_AUTO)
+    lp = torch.log_softmax(x.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0
+    for losses, grads in ((lf, gf), (la, ga)):
+        U.assert_same(losses, l_o, F32_RTOL, F32_ATOL * 100, "losses")
+        U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")

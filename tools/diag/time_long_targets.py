@@ -22,3 +22,4 @@ def run(B, T, V, S, lo, reps=20):
     e1.record(); torch.cuda.synchronize()
     print("B=%d T=%d V=%d S in [%d,%d]: %.1f us per call, %d flagged" % (B, T, V, lo, S, e0.elapsed_time(e1) / reps * 1e3, int(torch.isnan(losses).sum())))
 run(256, 1000, 29, 255, 200); run(256, 1000, 29, 255, 128); run(256, 1000, 29, 200, 100); run(256, 1000, 29, 223, 112)
+run(256, 1000, 29, 300, 256, reps=5); run(256, 2000, 29, 400, 300, reps=5); run(64, 2000, 29, 447, 400, reps=5)
