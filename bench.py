@@ -353,6 +353,29 @@ def fallback_regime_numbers(dev):
             "note": "flagged utterances are redone by the f64 segment redo / the exact kernel inside the same call"}
 
 
+def shape_cliff_numbers(dev):
+    """Loss shapes beside the headline one: what a call costs where the fast paths end.  One C-ABI call each,
+    HIP events, inputs resident."""
+    import torch
+    out = {}
+    for name, (B, T, V, S) in (("long_targets_T2000_S400", (256, 2000, 29, 400)),
+                               ("long_targets_T1000_S300", (256, 1000, 29, 300)),
+                               ("wordpiece_V8000_S200", (64, 256, 8000, 200)),
+                               ("wordpiece_V32000_S120", (16, 150, 32000, 120))):
+        _, db = make_batch(7000, B, T, V, S, dev)
+        hp = HotPath(db)
+        for _ in range(2):
+            hp.call()
+        ms = time_events(torch, hp.call, 3)
+        out[name] = {"workload": "B=%d T=%d V=%d S in [%d,%d] f32" % (B, T, V, S // 2, S), "ms": ms,
+                     "frames_per_s": B * T / (ms * 1e-3),
+                     "path": "fast path (eight pairs per lane)" if V <= 96 else
+                             "wide path: streaming rows + the exact kernel on the compact columns (more than 95 distinct labels)"}
+        del hp, db
+        torch.cuda.empty_cache()
+    return out
+
+
 def recorded_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
     for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
@@ -577,6 +600,7 @@ def main():
         if n_gpus == 1 and not args.no_decode:
             out["decode"] = decode_numbers(dev, not args.no_cpu_baseline)
             out["fallback_regime"] = fallback_regime_numbers(dev)
+            out["shape_cliffs"] = shape_cliff_numbers(dev)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

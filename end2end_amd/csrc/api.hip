@@ -176,7 +176,14 @@ int e2e_ctc_loss_fwd_bwd_opt(const void* x, int dtype, int input_is_logprobs,
   if (opts) { a.grad_scale = opts->grad_scale; a.reduced = opts->reduced; a.reduction = opts->reduction; a.chains = opts->chains; }
   const int r = resolve_algo(algo, dtype, T, V, Smax);
   if (r == E2E_ALGO_EXACT) { const int rc = launch_exact(a); return rc != E2E_OK ? rc : launch_reduce_losses(a); }
-  if (use_wide(dtype, T, V, Smax)) { const int rc = launch_wide(a, r == E2E_ALGO_AUTO); return rc != E2E_OK ? rc : launch_reduce_losses(a); }
+  if (use_wide(dtype, T, V, Smax)) {
+    if (r == E2E_ALGO_FAST && !wide_takes_fast_lattice(T, V, Smax, dtype)) {
+      set_error("fast CTC path does not support this shape/dtype (more than 95 distinct labels: the compact lattice is the exact kernel's)");
+      return E2E_ERR_UNSUPPORTED;
+    }
+    const int rc = launch_wide(a, r == E2E_ALGO_AUTO);
+    return rc != E2E_OK ? rc : launch_reduce_losses(a);
+  }
   if (r == E2E_ALGO_FAST) {
     if (!fast_supported(T, V, Smax, dtype)) { set_error("fast CTC path does not support this shape/dtype"); return E2E_ERR_UNSUPPORTED; }
     return launch_fast(a, false);

@@ -64,6 +64,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact);
 bool fast_supported(int T, int V, int Smax, int dtype);
 // wide alphabets: per-utterance compaction around the fast path (ctc_loss_wide.hip)
 bool wide_supported(int T, int V, int Smax, int dtype);
+bool wide_takes_fast_lattice(int T, int V, int Smax, int dtype);   // (false: the compact lattice is the exact kernel's)
 size_t wide_workspace_bytes(int B, int T, int V, int Smax, bool with_exact);
 int launch_wide(const LossArgs& a, bool fallback_to_exact);
 

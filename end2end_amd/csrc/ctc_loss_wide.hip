@@ -384,6 +384,13 @@ __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
   }
 }
 
+// More distinct labels than the lattice kernels' alphabet holds (targets of more than 95 word pieces): the compaction and the
+// streaming kernels still carry the V-wide work -- 2 V 4 bytes per frame -- and the lattice on the <= S+1 compact columns is
+// left to the reference's arithmetic (ctc_exact_kernel in log-prob mode, 256 utterances at a time on one set of alpha slabs).
+// B=64, T=256, V=8000, S<=200: 6.7 ms when the exact kernel also had to walk the 8000 columns of every frame in f64.
+constexpr int kWideExactChunk = 256;
+static bool wide_inner_exact(int T, int Smax) { return !fast_supported(T, Smax + 1, Smax, E2E_F32); }
+
 struct WideLayout { size_t targets_c, clabel, lse, shift, xc, gc, inner, total; int VC; };
 
 WideLayout wide_layout(int B, int T, int V, int Smax, bool with_exact) {
@@ -398,8 +405,12 @@ WideLayout wide_layout(int B, int T, int V, int Smax, bool with_exact) {
   l.xc = o; o += align_up((size_t)B * T * l.VC * sizeof(float), 256);
   l.gc = o; o += align_up((size_t)B * T * l.VC * sizeof(float), 256);
   l.inner = o;
-  o += fast_workspace_bytes(B, T, l.VC, Smax);
-  if (with_exact) o += exact_fallback_workspace_bytes(B, T, l.VC, Smax);
+  if (wide_inner_exact(T, Smax)) {
+    o += exact_workspace_bytes(B < kWideExactChunk ? B : kWideExactChunk, T, l.VC, Smax);
+  } else {
+    o += fast_workspace_bytes(B, T, l.VC, Smax);
+    if (with_exact) o += exact_fallback_workspace_bytes(B, T, l.VC, Smax);
+  }
   l.total = o;
   return l;
 }
@@ -407,7 +418,12 @@ WideLayout wide_layout(int B, int T, int V, int Smax, bool with_exact) {
 }  // namespace
 
 bool wide_supported(int T, int V, int Smax, int dtype) {
-  return dtype == E2E_F32 && V > 1 && Smax >= 0 && fast_supported(T, Smax + 1, Smax, dtype);
+  if (!(dtype == E2E_F32 && V > 1 && Smax >= 0)) return false;
+  // (with the lattice left to the exact kernel the compaction must at least halve the columns to be worth its passes)
+  return fast_supported(T, Smax + 1, Smax, dtype) || V >= 2 * (Smax + 1);
+}
+bool wide_takes_fast_lattice(int T, int V, int Smax, int dtype) {
+  return wide_supported(T, V, Smax, dtype) && !wide_inner_exact(T, Smax);
 }
 
 size_t wide_workspace_bytes(int B, int T, int V, int Smax, bool with_exact) {
@@ -472,8 +488,20 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
     c.ws = ws + l.inner; c.ws_bytes = a.ws_bytes - l.inner;
     c.grad_scale = 1.0; c.reduced = nullptr; c.reduction = 0;      // (the compact gradient stays unscaled; the losses
                                                                     //  are corrected below, the caller reduces them after)
-    const int rc = launch_fast(c, fallback_to_exact);
-    if (rc != E2E_OK) return rc;
+    if (wide_inner_exact(a.T, a.Smax)) {
+      for (int c0 = 0; c0 < nb; c0 += kWideExactChunk) {
+        LossArgs e = c;
+        e.B = nb - c0 < kWideExactChunk ? nb - c0 : kWideExactChunk;
+        e.x = q.xc + (size_t)c0 * a.T * l.VC; e.grads = const_cast<float*>(q.gc) + (size_t)c0 * a.T * l.VC;
+        e.targets = c.targets + (size_t)c0 * c.tgt_stride; e.x_len = c.x_len + c0; e.t_len = c.t_len + c0;
+        e.losses = reinterpret_cast<float*>(c.losses) + c0;
+        const int rc = launch_exact(e);
+        if (rc != E2E_OK) return rc;
+      }
+    } else {
+      const int rc = launch_fast(c, fallback_to_exact);
+      if (rc != E2E_OK) return rc;
+    }
     hipLaunchKernelGGL(wide_loss_fix_kernel, dim3(nb), dim3(64), 0, s_lat, q);
     E2E_HIP_CHECK(hipGetLastError(), "wide_loss_fix_kernel launch");
     if (dense) hipLaunchKernelGGL(wide_fix_kernel, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
