@@ -355,6 +355,30 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
     __syncthreads();
     return;
   }
+  // Too few frames for the targets -- T < S + (adjacent equal labels), with no target equal to the blank id -- has no
+  // alignment whatever the emissions: the reference walks the whole lattice to find log Z = -inf, then its
+  // exp(-inf - (-inf)) poisons the slab (Q2: loss +inf, grads NaN).  Same result here without the walk: a batch with one
+  // such utterance cost the fast path's caller a full 7 ms recomputation per step.
+  {
+    int need = 0, blank_label = 0;
+    for (int i = tid; i < S; i += kThreads) {
+      const int li = ext[2 * i + 1];
+      need += 1 + ((i > 0 && ext[2 * i - 1] == li) ? 1 : 0);
+      blank_label |= li == blank;
+    }
+    need = (int)wave_sum((double)need);
+    if (lane == 0) red[wid] = (double)need;
+    const int any_blank = __syncthreads_or(blank_label);
+    int total = 0;
+    for (int w2 = 0; w2 < kThreads / 64; w2++) total += (int)red[w2];
+    __syncthreads();
+    if (!any_blank && T < total) {
+      const double qnan = __builtin_nan("");
+      if (tid == 0) losses[b] = (IO)__builtin_huge_val();
+      for (size_t i = tid; i < (size_t)Tmax * V; i += kThreads) grads[i] = (IO)qnan;
+      return;
+    }
+  }
   // stable rank of target i among the S targets by label value (same-label cells keep increasing j,
   // so the per-label sums below run in the reference's order, ctc_loss.cpp:109-114)
   for (int i = tid; i < S; i += kThreads) {
