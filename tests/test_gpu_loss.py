@@ -503,3 +503,31 @@ def test_long_transcripts_take_the_fast_path(shape):
     for losses, grads in ((lf, gf), (la, ga)):
         U.assert_same(losses, l_o, F32_RTOL, F32_ATOL * 100, "losses")
         U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
+
+
+def test_flagged_launch_with_more_utterances_than_its_flag_cache():
+    """3000 utterances (the flagged launch caches 2048 flag words in LDS and reads the rest from memory; 24 alpha slabs serve
+    every utterance that needs the reference's arithmetic): blank-valued targets and impossible lengths sprinkled over the
+    whole batch, the sum of the losses written by the same call."""
+    rng = np.random.default_rng(21)
+    B, T, V, S = 3000, 48, 20, 12
+    x = rng.standard_normal((B, T, V)).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, S)); tl = rng.integers(4, S + 1, size=B); xl = rng.integers(30, T + 1, size=B)
+    hard = rng.choice(B, size=90, replace=False)
+    tg[hard[:45], 2] = 0                                        # a target equal to the blank id
+    xl[hard[45:]] = 3                                           # fewer frames than labels
+    xt = torch.from_numpy(x)
+    lp = torch.log_softmax(xt.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg, xl, tl, 0)
+    feasible = np.isfinite(l_o)
+    for b in range(B):
+        if feasible[b]:
+            g_o[b, xl[b]:] = 0
+    la, ga, red = U.c_abi_loss(xt, tg, xl, tl, 0, False, _lib.ALGO_AUTO, opts=(1.0, _lib.REDUCE_SUM))
+    assert (~feasible).sum() >= 40 and (~feasible[2048:]).sum() >= 5
+    U.assert_same(la, l_o, F32_RTOL, 2e-5, "losses")
+    U.assert_same(ga[feasible], g_o[feasible], F32_RTOL, F32_ATOL, "grads")
+    assert np.isnan(ga[~feasible]).all() and np.isinf(red)
+    ok = np.flatnonzero(feasible)
+    la2, _, red2 = U.c_abi_loss(xt[ok], tg[ok], xl[ok], tl[ok], 0, False, _lib.ALGO_AUTO, opts=(1.0, _lib.REDUCE_SUM))
+    assert abs(red2 - l_o[ok].sum()) <= 2e-6 * abs(l_o[ok].sum())
