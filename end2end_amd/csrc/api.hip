@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -174,6 +175,10 @@ int e2e_ctc_loss_fwd_bwd_opt(const void* x, int dtype, int input_is_logprobs,
   LossArgs a{x, dtype, input_is_logprobs ? 1 : 0, sB, sT, sV, targets, tgt_stride, x_len, t_len,
              B, T, V, Smax, blank, losses, grads, workspace, workspace_bytes, (hipStream_t)stream};
   if (opts) { a.grad_scale = opts->grad_scale; a.reduced = opts->reduced; a.reduction = opts->reduction; a.chains = opts->chains; }
+  // AUTO with f32 I/O: wherever the exact kernel stands in for (or finishes) an f32 path it may use its scaled f64 form;
+  // E2E_ALGO_EXACT and f64 always run the reference's log-domain arithmetic.  (E2E_EXACT_LOGDOMAIN=1: everywhere.)
+  static const bool logdomain_only = [] { const char* e = getenv("E2E_EXACT_LOGDOMAIN"); return e && e[0] == '1'; }();
+  a.scaled_exact = (algo == E2E_ALGO_AUTO && dtype == E2E_F32 && !logdomain_only) ? 1 : 0;
   const int r = resolve_algo(algo, dtype, T, V, Smax);
   if (r == E2E_ALGO_EXACT) { const int rc = launch_exact(a); return rc != E2E_OK ? rc : launch_reduce_losses(a); }
   if (use_wide(dtype, T, V, Smax)) {

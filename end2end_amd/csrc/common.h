@@ -34,6 +34,7 @@ struct LossArgs {
   void* reduced = nullptr;
   int reduction = 0;
   int chains = 0;          // E2E_CHAINS_*
+  int scaled_exact = 0;    // the exact kernel may use its scaled probability-domain form (f32 I/O, algo AUTO; see ctc_exact_one)
 };
 // sum / mean of the losses by one small launch (paths that have no tail to fold it into)
 int launch_reduce_losses(const LossArgs& a);

@@ -30,6 +30,8 @@ struct ExactParams {
   void* losses; void* grads;
   double* ws_alpha;   // [B][T][Lmax]
   double* ws_lse;     // [B][T] row log-sum-exp (logits mode)
+  int* ws_exp;        // [B][T] scaled form: exponent removed from alpha row t
+  int scaled;         // 1: scaled probability-domain lattice where allowed (see ctc_exact_one), 0: the reference's log domain only
   int* flags;         // per-utterance "redo me" words written by the fast path (mode != 0); mode 1 adds bit 512: the f64
                       // redo of a segment could not settle the utterance
   int mode;           // 0: every utterance; 1: only flagged ones; 2: poison flagged ones, compute nothing
@@ -57,6 +59,25 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// Reductions over the wave by DPP (a dozen cycles a stage instead of an LDS permute's hundred): the result is in LANE 63.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_or0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false); }
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_or0(double v) {
+  return __hiloint2double(dpp_or0<CTRL, ROWS>(__double2hiint(v)), dpp_or0<CTRL, ROWS>(__double2loint(v)));
+}
+__device__ __forceinline__ int wave_max_nonneg_lane63(int v) {
+  v = max(v, dpp_or0<0xB1, 0xf>(v)); v = max(v, dpp_or0<0x4E, 0xf>(v));         // quads
+  v = max(v, dpp_or0<0x141, 0xf>(v)); v = max(v, dpp_or0<0x140, 0xf>(v));       // rows of 16 (half mirror, mirror)
+  v = max(v, dpp_or0<0x142, 0xa>(v)); v = max(v, dpp_or0<0x143, 0xc>(v));       // lane 15 -> next row, lane 31 -> rows 2, 3
+  return v;
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v += dpp_or0<0xB1, 0xf>(v); v += dpp_or0<0x4E, 0xf>(v);
+  v += dpp_or0<0x141, 0xf>(v); v += dpp_or0<0x140, 0xf>(v);
+  v += dpp_or0<0x142, 0xa>(v); v += dpp_or0<0x143, 0xc>(v);
   return v;
 }
 
@@ -303,7 +324,14 @@ __device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned
 // One utterance b, with the alpha slab `slot` of the workspace.
 // (forced inline: out of line the parameter block is handed over through scratch memory and every pointer in it becomes
 // a generic one -- flat loads behind scratch loads)
-template <typename IO>
+// SCALED: the same lattice in the probability domain -- f64 cells, every row divided by a power of two taken from the row
+// before it (the wave maxima ride on the step's own barrier), alpha rows in the same slab with their exponents beside
+// them -- instead of the reference's log(1.0 + exp(x)) per addition: ~1.7 instead of ~7 us per frame.  Not the reference's
+// arithmetic (results agree to ~1e-12 relative), so it only stands in where this kernel is the *fallback or the tail of
+// an f32 path*: utterances the fast path hands over, the compact lattice of the wide path, targets beyond the fast
+// kernels' width.  f64 inputs, E2E_ALGO_EXACT and anything whose scaled partition sum is not a positive finite number
+// (infeasible, or probabilities below f64's range) take the log-domain code below.
+template <typename IO, bool SCALED = false>
 __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned char* smem, int b, int slot) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -311,9 +339,9 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
 
   double* buf0 = reinterpret_cast<double*>(smem);          // [Lmax]
   double* buf1 = buf0 + Lmax;                              // [Lmax]
-  double* psorted = buf1 + Lmax;                           // [Smax] label-sorted posteriors
-  double* red = psorted + (Smax > 0 ? Smax : 1);           // [16]
-  int* ext = reinterpret_cast<int*>(red + 16);             // [Lmax]
+  double* psorted = buf1 + Lmax;                           // [2][Smax] label-sorted posteriors (second half: scaled form)
+  double* red = psorted + 2 * (Smax > 0 ? Smax : 1);       // [40]: sums; the scaled form's wave sums and maxima
+  int* ext = reinterpret_cast<int*>(red + 40);             // [Lmax]
   int* rank = ext + Lmax;                                  // [Smax] rank of target i in label order
   int* sorted_lab = rank + (Smax > 0 ? Smax : 1);          // [Smax] label at sorted position r
   unsigned* is_label = reinterpret_cast<unsigned*>(sorted_lab + (Smax > 0 ? Smax : 1));   // [(V+31)/32] bit v: column v is a target label
@@ -413,6 +441,244 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
     return p.logprobs ? r : r - wl[t];
   };
 
+  if (SCALED && L <= 2 * kThreads) {
+    // A step is a chain -- barrier, LDS reads, a handful of f64 operations, LDS writes, the row maximum, barrier -- that every
+    // wave walks alone, so it is written for latency: no branches around the cells (dead neighbours are multiplied by 0,
+    // dead threads read a clamped address and do not write), all LDS reads of a step issued together with exp() of the
+    // emissions in their shadow, reductions by DPP, the barrier waits for LDS only, and every global value a step needs is
+    // asked for kAhead steps earlier (register ring; the sweeps are unrolled by kAhead).  Cells outside the reference's
+    // [start, end) window are not forced to zero: above it they are zero by themselves, below it alpha is not but beta is
+    // (and the other way round), so their posteriors are exact zeros all the same.
+    constexpr int kAhead = 4;
+    int* wexp = p.ws_exp + (size_t)slot * (size_t)Tmax;
+    double* psort2 = psorted;                                // [2][S1] (the log-domain code uses the first half)
+    double* redb = red + 10;                                 // [2][8] blank-cell sums of the waves
+    int* rmax = reinterpret_cast<int*>(red + 26);            // [2][8] wave maxima (high words) of the row just written
+    int* blank_is_label = reinterpret_cast<int*>(red + 34);
+    const int S1 = Smax > 0 ? Smax : 1;
+    const double gscale = p.gscale;
+    const bool lpin = p.logprobs != 0;
+    const int K = L > kThreads ? 2 : 1;                      // cells per thread: j = tid, tid + kThreads
+    bool live[2]; int64_t off[2]; int rk[2];
+    int jc[2], jm1[2], jm2[2], jp1[2], jp2[2];               // clamped LDS indices of the cell and its neighbours
+    double f0[2], f1[2], f2[2], g1[2], g2[2], binit[2];       // 1.0 where that neighbour counts
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int j = tid + k * kThreads;
+      live[k] = j < L;
+      jc[k] = min(j, L - 1);
+      const int c = ext[jc[k]];
+      jm1[k] = max(jc[k] - 1, 0); jm2[k] = max(jc[k] - 2, 0); jp1[k] = min(jc[k] + 1, L - 1); jp2[k] = min(jc[k] + 2, L - 1);
+      f0[k] = live[k] ? 1.0 : 0.0;
+      f1[k] = (live[k] && j > 0) ? 1.0 : 0.0;
+      f2[k] = (live[k] && c != blank && j >= 2 && ext[jm2[k]] != c) ? 1.0 : 0.0;
+      g1[k] = (live[k] && j < L - 1) ? 1.0 : 0.0;
+      g2[k] = (live[k] && c != blank && j + 2 < L && ext[jp2[k]] != c) ? 1.0 : 0.0;
+      binit[k] = (live[k] && ((j == L - 1 && (T > 1 || L == 1)) || j == L - 2)) ? 1.0 : 0.0;
+      off[k] = (int64_t)c * p.sV;
+      rk[k] = (live[k] && (j & 1)) ? rank[j >> 1] : 0;
+    }
+    // this thread's column of the gradient row: its label (sorted position tid) if it is the first of its run; the last
+    // thread has the blank column
+    const bool leader = tid < S && (tid == 0 || sorted_lab[tid - 1] != sorted_lab[tid]);
+    const int llab = leader ? sorted_lab[tid] : blank;
+    int lrun = 0;
+    if (leader) { lrun = 1; while (tid + lrun < S && sorted_lab[tid + lrun] == llab) lrun++; }
+    if (tid == 0) *blank_is_label = 0;
+    __syncthreads();
+    if (leader && llab == blank) *blank_is_label = 1;
+    __syncthreads();
+    const bool blank_leader = leader && llab == blank;
+    const bool blank_thread = tid == kThreads - 1 && !*blank_is_label;
+    const bool hascol = leader || blank_thread;
+    const int64_t coloff = (int64_t)llab * p.sV;
+    auto row_exp = [&](int which) -> int {                   // exponent of the largest cell of that row (0 for an all-zero row)
+      const int4 lo = *reinterpret_cast<const int4*>(rmax + which * 8), hi = *reinterpret_cast<const int4*>(rmax + which * 8 + 4);
+      const int m = max(max(max(lo.x, lo.y), max(lo.z, lo.w)), max(max(hi.x, hi.y), max(hi.z, hi.w)));
+      return m > 0 ? ((m >> 20) & 0x7ff) - 1023 : 0;         // (non-negative doubles order like their high words)
+    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- alpha ----
+    struct ASlot { IO xr[2]; double rl; };
+    ASlot ar[kAhead];
+    auto afetch = [&](ASlot& q, int t) {
+      if (t < T) {
+        const IO* row = x + (int64_t)t * p.sT;
+        q.xr[0] = row[off[0]];
+        if (K == 2) q.xr[1] = row[off[1]];
+        q.rl = lpin ? 0.0 : wl[t];
+      }
+    };
+    int E = 0;
+    auto astep = [&](int t, ASlot& q) {
+      const double* prev = (t & 1) ? buf0 : buf1;
+      double* cur = (t & 1) ? buf1 : buf0;
+      double* warow = wa + (size_t)t * Lmax;
+      const int e = row_exp((t - 1) & 1);
+      double p0[2], p1[2], p2[2], y[2];
+      p0[0] = prev[jc[0]]; p1[0] = prev[jm1[0]]; p2[0] = prev[jm2[0]];
+      if (K == 2) { p0[1] = prev[jc[1]]; p1[1] = prev[jm1[1]]; p2[1] = prev[jm2[1]]; }
+      y[0] = exp((double)q.xr[0] - q.rl);
+      if (K == 2) y[1] = exp((double)q.xr[1] - q.rl);
+      afetch(q, t + kAhead);
+      E += e;
+      const double a0 = ldexp((p0[0] * f0[0] + p1[0] * f1[0] + p2[0] * f2[0]) * y[0], -e);
+      if (live[0]) { cur[tid] = a0; warow[tid] = a0; }
+      int mt = live[0] ? __double2hiint(a0) : 0;
+      if (K == 2) {
+        const double a1 = ldexp((p0[1] * f0[1] + p1[1] * f1[1] + p2[1] * f2[1]) * y[1], -e);
+        if (live[1]) { cur[tid + kThreads] = a1; warow[tid + kThreads] = a1; mt = max(mt, __double2hiint(a1)); }
+      }
+      mt = wave_max_nonneg_lane63(mt);
+      if (lane == 63) rmax[(t & 1) * 8 + wid] = mt;
+      if (tid == 0) wexp[t] = E;
+      lds_barrier();
+    };
+    {
+      int mt = 0;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int j = tid + k * kThreads;
+        if (live[k]) {
+          double a = 0.0;
+          if ((j == 0 && (T > 1 || L == 1)) || j == 1) a = exp(lp(0, ext[j]));
+          buf0[j] = a; wa[j] = a;
+          mt = max(mt, __double2hiint(a));
+        }
+      }
+      mt = wave_max_nonneg_lane63(mt);
+      if (lane == 63) rmax[wid] = mt;
+      if (tid == 0) wexp[0] = 0;
+#pragma unroll
+      for (int i = 0; i < kAhead; i++) afetch(ar[(1 + i) % kAhead], 1 + i);
+      lds_barrier();
+    }
+    for (int t = 1; t < T; t += kAhead) {
+      astep(t, ar[1]);
+      if (t + 1 < T) astep(t + 1, ar[2]);
+      if (t + 2 < T) astep(t + 2, ar[3]);
+      if (t + 3 < T) astep(t + 3, ar[0]);
+    }
+    const double* last = ((T - 1) & 1) ? buf1 : buf0;
+    const double z = (L > 1) ? last[L - 1] + last[L - 2] : last[L - 1];
+    __syncthreads();                                          // (also: wexp[] and the alpha rows are in memory)
+    bool ok = z > 1e-250 && z < __builtin_huge_val();
+    if (ok) {
+      const double logZ = log(z) + (double)E * 0.693147180559945309417;
+      const int ET = E;
+      const double invz = 1.0 / z;
+      // ---- beta, posteriors, the label and blank columns of the gradient: row t leaves in the step that makes beta's row t ----
+      struct BSlot { IO xr[2]; IO xcol; double rl; double war[2]; int ex; };
+      BSlot br[kAhead];
+      auto bfetch = [&](BSlot& q, int t) {
+        if (t >= 0) {
+          const IO* row = x + (int64_t)t * p.sT;
+          const double* warow = wa + (size_t)t * Lmax;
+          q.xr[0] = row[off[0]]; q.war[0] = warow[jc[0]];
+          if (K == 2) { q.xr[1] = row[off[1]]; q.war[1] = warow[jc[1]]; }
+          q.xcol = row[coloff];
+          q.rl = lpin ? 0.0 : wl[t];
+          q.ex = wexp[t];
+        }
+      };
+      int F = 0;                                              // exponent taken out of the beta row t+1 (with its emissions)
+      int bad = 0;
+      auto bstep = [&](int t, BSlot& q) {
+        const double* be_next = (t & 1) ? buf0 : buf1;
+        double* be_cur = (t & 1) ? buf1 : buf0;
+        const bool first = t == T - 1;
+        const int e = first ? 0 : row_exp((t + 1) & 1);
+        double b0[2], b1[2], b2[2], y[2];
+        b0[0] = be_next[jc[0]]; b1[0] = be_next[jp1[0]]; b2[0] = be_next[jp2[0]];
+        if (K == 2) { b0[1] = be_next[jc[1]]; b1[1] = be_next[jp1[1]]; b2[1] = be_next[jp2[1]]; }
+        y[0] = exp((double)q.xr[0] - q.rl);
+        if (K == 2) y[1] = exp((double)q.xr[1] - q.rl);
+        const double ycol = exp((double)q.xcol - q.rl);
+        // alpha_t beta_t / Z in the rows' units: 2^(E_t + F - E_T) / z
+        const double unit = ldexp(invz, q.ex + F - ET);
+        const double war0 = q.war[0] * unit, war1 = q.war[1] * unit;
+        bfetch(q, t - kAhead);
+        double* ps = psort2 + (t & 1) * S1;
+        double blank_part = 0.0;
+        const double bt0 = first ? binit[0] : b0[0] * f0[0] + b1[0] * g1[0] + b2[0] * g2[0];
+        const double bc0 = ldexp(bt0 * y[0], -e);
+        const double pj0 = war0 * bt0;
+        bad |= !(pj0 <= 2.0);
+        int mt = 0;
+        if (live[0]) {
+          be_cur[tid] = bc0; mt = __double2hiint(bc0);
+          if (tid & 1) ps[rk[0]] = pj0; else blank_part = pj0;
+        }
+        if (K == 2) {
+          const double bt1 = first ? binit[1] : b0[1] * f0[1] + b1[1] * g1[1] + b2[1] * g2[1];
+          const double bc1 = ldexp(bt1 * y[1], -e);
+          const double pj1 = war1 * bt1;
+          bad |= !(pj1 <= 2.0);
+          if (live[1]) {
+            be_cur[tid + kThreads] = bc1; mt = max(mt, __double2hiint(bc1));
+            if (tid & 1) ps[rk[1]] = pj1; else blank_part += pj1;         // (kThreads is even: same parity as tid)
+          }
+        }
+        F += e;
+        mt = wave_max_nonneg_lane63(mt);
+        blank_part = wave_sum_lane63(blank_part);
+        if (lane == 63) { redb[(t & 1) * 8 + wid] = blank_part; rmax[(t & 1) * 8 + wid] = mt; }
+        lds_barrier();
+        if (hascol) {
+          double s2 = 0.0;
+          if (leader) {
+            // the run's posteriors in increasing-j order (ctc_loss.cpp:109-114), four LDS reads in flight at a time
+            s2 = ps[tid];
+            int q2 = 1;
+            for (; q2 + 3 < lrun; q2 += 4) {
+              const double u0 = ps[tid + q2], u1 = ps[tid + q2 + 1], u2 = ps[tid + q2 + 2], u3 = ps[tid + q2 + 3];
+              s2 = (((s2 + u0) + u1) + u2) + u3;
+            }
+            for (; q2 < lrun; q2++) s2 += ps[tid + q2];
+          }
+          if (blank_leader || blank_thread) {
+            // (a target equal to the blank id shares the blank column, ctc_loss.cpp:109-113)
+            const double* rb = redb + (t & 1) * 8;
+            const double2 r0 = *reinterpret_cast<const double2*>(rb), r1 = *reinterpret_cast<const double2*>(rb + 2),
+                          r2 = *reinterpret_cast<const double2*>(rb + 4), r3 = *reinterpret_cast<const double2*>(rb + 6);
+            s2 += ((((((r0.x + r0.y) + r1.x) + r1.y) + r2.x) + r2.y) + r3.x) + r3.y;
+          }
+          grads[(size_t)t * V + llab] = (IO)((ycol - s2) * gscale);
+        }
+        // (no barrier here: the next step writes the other halves of ps / redb / rmax and the beta buffer this one read
+        //  before its barrier)
+      };
+#pragma unroll
+      for (int i = 0; i < kAhead; i++) bfetch(br[i], T - 1 - i);
+      for (int t = T - 1; t >= 0; t -= kAhead) {
+        bstep(t, br[0]);
+        if (t - 1 >= 0) bstep(t - 1, br[1]);
+        if (t - 2 >= 0) bstep(t - 2, br[2]);
+        if (t - 3 >= 0) bstep(t - 3, br[3]);
+      }
+      ok = !__syncthreads_or(bad);
+      if (ok) {
+        if (tid == 0) losses[b] = (IO)(-logZ);
+        // columns that are neither a label nor the blank: y itself, every row at once (nothing of the lattice in them)
+        for (int t = wid; t < T; t += kThreads / 64) {
+          const IO* row = x + (int64_t)t * p.sT;
+          const double rl = lpin ? 0.0 : wl[t];
+          for (int v = lane; v < V; v += 64) {
+            if (v == blank || ((is_label[v >> 5] >> (v & 31)) & 1u)) continue;
+            grads[(size_t)t * V + v] = (IO)(exp((double)row[(int64_t)v * p.sV] - rl) * gscale);
+          }
+        }
+        for (size_t i = (size_t)T * V + tid; i < (size_t)Tmax * V; i += kThreads) {
+          const int t = (int)(i / V), v = (int)(i % V);
+          grads[i] = lpin ? (IO)(exp((double)x[(int64_t)t * p.sT + (int64_t)v * p.sV]) * gscale) : (IO)0;
+        }
+        return;
+      }
+    }
+    // (no positive finite partition sum -- no alignment, or probabilities beyond f64's range -- or a posterior that is not
+    //  a number: the log-domain walk below decides, and rewrites everything)
+  }
   // ---- P1: alpha sweep, ctc_loss.cpp:33-61 ----
   for (int j = tid; j < L; j += kThreads) {
     double a = neg_inf();
@@ -547,16 +813,18 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 //      first `nslabs` workgroups (the alpha slabs of the workspace: 24 at most -- 77 MB at B=256, T=1000, S=200 -- instead
 //      of one per workgroup);
 //   3. the last workgroup to finish recomputes what step 1 could not settle (bit 512; rare) and writes the reduction.
-template <typename IO>
+template <typename IO, bool SCALED>
+__global__ __launch_bounds__(kThreads) void ctc_exact_all_kernel(ExactParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    ctc_exact_one<IO, SCALED>(p, smem, b, blockIdx.x);
+    __syncthreads();                       // LDS is reused by the next utterance
+  }
+}
+
+template <typename IO, bool SCALED>
 __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  if (p.mode == 0) {
-    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
-      ctc_exact_one<IO>(p, smem, b, blockIdx.x);
-      __syncthreads();                       // LDS is reused by the next utterance
-    }
-    return;
-  }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // the whole flag vector in ONE round trip per workgroup (every workgroup looks at all of it, so that all of them agree
   // on what is flagged); flag words and segment counts are kept in LDS for the walks below
@@ -600,7 +868,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
 
   if (p.mode == 2) {
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
-      ctc_exact_one<IO>(p, smem, b, 0);      // (poisons flagged utterances, touches no slab)
+      ctc_exact_one<IO, false>(p, smem, b, 0);      // (poisons flagged utterances, touches no slab)
       __syncthreads();
     }
   } else {
@@ -643,7 +911,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
       while (hard) {
         const int l = __builtin_ctzll(hard); hard &= hard - 1;
         if ((int)blockIdx.x < p.nslabs && h % p.nslabs == (int)blockIdx.x) {
-          ctc_exact_one<IO>(p, smem, c0 + l, blockIdx.x);
+          ctc_exact_one<IO, SCALED>(p, smem, c0 + l, blockIdx.x);
           __syncthreads();
         }
         h++;
@@ -667,7 +935,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
       while (failed) {
         const int l = __builtin_ctzll(failed); failed &= failed - 1;
         if (tid == 0) atomicAdd(&p.ctl[1], 1);          // (diagnostics: redone in full although only the segments' range gave out)
-        ctc_exact_one<IO>(p, smem, c0 + l, 0);
+        ctc_exact_one<IO, SCALED>(p, smem, c0 + l, 0);
         __syncthreads();
       }
     }
@@ -679,7 +947,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
 
 size_t exact_lds_bytes(int V, int Smax) {
   const size_t Lmax = 2 * (size_t)Smax + 1, S1 = Smax > 0 ? Smax : 1;
-  return sizeof(double) * (2 * Lmax + S1 + 16) + sizeof(int) * (Lmax + 2 * S1 + ((size_t)V + 31) / 32);
+  return sizeof(double) * (2 * Lmax + 2 * S1 + 40) + sizeof(int) * (Lmax + 2 * S1 + ((size_t)V + 31) / 32);
 }
 // waves per workgroup that fit the redo's LDS beside the kernel's static 8.5 KB (wide alphabets: fewer than 8)
 int retry_waves(int V) {
@@ -697,7 +965,8 @@ constexpr int kFallbackGrid = 256;     // workgroups of that launch: 2 048 waves
 
 static size_t exact_bytes_for(int slabs, int T, int Smax) {
   const size_t Lmax = 2 * (size_t)Smax + 1;
-  return align_up((size_t)slabs * T * Lmax * sizeof(double), 256) + align_up((size_t)slabs * T * sizeof(double), 256);
+  return align_up((size_t)slabs * T * Lmax * sizeof(double), 256) + align_up((size_t)slabs * T * sizeof(double), 256) +
+         align_up((size_t)slabs * T * sizeof(int), 256);
 }
 
 size_t exact_workspace_bytes(int B, int T, int V, int Smax) {
@@ -742,17 +1011,26 @@ int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetr
   p.ws_alpha = reinterpret_cast<double*>(a.ws);
   p.ws_lse = reinterpret_cast<double*>(reinterpret_cast<char*>(a.ws) +
                                        align_up((size_t)slabs * a.T * p.Lmax * sizeof(double), 256));
+  p.ws_exp = reinterpret_cast<int*>(reinterpret_cast<char*>(p.ws_lse) + align_up((size_t)slabs * a.T * sizeof(double), 256));
+  const bool scaled = a.scaled_exact && a.dtype == E2E_F32;
+  p.scaled = scaled ? 1 : 0;
   const int grid = mode == 0 ? slabs : (a.B < kFallbackGrid ? a.B : kFallbackGrid);
   if (a.B == 0) return E2E_OK;
-  if (a.dtype == E2E_F32) {
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_exact_kernel<float>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_exact_kernel<float>, dim3(grid), dim3(kThreads), lds, a.stream, p);
-  } else {
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_exact_kernel<double>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_exact_kernel<double>, dim3(grid), dim3(kThreads), lds, a.stream, p);
-  }
+  auto go = [&](auto kernel) -> int {
+    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                  "hipFuncSetAttribute");
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds, a.stream, p);
+    return E2E_OK;
+  };
+  int rc;
+  if (mode == 0) {
+    if (a.dtype != E2E_F32) rc = go(&ctc_exact_all_kernel<double, false>);
+    else if (scaled) rc = go(&ctc_exact_all_kernel<float, true>);
+    else rc = go(&ctc_exact_all_kernel<float, false>);
+  } else if (a.dtype != E2E_F32) rc = go(&ctc_exact_kernel<double, false>);
+  else if (scaled) rc = go(&ctc_exact_kernel<float, true>);
+  else rc = go(&ctc_exact_kernel<float, false>);
+  if (rc != E2E_OK) return rc;
   E2E_HIP_CHECK(hipGetLastError(), "ctc_exact_kernel launch");
   return E2E_OK;
 }

@@ -1,0 +1,42 @@
+"""A/B builds of libe2e_ctc.so in ONE process on shapes that reach the exact kernel's scaled form (interleaved, median):
+  long   B=32 T=1200 V=29 S in [450,500]  (beyond the fast kernels: every utterance, two cells per thread)
+  hard   B=24 T=1000 V=29 S in [100,200], a blank-valued label in every utterance (the fast path hands all of them over)"""
+import ctypes as C, os, sys, statistics
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root)
+import torch
+from end2end_amd import _lib
+def bind(path):
+    L = C.CDLL(path)
+    L.e2e_ctc_loss_workspace_bytes.restype = C.c_size_t; L.e2e_ctc_loss_workspace_bytes.argtypes = [C.c_int] * 6
+    L.e2e_ctc_loss_fwd_bwd.restype = C.c_int
+    L.e2e_ctc_loss_fwd_bwd.argtypes = _lib.load().e2e_ctc_loss_fwd_bwd.argtypes
+    return L
+libs = {os.path.basename(p): bind(os.path.join(root, p)) for p in sys.argv[1:]}
+d = torch.device("cuda", 0)
+def case(B, T, V, S, lo, with_blank):
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, V, generator=gen).to(d); tg = torch.randint(1, V, (B, S), generator=gen)
+    if with_blank: tg[:, 5] = 0
+    tg = tg.to(d)
+    tl = torch.randint(lo, S + 1, (B,), generator=gen).to(d); xl = torch.full((B,), T).to(d)
+    losses = torch.empty(B, device=d); grads = torch.empty(B, T, V, device=d)
+    n = max(L.e2e_ctc_loss_workspace_bytes(B, T, V, S, 0, 0) for L in libs.values()); ws = torch.zeros(n, dtype=torch.uint8, device=d)
+    def call(L):
+        rc = L.e2e_ctc_loss_fwd_bwd(x.data_ptr(), 0, 0, *x.stride(), tg.data_ptr(), tg.stride(0), xl.data_ptr(), tl.data_ptr(),
+                                    B, T, V, S, 0, losses.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(), 0, None)
+        assert rc == 0
+    return call
+for name, args in (("long", (32, 1200, 29, 500, 450, False)), ("hard", (24, 1000, 29, 200, 100, True))):
+    call = case(*args)
+    res = {k: [] for k in libs}
+    for rnd in range(5):
+        for k, L in libs.items():
+            call(L); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3): call(L)
+            e1.record(); torch.cuda.synchronize()
+            res[k].append(e0.elapsed_time(e1) / 3)
+    for k, v in res.items():
+        print("%-6s %-28s median %.3f ms  min %.3f ms" % (name, k, statistics.median(v), min(v)))
