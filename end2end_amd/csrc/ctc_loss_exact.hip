@@ -458,14 +458,17 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
     const int S1 = Smax > 0 ? Smax : 1;
     const double gscale = p.gscale;
     const bool lpin = p.logprobs != 0;
-    const int K = L > kThreads ? 2 : 1;                      // cells per thread: j = tid, tid + kThreads
+    // two cells per thread, j = tid and tid + NT, on the first NT threads: half of the waves (one per SIMD, its two cells
+    // interleaved) when that covers the row -- the other waves only keep the barriers (and the blank column) company
+    const int NT = L > kThreads ? kThreads : kThreads / 2;
+    const bool act = tid < NT;
     bool live[2]; int64_t off[2]; int rk[2];
     int jc[2], jm1[2], jm2[2], jp1[2], jp2[2];               // clamped LDS indices of the cell and its neighbours
     double f0[2], f1[2], f2[2], g1[2], g2[2], binit[2];       // 1.0 where that neighbour counts
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-      const int j = tid + k * kThreads;
-      live[k] = j < L;
+      const int j = tid + k * NT;
+      live[k] = act && j < L;
       jc[k] = min(j, L - 1);
       const int c = ext[jc[k]];
       jm1[k] = max(jc[k] - 1, 0); jm2[k] = max(jc[k] - 2, 0); jp1[k] = min(jc[k] + 1, L - 1); jp2[k] = min(jc[k] + 2, L - 1);
@@ -502,44 +505,44 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
     // ---- alpha ----
     struct ASlot { IO xr[2]; double rl; };
     ASlot ar[kAhead];
+    // (fetches and steps are unconditional -- rows clamped, the steps past the end with their stores switched off: a path
+    //  through the loop that issues fewer loads makes the compiler's wait-count bookkeeping drain the ring at every use)
     auto afetch = [&](ASlot& q, int t) {
-      if (t < T) {
-        const IO* row = x + (int64_t)t * p.sT;
-        q.xr[0] = row[off[0]];
-        if (K == 2) q.xr[1] = row[off[1]];
-        q.rl = lpin ? 0.0 : wl[t];
-      }
+      t = min(t, T - 1);
+      const IO* row = x + (int64_t)t * p.sT;
+      q.xr[0] = row[off[0]]; q.xr[1] = row[off[1]];
+      q.rl = lpin ? 0.0 : wl[t];
     };
     int E = 0;
     auto astep = [&](int t, ASlot& q) {
-      const double* prev = (t & 1) ? buf0 : buf1;
-      double* cur = (t & 1) ? buf1 : buf0;
-      double* warow = wa + (size_t)t * Lmax;
-      const int e = row_exp((t - 1) & 1);
-      double p0[2], p1[2], p2[2], y[2];
-      p0[0] = prev[jc[0]]; p1[0] = prev[jm1[0]]; p2[0] = prev[jm2[0]];
-      if (K == 2) { p0[1] = prev[jc[1]]; p1[1] = prev[jm1[1]]; p2[1] = prev[jm2[1]]; }
-      y[0] = exp((double)q.xr[0] - q.rl);
-      if (K == 2) y[1] = exp((double)q.xr[1] - q.rl);
+      const bool valid = t < T;
+      const ASlot c = q;
       afetch(q, t + kAhead);
-      E += e;
-      const double a0 = ldexp((p0[0] * f0[0] + p1[0] * f1[0] + p2[0] * f2[0]) * y[0], -e);
-      if (live[0]) { cur[tid] = a0; warow[tid] = a0; }
-      int mt = live[0] ? __double2hiint(a0) : 0;
-      if (K == 2) {
-        const double a1 = ldexp((p0[1] * f0[1] + p1[1] * f1[1] + p2[1] * f2[1]) * y[1], -e);
-        if (live[1]) { cur[tid + kThreads] = a1; warow[tid + kThreads] = a1; mt = max(mt, __double2hiint(a1)); }
+      if (act) {
+        const double* prev = (t & 1) ? buf0 : buf1;
+        double* cur = (t & 1) ? buf1 : buf0;
+        double* warow = wa + (size_t)t * Lmax;
+        const int e = row_exp((t - 1) & 1);
+        const double p00 = prev[jc[0]], p10 = prev[jm1[0]], p20 = prev[jm2[0]];
+        const double p01 = prev[jc[1]], p11 = prev[jm1[1]], p21 = prev[jm2[1]];
+        const double y0 = exp((double)c.xr[0] - c.rl), y1 = exp((double)c.xr[1] - c.rl);
+        E += valid ? e : 0;
+        const double a0 = ldexp((p00 * f0[0] + p10 * f1[0] + p20 * f2[0]) * y0, -e);
+        const double a1 = ldexp((p01 * f0[1] + p11 * f1[1] + p21 * f2[1]) * y1, -e);
+        if (live[0] && valid) { cur[tid] = a0; warow[tid] = a0; }
+        if (live[1] && valid) { cur[tid + NT] = a1; warow[tid + NT] = a1; }
+        int mt = max(live[0] ? __double2hiint(a0) : 0, live[1] ? __double2hiint(a1) : 0);
+        mt = wave_max_nonneg_lane63(mt);
+        if (lane == 63 && valid) rmax[(t & 1) * 8 + wid] = mt;
       }
-      mt = wave_max_nonneg_lane63(mt);
-      if (lane == 63) rmax[(t & 1) * 8 + wid] = mt;
-      if (tid == 0) wexp[t] = E;
+      if (tid == 0 && valid) wexp[t] = E;
       lds_barrier();
     };
     {
       int mt = 0;
 #pragma unroll
       for (int k = 0; k < 2; k++) {
-        const int j = tid + k * kThreads;
+        const int j = tid + k * NT;
         if (live[k]) {
           double a = 0.0;
           if ((j == 0 && (T > 1 || L == 1)) || j == 1) a = exp(lp(0, ext[j]));
@@ -548,18 +551,13 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
         }
       }
       mt = wave_max_nonneg_lane63(mt);
-      if (lane == 63) rmax[wid] = mt;
+      if (lane == 63) { rmax[wid] = mt; rmax[8 + wid] = 0; redb[wid] = 0.0; redb[8 + wid] = 0.0; }   // (waves without cells never write these again)
       if (tid == 0) wexp[0] = 0;
 #pragma unroll
       for (int i = 0; i < kAhead; i++) afetch(ar[(1 + i) % kAhead], 1 + i);
       lds_barrier();
     }
-    for (int t = 1; t < T; t += kAhead) {
-      astep(t, ar[1]);
-      if (t + 1 < T) astep(t + 1, ar[2]);
-      if (t + 2 < T) astep(t + 2, ar[3]);
-      if (t + 3 < T) astep(t + 3, ar[0]);
-    }
+    for (int t = 1; t < T; t += kAhead) { astep(t, ar[1]); astep(t + 1, ar[2]); astep(t + 2, ar[3]); astep(t + 3, ar[0]); }
     const double* last = ((T - 1) & 1) ? buf1 : buf0;
     const double z = (L > 1) ? last[L - 1] + last[L - 2] : last[L - 1];
     __syncthreads();                                          // (also: wexp[] and the alpha rows are in memory)
@@ -572,60 +570,58 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
       struct BSlot { IO xr[2]; IO xcol; double rl; double war[2]; int ex; };
       BSlot br[kAhead];
       auto bfetch = [&](BSlot& q, int t) {
-        if (t >= 0) {
-          const IO* row = x + (int64_t)t * p.sT;
-          const double* warow = wa + (size_t)t * Lmax;
-          q.xr[0] = row[off[0]]; q.war[0] = warow[jc[0]];
-          if (K == 2) { q.xr[1] = row[off[1]]; q.war[1] = warow[jc[1]]; }
-          q.xcol = row[coloff];
-          q.rl = lpin ? 0.0 : wl[t];
-          q.ex = wexp[t];
-        }
+        t = max(t, 0);
+        const IO* row = x + (int64_t)t * p.sT;
+        const double* warow = wa + (size_t)t * Lmax;
+        q.xr[0] = row[off[0]]; q.war[0] = warow[jc[0]];
+        q.xr[1] = row[off[1]]; q.war[1] = warow[jc[1]];
+        q.xcol = row[coloff];
+        q.rl = lpin ? 0.0 : wl[t];
+        q.ex = wexp[t];
       };
       int F = 0;                                              // exponent taken out of the beta row t+1 (with its emissions)
       int bad = 0;
       auto bstep = [&](int t, BSlot& q) {
-        const double* be_next = (t & 1) ? buf0 : buf1;
-        double* be_cur = (t & 1) ? buf1 : buf0;
-        const bool first = t == T - 1;
-        const int e = first ? 0 : row_exp((t + 1) & 1);
-        double b0[2], b1[2], b2[2], y[2];
-        b0[0] = be_next[jc[0]]; b1[0] = be_next[jp1[0]]; b2[0] = be_next[jp2[0]];
-        if (K == 2) { b0[1] = be_next[jc[1]]; b1[1] = be_next[jp1[1]]; b2[1] = be_next[jp2[1]]; }
-        y[0] = exp((double)q.xr[0] - q.rl);
-        if (K == 2) y[1] = exp((double)q.xr[1] - q.rl);
-        const double ycol = exp((double)q.xcol - q.rl);
-        // alpha_t beta_t / Z in the rows' units: 2^(E_t + F - E_T) / z
-        const double unit = ldexp(invz, q.ex + F - ET);
-        const double war0 = q.war[0] * unit, war1 = q.war[1] * unit;
+        const bool valid = t >= 0;
+        const BSlot c = q;
         bfetch(q, t - kAhead);
         double* ps = psort2 + (t & 1) * S1;
-        double blank_part = 0.0;
-        const double bt0 = first ? binit[0] : b0[0] * f0[0] + b1[0] * g1[0] + b2[0] * g2[0];
-        const double bc0 = ldexp(bt0 * y[0], -e);
-        const double pj0 = war0 * bt0;
-        bad |= !(pj0 <= 2.0);
-        int mt = 0;
-        if (live[0]) {
-          be_cur[tid] = bc0; mt = __double2hiint(bc0);
-          if (tid & 1) ps[rk[0]] = pj0; else blank_part = pj0;
-        }
-        if (K == 2) {
-          const double bt1 = first ? binit[1] : b0[1] * f0[1] + b1[1] * g1[1] + b2[1] * g2[1];
-          const double bc1 = ldexp(bt1 * y[1], -e);
-          const double pj1 = war1 * bt1;
-          bad |= !(pj1 <= 2.0);
-          if (live[1]) {
-            be_cur[tid + kThreads] = bc1; mt = max(mt, __double2hiint(bc1));
-            if (tid & 1) ps[rk[1]] = pj1; else blank_part += pj1;         // (kThreads is even: same parity as tid)
+        const double xcol = (double)c.xcol - c.rl;
+        double ycol = 0.0;
+        if (act) {
+          const double* be_next = (t & 1) ? buf0 : buf1;
+          double* be_cur = (t & 1) ? buf1 : buf0;
+          const bool first = t == T - 1;
+          const int e = first ? 0 : row_exp((t + 1) & 1);
+          const double b00 = be_next[jc[0]], b10 = be_next[jp1[0]], b20 = be_next[jp2[0]];
+          const double b01 = be_next[jc[1]], b11 = be_next[jp1[1]], b21 = be_next[jp2[1]];
+          const double y0 = exp((double)c.xr[0] - c.rl), y1 = exp((double)c.xr[1] - c.rl);
+          ycol = exp(xcol);
+          // alpha_t beta_t / Z in the rows' units: 2^(E_t + F - E_T) / z
+          const double unit = ldexp(invz, c.ex + F - ET);
+          const double war0 = c.war[0] * unit, war1 = c.war[1] * unit;
+          const double bt0 = first ? binit[0] : b00 * f0[0] + b10 * g1[0] + b20 * g2[0];
+          const double bt1 = first ? binit[1] : b01 * f0[1] + b11 * g1[1] + b21 * g2[1];
+          const double bc0 = ldexp(bt0 * y0, -e), bc1 = ldexp(bt1 * y1, -e);
+          const double pj0 = war0 * bt0, pj1 = war1 * bt1;
+          bad |= valid & (!(pj0 <= 2.0) | !(pj1 <= 2.0));
+          double blank_part = 0.0;
+          if (live[0] && valid) {
+            be_cur[tid] = bc0;
+            if (tid & 1) ps[rk[0]] = pj0; else blank_part = pj0;
           }
+          if (live[1] && valid) {
+            be_cur[tid + NT] = bc1;
+            if (tid & 1) ps[rk[1]] = pj1; else blank_part += pj1;          // (NT is even: same parity as tid)
+          }
+          F += e;
+          int mt = max(live[0] ? __double2hiint(bc0) : 0, live[1] ? __double2hiint(bc1) : 0);
+          mt = wave_max_nonneg_lane63(mt);
+          blank_part = wave_sum_lane63(blank_part);
+          if (lane == 63 && valid) { redb[(t & 1) * 8 + wid] = blank_part; rmax[(t & 1) * 8 + wid] = mt; }
         }
-        F += e;
-        mt = wave_max_nonneg_lane63(mt);
-        blank_part = wave_sum_lane63(blank_part);
-        if (lane == 63) { redb[(t & 1) * 8 + wid] = blank_part; rmax[(t & 1) * 8 + wid] = mt; }
         lds_barrier();
-        if (hascol) {
+        if (hascol && valid) {
           double s2 = 0.0;
           if (leader) {
             // the run's posteriors in increasing-j order (ctc_loss.cpp:109-114), four LDS reads in flight at a time
@@ -644,19 +640,16 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
                           r2 = *reinterpret_cast<const double2*>(rb + 4), r3 = *reinterpret_cast<const double2*>(rb + 6);
             s2 += ((((((r0.x + r0.y) + r1.x) + r1.y) + r2.x) + r2.y) + r3.x) + r3.y;
           }
+          if (!act) ycol = exp(xcol);                       // (the blank column's thread when its wave has no cells)
           grads[(size_t)t * V + llab] = (IO)((ycol - s2) * gscale);
         }
         // (no barrier here: the next step writes the other halves of ps / redb / rmax and the beta buffer this one read
-        //  before its barrier)
+        //  before its barrier.  Folding this column pass into the next step's stretch of code -- one LDS round trip for
+        //  both -- measured no faster: 1.90 against 1.94 ms on 24 handed-over C2 utterances, 3.67 against 3.28 ms at S=500.)
       };
 #pragma unroll
       for (int i = 0; i < kAhead; i++) bfetch(br[i], T - 1 - i);
-      for (int t = T - 1; t >= 0; t -= kAhead) {
-        bstep(t, br[0]);
-        if (t - 1 >= 0) bstep(t - 1, br[1]);
-        if (t - 2 >= 0) bstep(t - 2, br[2]);
-        if (t - 3 >= 0) bstep(t - 3, br[3]);
-      }
+      for (int t = T - 1; t >= 0; t -= kAhead) { bstep(t, br[0]); bstep(t - 1, br[1]); bstep(t - 2, br[2]); bstep(t - 3, br[3]); }
       ok = !__syncthreads_or(bad);
       if (ok) {
         if (tid == 0) losses[b] = (IO)(-logZ);
