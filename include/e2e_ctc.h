@@ -39,7 +39,8 @@ extern "C" {
 #define E2E_ERR_IO (-5)           /* LM file could not be read / parsed (host) */
 
 /* which CTC loss algorithm to run */
-#define E2E_ALGO_AUTO 0    /* fast scaled path for f32 where valid, exact otherwise */
+#define E2E_ALGO_AUTO 0    /* fast scaled path for f32 where valid; otherwise the exact kernel -- for f32 in its rescaled
+                            * f64 probability-domain form, for f64 in the reference's log domain */
 #define E2E_ALGO_EXACT 1   /* f64 log-domain lattice, the reference's arithmetic */
 #define E2E_ALGO_FAST 2    /* scaled linear-domain lattice, flags invalid utterances */
 

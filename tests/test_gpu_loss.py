@@ -437,12 +437,12 @@ def test_word_piece_vocabularies_are_served_whatever_the_dtype(dtype):
 
 
 @pytest.mark.parametrize("shape", [(2, 400, 500, 150), (2, 700, 29, 300), (1, 650, 3000, 300), (2, 300, 97, 120),
-                                   (2, 256, 8000, 200), (1, 2000, 29, 400)],
+                                   (2, 256, 8000, 200), (1, 2000, 29, 400), (2, 1300, 29, 500), (1, 1100, 40, 520)],
                          ids=lambda s: "B%d_T%d_V%d_S%d" % s)
 def test_shapes_outside_the_fast_paths_are_still_served(shape):
-    """Targets longer than 255 labels, or more than 95 distinct labels at an alphabet beyond 96 columns: neither the
-    small-alphabet lattice kernels nor the wide-alphabet compaction take these; the exact kernel must (no
-    E2E_ERR_UNSUPPORTED, the reference has no such bounds)."""
+    """Targets longer than the fast kernels take (447 labels), or more than 95 distinct labels at an alphabet beyond 96
+    columns: the exact kernel must serve these (no E2E_ERR_UNSUPPORTED, the reference has no such bounds) -- under AUTO
+    with f32 in its scaled probability-domain form (two cells per thread: up to 511 labels), beyond that in the log domain."""
     B, T, V, S = shape
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, T, V, generator=g)
@@ -480,6 +480,27 @@ def test_more_fully_recomputed_utterances_than_alpha_slabs_and_a_mixed_batch():
     assert np.isinf(red) and red > 0
     la2, _, red2 = U.c_abi_loss(xt[50:], tg[50:], xl[50:], tl[50:], 0, False, _lib.ALGO_AUTO, opts=(1.0, _lib.REDUCE_MEAN))
     assert abs(red2 - l_o[50:].mean()) <= 1e-5 * abs(l_o[50:].mean())
+
+
+def test_scaled_exact_form_hands_over_to_the_log_domain_beyond_f64_range():
+    """Under AUTO the exact kernel walks f32 utterances in the probability domain (f64 rows rescaled by powers of two).
+    Log-probabilities below f64's exponent range (exp(-800) == 0) leave that form without a partition sum: it must hand the
+    utterance to the log-domain walk, whose answer the oracle gives; a row that merely drives the *product* out of range
+    (-300 a frame) stays in the scaled form.  Both utterances reach the exact kernel through a blank-valued label."""
+    T, V = 12, 6
+    lp = np.full((2, T, V), -800.0, dtype=np.float32)
+    lp[1] = -300.0
+    rng = np.random.default_rng(3)
+    lp += rng.uniform(-2, 0, size=lp.shape).astype(np.float32)
+    tg = np.array([[1, 0, 3], [2, 0, 2]]); xl = [T, T - 2]; tl = [3, 3]
+    l_o, g_o = O.ctc_loss(lp.astype(np.float64), tg, xl, tl, 0)
+    assert np.isfinite(l_o).all() and l_o[0] > 9000 and l_o[1] > 2900
+    losses, grads = U.c_abi_loss(torch.from_numpy(lp), tg, xl, tl, 0, True, _lib.ALGO_AUTO)
+    U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
+    le, ge = U.c_abi_loss(torch.from_numpy(lp), tg, xl, tl, 0, True, _lib.ALGO_EXACT)
+    U.assert_same(le, losses, 1e-6, 0, "losses: scaled / handed-over against the log-domain kernel")
+    U.assert_same(ge, grads, 1e-6, 1e-9, "grads: scaled / handed-over against the log-domain kernel")
 
 
 @pytest.mark.parametrize("shape", [(3, 700, 29, 300), (2, 2000, 29, 400), (2, 1100, 48, 447)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)

@@ -15,7 +15,7 @@ python3 tools/diag/pmc_summary.py gpurun_out/pmc_${TAG}_fetch
 python3 tools/diag/pmc_summary.py gpurun_out/pmc_${TAG}_write
 fi
 find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs head -8 | cut -c1-180
-tail -1 gpurun_out/prof_$TAG.log | python3 -c "
+grep '^{"metric' gpurun_out/prof_$TAG.log | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print({k:d[k] for k in ('value','ms_per_step','module_ms_per_step')}, d['roofline']['kernel_ms'], d['roofline']['frac'], d['roofline']['peak_measured'])
