@@ -660,6 +660,8 @@ struct SlotMap {
 #ifdef E2E_BEAM_PROFILE
 } }  // leave the namespaces for the device symbol
 __device__ unsigned long long g_beam_prof[16];
+__device__ unsigned long long g_beam_sigs[1 << 17];
+__device__ int g_beam_nsig;
 namespace e2e { namespace {
 #define BPROF(slot) do { if (b == 0 && tid == 0) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); g_beam_prof[slot] += _n - _tprev; _tprev = _n; } } while (0)
 #else
@@ -1109,6 +1111,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
             if (same) leader = o;
           }
           if (leader == j2) newlist[atomicAdd(&s_nnew, 1)] = j2;
+#ifdef E2E_BEAM_PROFILE
+          if (leader == j2 && b == 0) { const int q9 = atomicAdd(&g_beam_nsig, 1); if (q9 < (1 << 17)) g_beam_sigs[q9] = sg[j2]; }
+#endif
         }
         ldr[j2] = leader;
       }
@@ -1815,6 +1820,16 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
 }
 
 #ifdef E2E_BEAM_PROFILE
+extern "C" int e2e_debug_beam_sigs(unsigned long long* host, int cap) {
+  int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_beam_nsig), sizeof(int)) != hipSuccess) return -1;
+  if (n > cap) n = cap;
+  if (n > (1 << 17)) n = 1 << 17;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_beam_sigs), sizeof(unsigned long long) * n) != hipSuccess) return -1;
+  const int zero = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_beam_nsig), &zero, sizeof(int));
+  return n;
+}
 extern "C" int e2e_debug_beam_profile(unsigned long long* host) {
   if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_beam_prof), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : E2E_ERR_HIP;

@@ -14,6 +14,7 @@ to the C ABI (include/e2e_ctc.h) through the pybind11 layer `end2end_amd._C`.  C
 and the loss results moved back to the source device and dtype (forward_backward.cpp:55-56); decode results are CPU
 tensors as upstream (ctc_decoder.cpp:157,449) unless `keep_on_device` is set.
 """
+import numpy as np
 import torch
 
 from . import _runtime as R
@@ -158,6 +159,8 @@ class CTCDecoderEngine:
         self.keep_on_device = bool(keep_on_device)
         # index of " " among the labels, else -1 (src/decoders/ctc_decoder.cpp:55-59)
         self.space_id = self.labels.index(" ") if " " in self.labels else -1
+        self._codes = (np.array([ord(c) for c in self.labels], dtype="<u4")
+                       if self.labels and all(len(c) == 1 for c in self.labels) else None)
         self.lm = None
         if self.labels and self.beam_width > 1:
             # the beam lives in one workgroup's LDS: a width / alphabet it cannot hold is reported now, not at the first
@@ -177,6 +180,17 @@ class CTCDecoderEngine:
         # the reference then reads labels[-1] out of bounds (undefined behaviour) -- here that id spells nothing.
         if not self.labels:
             return ["" for _ in lens]
+        if self._codes is not None and len(lens) and isinstance(rows, torch.Tensor):
+            # one-character labels (the usual alphabet): one table lookup and one decode for the whole batch instead of a
+            # Python-level join per id (4 ms of a 17 ms beam-search call at B=64, T=1500)
+            ids = rows.numpy()
+            if ids.size == 0 or int(ids.min()) >= 0:
+                width = ids.shape[1]
+                text = self._codes[ids].tobytes().decode("utf-32-le")
+                return [text[b * width: b * width + n] for b, n in enumerate(lens)]
+            rows = ids.tolist()
+        elif isinstance(rows, torch.Tensor):
+            rows = rows.tolist()
         return ["".join(self.labels[k] for k in row[:n] if k >= 0) for row, n in zip(rows, lens)]
 
     def _prep(self, logits_, logits_lengths_):
@@ -213,7 +227,7 @@ class CTCDecoderEngine:
                 _C.ctc_greedy(x.data_ptr(), R.dtype_code(x.dtype), sB, sT, sV, xl.data_ptr(), B, T, V,
                               self.blank_idx, out.data_ptr(), out_len.data_ptr(), R.stream_handle(dev))
         out, out_len = self._result(out), self._result(out_len)
-        sentences = self._strings(out.tolist(), out_len.tolist()) if self.labels else ["" for _ in range(B)]
+        sentences = self._strings(out.cpu(), out_len.tolist()) if self.labels else ["" for _ in range(B)]
         return out, out_len, sentences
 
     def decode(self, logits_, logits_lengths_):
@@ -243,7 +257,7 @@ class CTCDecoderEngine:
         width = max(lens) if lens else 0
         ids = out[:, :width].contiguous()    # packed to the longest result (ctc_decoder.cpp:192-200)
         ids, out_len = self._result(ids), self._result(out_len)
-        return ids, out_len, self._strings(ids.tolist(), lens)
+        return ids, out_len, self._strings(ids.cpu(), lens)
 
     def print_scores_for_sentence(self, words):
         """src/decoders/ctc_decoder.cpp:141-151: word, decoder index, vocabulary index, log10 score."""

@@ -37,6 +37,7 @@ int e2e_debug_fast_profile3(unsigned long long* host, int reset);
 #endif
 #ifdef E2E_BEAM_PROFILE
 int e2e_debug_beam_profile(unsigned long long* host);
+int e2e_debug_beam_sigs(unsigned long long* host, int cap);   /* LM states of utterance 0 that had to ask, in order; resets the list */
 #endif
 
 #ifdef __cplusplus
