@@ -162,3 +162,41 @@ def test_flagged_utterances_are_settled_by_the_segment_redo_not_by_the_exact_ker
     L.e2e_debug_fast_redo_failures.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
     assert L.e2e_debug_fast_redo_failures(kept["workspace"].data_ptr(), B, T, V, S, ctypes.byref(n)) == 0
     assert 0 <= n.value <= flagged // 4, (n.value, flagged)
+
+
+@pytest.mark.parametrize("seed,n", [(301, 60), (302, 60)])
+def test_scaled_exact_form_agrees_with_the_log_domain_kernel(seed, n):
+    """Under AUTO with f32 the exact kernel walks in the probability domain (ctc_loss_exact.hip, SCALED).  Every utterance here
+    reaches it -- a target equal to the blank id in the batch's every utterance that has targets (the fast path hands those
+    over), or targets beyond the fast kernels' 447 labels -- and must agree with E2E_ALGO_EXACT, the reference's log-domain
+    arithmetic (pinned to the oracle elsewhere), to f32 rounding: T from 1, empty targets, ragged lengths, repeats,
+    infeasible alignments (the log-domain walk's inf / NaN pattern), fused logits and log-probs, any blank id."""
+    rng = np.random.default_rng(seed)
+    for case in range(n):
+        long_targets = case % 6 == 5
+        B = int(rng.integers(1, 5))
+        if long_targets:
+            T = int(rng.integers(460, 1200)); V = int(rng.integers(3, 60)); Smax = int(rng.integers(448, min(T, 640) + 1))
+        else:
+            T = int(rng.integers(1, 300)); V = int(rng.integers(2, 97)); Smax = int(rng.integers(1, min(255, T) + 1))
+        sharp = float(rng.choice([0.1, 1.0, 3.0, 8.0]))
+        fused = bool(rng.integers(0, 2)); blank = int(rng.choice([0, V - 1, rng.integers(0, V)]))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(B, T, V, generator=g) * sharp
+        if not fused:
+            x = torch.log_softmax(x.double(), -1).float()
+        labs = [v for v in range(V) if v != blank]
+        few = labs[: max(1, len(labs) // 8)] if rng.integers(0, 2) else labs        # (few labels: many adjacent repeats)
+        tg = torch.tensor(rng.choice(few, size=(B, Smax)), dtype=torch.long)
+        xl = torch.tensor(rng.integers(1, T + 1, size=B)); xl[0] = T
+        tl = torch.tensor(rng.integers(0, Smax + 1, size=B)); tl[0] = Smax
+        if not long_targets:
+            for b in range(B):
+                if tl[b] > 0:
+                    tg[b, int(rng.integers(0, int(tl[b])))] = blank             # handed over by the fast path
+        le, ge = U.c_abi_loss(x, tg, xl, tl, blank, not fused, _lib.ALGO_EXACT)
+        la, ga = U.c_abi_loss(x, tg, xl, tl, blank, not fused, _lib.ALGO_AUTO)
+        what = "case %d: B=%d T=%d V=%d S=%d fused=%d blank=%d sharp=%g xl=%s tl=%s" % (
+            case, B, T, V, Smax, fused, blank, sharp, xl.tolist(), tl.tolist())
+        U.assert_same(la, le, 2e-6, 0, "losses, " + what)
+        U.assert_same(ga, ge, 1e-5, 2e-7, "grads, " + what)
