@@ -7,7 +7,7 @@ root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import torch
 import end2end_amd._lib as _lib
-_lib.LIB_PATH = os.path.join(root, "build/diag/prof_lib.so")
+_lib.LIB_PATH = os.path.join(root, os.environ.get("E2E_PROF_LIB", "build/diag/prof_lib.so"))
 import gpu_util as U
 d = torch.device("cuda", 0)
 labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
