@@ -387,6 +387,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
   // alignment whatever the emissions: the reference walks the whole lattice to find log Z = -inf, then its
   // exp(-inf - (-inf)) poisons the slab (Q2: loss +inf, grads NaN).  Same result here without the walk: a batch with one
   // such utterance cost the fast path's caller a full 7 ms recomputation per step.
+  bool blank_valued_label = false;     // a target equal to the blank id (the reference shares the blank column, :109-113)
   {
     int need = 0, blank_label = 0;
     for (int i = tid; i < S; i += kThreads) {
@@ -400,6 +401,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
     int total = 0;
     for (int w2 = 0; w2 < kThreads / 64; w2++) total += (int)red[w2];
     __syncthreads();
+    blank_valued_label = any_blank != 0;
     if (!any_blank && T < total) {
       const double qnan = __builtin_nan("");
       if (tid == 0) losses[b] = (IO)__builtin_huge_val();
@@ -709,12 +711,16 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
   if (tid == 0) losses[b] = (IO)(-logZ);
   __syncthreads();
 
-  if (logZ == neg_inf()) {
+  const double qnan = __builtin_nan("");
+  const bool infeasible = logZ == neg_inf();
+  if (infeasible && !blank_valued_label) {
     // infeasible alignment: the reference's exp(-inf - (-inf)) poisons the whole slab (Q2)
-    const double qnan = __builtin_nan("");
     for (size_t i = tid; i < (size_t)Tmax * V; i += kThreads) grads[i] = (IO)qnan;
     return;
   }
+  // (infeasible WITH a blank-valued target: the reference's alpha refuses the skip into such a label, its beta takes it, so
+  //  cells can have a finite alpha + beta although log Z is -inf; exp(log_post - logZ) is then +inf for a column with such a
+  //  cell and NaN for the others.  The sweep below runs with "is the cell finite" in place of the posterior.)
 
   // ---- P3: beta sweep (ctc_loss.cpp:72-100) fused with the gradient (:102-117) ----
   // be[j] holds beta[j][t+1] + lp[t+1][ext[j]], the quantity the three-way sum reads.
@@ -738,7 +744,8 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
         }
       }
       be_cur[j] = bt + lp(t, cl);
-      const double pj = exp(warow[j] + bt - logZ);   // posterior of cell (j,t); exp(-inf)=0
+      // posterior of cell (j,t); exp(-inf)=0   (infeasible: 1 for a finite cell)
+      const double pj = infeasible ? ((warow[j] + bt > neg_inf()) ? 1.0 : 0.0) : exp(warow[j] + bt - logZ);
       if (j & 1) psorted[rank[j >> 1]] = pj; else blank_part += pj;
     }
     blank_part = wave_sum(blank_part);
@@ -755,6 +762,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
           // the label's column of the gradient row, written here by the thread that holds its sum (the dense pass below
           // skips the columns that are labels)
           const double rl_ = p.logprobs ? 0.0 : wl[t];
+          if (infeasible) s = s > 0.0 ? __builtin_huge_val() : qnan;
           grads[(size_t)t * V + lab] = (IO)((exp((double)x[(int64_t)t * p.sT + (int64_t)lab * p.sV] - rl_) - s) * p.gscale);
         } else red[8] = s;
       }
@@ -773,7 +781,8 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
         // blank column = even cells (+ target cells whose label equals the blank id, red[8]); every other column that is
         // not a label has posterior 0
         if ((is_label[v >> 5] >> (v & 31)) & 1u) continue;
-        const double pv = (v == blank) ? red[9] + red[8] : 0.0;
+        double pv = (v == blank) ? red[9] + red[8] : 0.0;
+        if (infeasible) pv = pv > 0.0 ? __builtin_huge_val() : qnan;
         grow[v] = (IO)((exp((double)xrow[(int64_t)v * p.sV] - rl) - pv) * p.gscale);
       }
     }
@@ -782,10 +791,10 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
     __syncthreads();
   }
 
-  // ---- padded frames t >= T: exp(lp) in log-prob mode (Q1), 0 for fused logits ----
+  // ---- padded frames t >= T: exp(lp) in log-prob mode (Q1), 0 for fused logits; infeasible: NaN (-inf - -inf) ----
   for (size_t i = (size_t)T * V + tid; i < (size_t)Tmax * V; i += kThreads) {
     const int t = (int)(i / V), v = (int)(i % V);
-    grads[i] = p.logprobs ? (IO)(exp((double)x[(int64_t)t * p.sT + (int64_t)v * p.sV]) * p.gscale) : (IO)0;
+    grads[i] = infeasible ? (IO)qnan : p.logprobs ? (IO)(exp((double)x[(int64_t)t * p.sT + (int64_t)v * p.sV]) * p.gscale) : (IO)0;
   }
 }
 

@@ -482,6 +482,21 @@ def test_more_fully_recomputed_utterances_than_alpha_slabs_and_a_mixed_batch():
     assert abs(red2 - l_o[50:].mean()) <= 1e-5 * abs(l_o[50:].mean())
 
 
+@pytest.mark.parametrize("algo", [_lib.ALGO_AUTO, _lib.ALGO_EXACT], ids=ALGO_IDS.get)
+def test_no_alignment_and_a_blank_valued_target_leaves_the_references_element_pattern(algo):
+    """Invalid input twice over: the reference's alpha refuses the skip into a label equal to the blank id, its beta takes
+    it, so alpha + beta can be finite where log Z is -inf -- exp(log_post - logZ) then leaves -inf in those columns and NaN
+    in the others (ctc_loss.cpp:102-117).  Found by tools/diag/fuzz_scaled_vs_oracle.py; utterances 1..3 are ordinary."""
+    x = torch.randn(4, 2, 2, generator=torch.Generator().manual_seed(640)) * 8.0
+    lp = torch.log_softmax(x.double(), -1)
+    tg = np.array([[1, 0], [0, 1], [1, 1], [0, 1]]); xl = [2, 1, 1, 2]; tl = [2, 1, 0, 1]
+    l_o, g_o = O.ctc_loss(lp.numpy(), tg, xl, tl, 0)
+    assert np.isinf(l_o[0]) and np.isneginf(g_o[0]).any() and np.isnan(g_o[0]).any() and np.isfinite(l_o[1:]).all()
+    losses, grads = U.c_abi_loss(lp.float(), tg, xl, tl, 0, True, algo)
+    U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
+
+
 def test_scaled_exact_form_hands_over_to_the_log_domain_beyond_f64_range():
     """Under AUTO the exact kernel walks f32 utterances in the probability domain (f64 rows rescaled by powers of two).
     Log-probabilities below f64's exponent range (exp(-800) == 0) leave that form without a partition sum: it must hand the

@@ -37,13 +37,6 @@ for case in range(n_cases):
         for b in range(B):
             if np.isfinite(l_o[b]): g_o[b, int(xl[b]):] = 0.0          # (an infeasible utterance stays NaN everywhere, quirk Q2)
     lg, gg = U.c_abi_loss(inp, tg, xl, tl, blank, not fused, _lib.ALGO_AUTO)
-    for b in range(B):
-        # No alignment AND a blank-valued target: the reference's exp(log_post - logZ) with logZ = -inf leaves -inf where a
-        # label's cells are finite and NaN elsewhere; the kernels poison the whole slab with NaN (as the reference does
-        # for every infeasible utterance with valid targets).  Compared as "not finite".
-        if np.isinf(l_o[b]):
-            assert not np.isfinite(g_o[b][: int(xl[b])]).any()
-            g_o[b] = np.nan
     try:
         U.assert_same(lg, l_o, 1e-4, 2e-6, "losses"); U.assert_same(gg, g_o, 1e-4, 2e-6, "grads")
     except AssertionError as e:
