@@ -191,18 +191,24 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
   float fix[kMaxFix]; int fixcol[kMaxFix];
 #pragma unroll
   for (int u = 0; u < kMaxFix; u++) { fix[u] = 0.f; fixcol[u] = -1; }
-  if (live) {
+  // (no alignment AND a target equal to the blank id: the reference leaves -inf in the columns that have a cell with a finite
+  //  alpha + beta -- see ctc_exact_one -- and the compact gradient carries that pattern into the poisoned row)
+  const bool inf_pattern = !bad_len && loss == __builtin_huge_valf() && t < Tq;
+  if (live || inf_pattern) {
     const float* gc = p.gc + (size_t)row * p.VC;
     const int* cl = p.clabel + (size_t)b * p.VC;
-    const float sh = p.shift[row];
+    const float sh = live ? p.shift[row] : 0.f;
 #pragma unroll
     for (int u = 0; u < kMaxFix; u++) {
       const int k = lane + 64 * u;
       if (k < p.VC) {
         const int l = cl[k];
-        if (l >= 0) {
+        if (l >= 0 && live) {
           const float xl = xr[(int64_t)l * p.sV] - lse;
           fix[u] = (exp_acc(xl) - (exp_acc(xl - sh) - gc[k])) * p.gscale;
+          fixcol[u] = l;
+        } else if (l >= 0 && gc[k] == -__builtin_huge_valf()) {
+          fix[u] = -__builtin_huge_valf();
           fixcol[u] = l;
         }
       }
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
   } else {
     for (int i = lane; i < p.V; i += 64) gr[i] = poison ? qnan : (zero ? 0.f : exp_acc(xr[(int64_t)i * p.sV] - lse) * p.gscale);
   }
-  if (live) {
+  if (live || inf_pattern) {
     // the dense row above and these columns are written by different lanes of this wave: order them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
@@ -368,6 +374,17 @@ __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
     const vf4 o = {f, f, f, f};
     vf4* g4 = reinterpret_cast<vf4*>(gr);
     for (int i = lane; i < (p.V >> 2); i += 64) __builtin_nontemporal_store(o, &g4[i]);
+    if (t < Tq) {
+      // (no alignment AND a target equal to the blank id: the reference leaves -inf in the columns that have a cell with a
+      //  finite alpha + beta -- see ctc_exact_one -- and the compact gradient carries that pattern)
+      const float* gc = p.gc + (size_t)row * p.VC;
+      const int* cl = p.clabel + (size_t)b * p.VC;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the row's NaN stores have landed)
+      for (int k = lane; k < p.VC; k += 64) {
+        const int l = cl[k];
+        if (l >= 0 && gc[k] == -__builtin_huge_valf()) gr[l] = -__builtin_huge_valf();
+      }
+    }
     return;
   }
   if (t >= Tq) return;

@@ -482,12 +482,14 @@ def test_more_fully_recomputed_utterances_than_alpha_slabs_and_a_mixed_batch():
     assert abs(red2 - l_o[50:].mean()) <= 1e-5 * abs(l_o[50:].mean())
 
 
+@pytest.mark.parametrize("V", [2, 300])
 @pytest.mark.parametrize("algo", [_lib.ALGO_AUTO, _lib.ALGO_EXACT], ids=ALGO_IDS.get)
-def test_no_alignment_and_a_blank_valued_target_leaves_the_references_element_pattern(algo):
+def test_no_alignment_and_a_blank_valued_target_leaves_the_references_element_pattern(algo, V):
     """Invalid input twice over: the reference's alpha refuses the skip into a label equal to the blank id, its beta takes
     it, so alpha + beta can be finite where log Z is -inf -- exp(log_post - logZ) then leaves -inf in those columns and NaN
-    in the others (ctc_loss.cpp:102-117).  Found by tools/diag/fuzz_scaled_vs_oracle.py; utterances 1..3 are ordinary."""
-    x = torch.randn(4, 2, 2, generator=torch.Generator().manual_seed(640)) * 8.0
+    in the others (ctc_loss.cpp:102-117).  Found by tools/diag/fuzz_scaled_vs_oracle.py; utterances 1..3 are ordinary;
+    V = 300 goes through the wide-alphabet path, which has to carry the pattern out of its compact columns."""
+    x = torch.randn(4, 2, V, generator=torch.Generator().manual_seed(640)) * 8.0
     lp = torch.log_softmax(x.double(), -1)
     tg = np.array([[1, 0], [0, 1], [1, 1], [0, 1]]); xl = [2, 1, 1, 2]; tl = [2, 1, 0, 1]
     l_o, g_o = O.ctc_loss(lp.numpy(), tg, xl, tl, 0)

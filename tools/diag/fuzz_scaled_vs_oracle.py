@@ -8,6 +8,7 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np, torch
 import gpu_util as U, oracle_lib as O
 from end2end_amd import _lib
+WIDE = os.environ.get("FUZZ_WIDE") == "1"      # also alphabets that take the wide path
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
@@ -17,7 +18,7 @@ for case in range(n_cases):
     if long_targets:
         T = int(rng.integers(450, 700)); V = int(rng.choice([3, 29, 64])); Smax = int(rng.integers(448, min(T + 2, 600) + 1))
     else:
-        T = int(rng.integers(1, 200)); V = int(rng.choice([2, 3, 5, 29, 64, 96])); Smax = int(rng.integers(1, min(120, T + 3) + 1))
+        T = int(rng.integers(1, 200)); V = int(rng.choice([2, 3, 5, 29, 64, 96, 200, 1500] if WIDE else [2, 3, 5, 29, 64, 96])); Smax = int(rng.integers(1, min(120, T + 3) + 1))
     fused = bool(rng.integers(0, 2)); blank = int(rng.choice([0, V - 1, rng.integers(0, V)]))
     g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
     x = torch.randn(B, T, V, generator=g, dtype=torch.float64) * float(rng.choice([0.3, 1.0, 4.0, 8.0, 12.0]))
