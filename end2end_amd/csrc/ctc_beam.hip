@@ -50,7 +50,19 @@ struct NgSlot { uint32_t ids[kLmMaxOrder]; int32_t n; float prob; float backoff;
 // The same tables in the form the kernel probes: one 16-byte load per probe, matched by the n-gram's 64-bit hash
 // (the loader checks that no two n-grams of the model share one; a queried n-gram that is NOT in the model would have
 // to collide in all 64 bits with the entry at its probe position to be mistaken for it).
-struct NgSig { uint64_t sig; float prob; float backoff; };       // sig 0: empty
+struct NgSig {                                                   // sig 0: empty
+  uint64_t sig; float prob; float backoff;
+  // second half, read for CONTEXT lookups only: one bit per continuation word of this n-gram (bit cont_bit(w) is set if the
+  // model lists (this n-gram, w)).  A query's longer n-grams are only looked up when their context says they may exist:
+  // what a beam step asks is bound by the number of distinct cache lines its waves touch, and for most
+  // (context, word) pairs a beam search tries there is no such n-gram.  No false negatives; contexts with many
+  // continuations fill their 64 bits and every lookup is made, as before.
+  uint64_t cont; uint64_t pad;
+};
+// Unigrams are not hashed at all: one 16-byte entry per word id (prob > 0: the model has no such unigram).  A few hundred
+// KB that stay in L2, where the hashed table (megabytes, one slot per random line) is a trip past it for every probe.
+struct UniEntry { float prob; float backoff; uint64_t cont; };
+__host__ __device__ inline int cont_bit(uint32_t w) { return (int)(((uint64_t)w * 0x9E3779B97F4A7C15ULL) >> 58); }
 struct VEntry { uint64_t key; uint32_t val; uint32_t pad; };     // key 0: empty
 
 struct LmView {                    // what the kernel sees (device pointers) / what the host scorer sees
@@ -61,6 +73,7 @@ struct LmView {                    // what the kernel sees (device pointers) / w
   const unsigned char* label_bytes; const int* label_off;   // label c spells bytes [off[c], off[c+1])
   int fold_case;
   const NgSig* ngs; const VEntry* vt;                        // device only (null: n-gram hashes collide, use ng / vkeys)
+  const UniEntry* uni; uint32_t nwords;                      // device only, with ngs
   float unk_prob;                                            // p(<unk>) (KenLM's -100 if the model has none)
 };
 
@@ -143,15 +156,16 @@ struct e2e_lm {
   uint64_t* d_vkeys = nullptr; uint32_t* d_vvals = nullptr; e2e::NgSlot* d_ng = nullptr;
   unsigned char* d_label_bytes = nullptr; int* d_label_off = nullptr;
   e2e::NgSig* d_ngs = nullptr; e2e::VEntry* d_vt = nullptr;     // (d_ngs stays null if two n-grams share a hash)
+  e2e::UniEntry* d_uni = nullptr; uint32_t nwords = 0;
   float unk_prob = -100.f;
   int device = -1;                                       // HIP device that holds the tables (-1: host only)
   e2e::LmView host_view() const {
     return {order, vkeys.data(), vvals.data(), (uint32_t)vkeys.size() - 1, ng.data(), (uint32_t)ng.size() - 1, bos,
-            label_bytes.data(), label_off.data(), fold_case, nullptr, nullptr, unk_prob};
+            label_bytes.data(), label_off.data(), fold_case, nullptr, nullptr, nullptr, nwords, unk_prob};
   }
   e2e::LmView dev_view() const {
     return {order, d_vkeys, d_vvals, (uint32_t)vkeys.size() - 1, d_ng, (uint32_t)ng.size() - 1, bos,
-            d_label_bytes, d_label_off, fold_case, d_ngs, d_ngs ? d_vt : nullptr, unk_prob};
+            d_label_bytes, d_label_off, fold_case, d_ngs, d_ngs ? d_vt : nullptr, d_ngs ? d_uni : nullptr, nwords, unk_prob};
   }
 };
 
@@ -280,7 +294,9 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
     return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
   };
   // the kernel's 16-byte forms of the two tables (same slots)
-  std::vector<NgSig> ngs(lm->ng.size(), NgSig{0, 0.f, 0.f});
+  std::vector<NgSig> ngs(lm->ng.size(), NgSig{0, 0.f, 0.f, 0, 0});
+  std::vector<UniEntry> uni(words.size(), UniEntry{1.f, 0.f, 0});
+  lm->nwords = (uint32_t)words.size();
   bool sig_ok = true;
   {
     std::vector<uint64_t> seen;
@@ -294,11 +310,29 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
     }
     std::sort(seen.begin(), seen.end());
     sig_ok = std::adjacent_find(seen.begin(), seen.end()) == seen.end();
+    // continuation bits: (w1 .. wn) sets bit cont_bit(wn) of its context (w1 .. wn-1).  An n-gram whose context is not
+    // listed (ARPA files written by the usual tools always list it) switches the filter off: every bit set.
+    bool contexts_listed = true;
+    const LmView hv = lm->host_view();
+    for (size_t i = 0; i < lm->ng.size(); i++) {
+      const NgSlot& sl = lm->ng[i];
+      if (sl.n == 1) { uni[sl.ids[0]].prob = sl.prob; uni[sl.ids[0]].backoff = sl.backoff; }
+    }
+    for (size_t i = 0; i < lm->ng.size() && contexts_listed; i++) {
+      const NgSlot& sl = lm->ng[i];
+      if (sl.n < 2) continue;
+      const NgSlot* c = lm_ngram_find(hv, sl.ids, sl.n - 1);
+      if (!c) { contexts_listed = false; break; }
+      const uint64_t bit = 1ULL << cont_bit(sl.ids[sl.n - 1]);
+      if (sl.n == 2) uni[sl.ids[0]].cont |= bit; else ngs[(size_t)(c - lm->ng.data())].cont |= bit;
+    }
+    if (!contexts_listed) { for (auto& e : ngs) e.cont = ~0ULL; for (auto& e : uni) e.cont = ~0ULL; }
   }
   std::vector<VEntry> vt(lm->vkeys.size());
   for (size_t i = 0; i < vt.size(); i++) vt[i] = VEntry{lm->vkeys[i], lm->vvals[i], 0u};
   bool ok = (!sig_ok || up((void**)&lm->d_ngs, ngs.data(), ngs.size() * sizeof(NgSig))) &&
             up((void**)&lm->d_vt, vt.data(), vt.size() * sizeof(VEntry)) &&
+            up((void**)&lm->d_uni, uni.data(), uni.size() * sizeof(UniEntry)) &&
             up((void**)&lm->d_vkeys, lm->vkeys.data(), lm->vkeys.size() * sizeof(uint64_t)) &&
             up((void**)&lm->d_vvals, lm->vvals.data(), lm->vvals.size() * sizeof(uint32_t)) &&
             up((void**)&lm->d_ng, lm->ng.data(), lm->ng.size() * sizeof(NgSlot)) &&
@@ -308,9 +342,9 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
     // no usable GPU: keep the host tables (e2e_lm_word_index / e2e_lm_score still work); e2e_ctc_beam refuses it
     (void)hipGetLastError();
     (void)hipFree(lm->d_vkeys); (void)hipFree(lm->d_vvals); (void)hipFree(lm->d_ng);
-    (void)hipFree(lm->d_label_bytes); (void)hipFree(lm->d_label_off); (void)hipFree(lm->d_ngs); (void)hipFree(lm->d_vt);
+    (void)hipFree(lm->d_label_bytes); (void)hipFree(lm->d_label_off); (void)hipFree(lm->d_ngs); (void)hipFree(lm->d_vt); (void)hipFree(lm->d_uni);
     lm->d_vkeys = nullptr; lm->d_vvals = nullptr; lm->d_ng = nullptr; lm->d_label_bytes = nullptr; lm->d_label_off = nullptr;
-    lm->d_ngs = nullptr; lm->d_vt = nullptr;
+    lm->d_ngs = nullptr; lm->d_vt = nullptr; lm->d_uni = nullptr;
   } else if (hipGetDevice(&lm->device) != hipSuccess) {
     lm->device = -1;
   }
@@ -321,7 +355,7 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
 extern "C" void e2e_lm_free(e2e_lm* lm) {
   if (!lm) return;
   (void)hipFree(lm->d_vkeys); (void)hipFree(lm->d_vvals); (void)hipFree(lm->d_ng);
-  (void)hipFree(lm->d_label_bytes); (void)hipFree(lm->d_label_off); (void)hipFree(lm->d_ngs); (void)hipFree(lm->d_vt);
+  (void)hipFree(lm->d_label_bytes); (void)hipFree(lm->d_label_off); (void)hipFree(lm->d_ngs); (void)hipFree(lm->d_vt); (void)hipFree(lm->d_uni);
   delete lm;
 }
 
@@ -437,9 +471,12 @@ __device__ __forceinline__ unsigned long long okey(double d) {
 // (global memory, several dependent probes) for every pair of every step.
 struct LmAnswer { float sc; uint32_t wi; };
 // (LabelTab: the labels' spellings, staged in LDS by the kernel when they fit -- two dependent global loads less per query)
-struct LabelTab { const int* off; const unsigned char* bytes; };
+// (one: LDS, per label its byte -- case already folded -- if it is spelled with exactly one, else -1; null when not staged.
+//  The usual alphabet: one LDS read instead of three dependent loads through generic pointers.)
+struct LabelTab { const int* off; const unsigned char* bytes; const int* one; };
 constexpr int kLabelLdsBytes = 512;
 __device__ __forceinline__ unsigned long long spell(const BeamParams& p, const LabelTab& lt, unsigned long long h, int c) {
+  if (lt.one) { const int o = lt.one[c]; if (o >= 0) return fnv_step(h, (unsigned char)o); }
   for (int bi = lt.off[c]; bi < lt.off[c + 1]; bi++) {
     unsigned char ch = lt.bytes[bi];
     if (p.lm.fold_case && ch >= 'A' && ch <= 'Z') ch += 32;
@@ -447,40 +484,77 @@ __device__ __forceinline__ unsigned long long spell(const BeamParams& p, const L
   }
   return h;
 }
-// lm_base_score for contexts of up to kParCtx words with every table probe of the back-off chain in flight at once:
-// the (k+1)-grams (ctx[k-1..0], word) and the context k-grams whose back-off weights the chain may need are hashed
-// first and then probed in ROUNDS -- every lookup that is still open requests its next slot before any answer is
-// consumed -- so a query costs as many memory round trips as its longest probe sequence, not the sum over the chain
-// (which, with 64 lanes waiting for the slowest at every one of up to 2n+1 lookups, was ~20 round trips).  The
-// answers are combined in the chain's order (same float additions).
+// lm_base_score for contexts of up to kParCtx words in two rounds of table probes.  Round 1 (issued by the caller beside the
+// vocabulary probe, which it does not depend on): the context k-grams -- their back-off weights and continuation bits.
+// Round 2, once the word is known: the unigram, and the (k+1)-grams (ctx[k-1..0], word) whose context lists the word among
+// its continuations.  Within a round every lookup that is still open requests its next slot before any answer is consumed.
+// The answers are combined in the chain's order (same float additions as lm_base_score).
 constexpr int kParCtx = 2;
-__device__ __forceinline__ float lm_score_parallel(const LmView& lm, const uint32_t (&ctx)[kCtx], int n, uint32_t word) {
-  constexpr int NL = 2 * kParCtx + 1;             // lookups: full[0..kParCtx], then bo[1..kParCtx]
-  uint64_t h[NL];
-  uint32_t idx[NL];
-  NgSig e[NL];
-  unsigned open = 0, hit = 0;                     // bit per lookup: still probing / found
+struct LmContexts { float backoff[kParCtx + 1]; uint64_t cont[kParCtx + 1]; unsigned hit; uint64_t hp[kParCtx + 1]; };
+__device__ __forceinline__ void lm_contexts(const LmView& lm, const uint32_t (&ctx)[kCtx], int n, LmContexts& cx) {
+  const uint4* tab = reinterpret_cast<const uint4*>(lm.ngs);
+  uint64_t h[kParCtx + 1]; uint32_t idx[kParCtx + 1]; uint4 e[kParCtx + 1];
+  unsigned open = 0;
+  cx.hit = 0; cx.hp[0] = kFnvInit;
 #pragma unroll
-  for (int k = 0; k <= kParCtx; k++) {
+  for (int k = 1; k <= kParCtx; k++) {
     uint64_t hp = kFnvInit;
 #pragma unroll
     for (int i = 0; i < k; i++) hp = ng_mix(hp, ctx[k - 1 - i]);
-    h[k] = ng_finish(ng_mix(hp, word), k + 1);
-    if (k <= n) open |= 1u << k;
-    if (k >= 1) { h[kParCtx + k] = ng_finish(hp, k); if (k <= n) open |= 1u << (kParCtx + k); }
+    cx.hp[k] = hp;
+    h[k] = ng_finish(hp, k);
+    idx[k] = (uint32_t)h[k] & lm.ngmask;
+    cx.backoff[k] = 0.f; cx.cont[k] = 0;
+    if (k >= 2 && k <= n) { open |= 1u << k; e[k] = tab[2 * (size_t)idx[k]]; }
   }
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    idx[l] = (uint32_t)h[l] & lm.ngmask;
-    if (open >> l & 1u) e[l] = lm.ngs[idx[l]];
+  if (n >= 1) {                                   // the one-word context: the unigram entry itself
+    const uint4 u = reinterpret_cast<const uint4*>(lm.uni)[ctx[0] < lm.nwords ? ctx[0] : 0];
+    if (__uint_as_float(u.x) <= 0.f && ctx[0] < lm.nwords) {
+      cx.hit |= 2u; cx.backoff[1] = __uint_as_float(u.y); cx.cont[1] = ((uint64_t)u.w << 32) | u.z;
+    }
   }
   while (open) {
 #pragma unroll
-    for (int l = 0; l < NL; l++) {
-      if (open >> l & 1u) {
-        if (e[l].sig == h[l]) { hit |= 1u << l; open &= ~(1u << l); }
-        else if (e[l].sig == 0) open &= ~(1u << l);
-        else { idx[l] = (idx[l] + 1) & lm.ngmask; e[l] = lm.ngs[idx[l]]; }
+    for (int k = 2; k <= kParCtx; k++) {
+      if (open >> k & 1u) {
+        const uint64_t sig = ((uint64_t)e[k].y << 32) | e[k].x;
+        if (sig == h[k]) {
+          cx.hit |= 1u << k; open &= ~(1u << k);
+          cx.backoff[k] = __uint_as_float(e[k].w);
+          const uint4 c = tab[2 * (size_t)idx[k] + 1];                  // (same cache line as the slot's first half)
+          cx.cont[k] = ((uint64_t)c.y << 32) | c.x;
+        } else if (sig == 0) open &= ~(1u << k);
+        else { idx[k] = (idx[k] + 1) & lm.ngmask; e[k] = tab[2 * (size_t)idx[k]]; }
+      }
+    }
+  }
+}
+__device__ __forceinline__ float lm_score_parallel(const LmView& lm, const LmContexts& cx, int n, uint32_t word) {
+  const uint4* tab = reinterpret_cast<const uint4*>(lm.ngs);
+  uint64_t h[kParCtx + 1]; uint32_t idx[kParCtx + 1]; uint4 e[kParCtx + 1];
+  float prob[kParCtx + 1];
+  unsigned open = 0, hit = 0;
+  const int bit = cont_bit(word);
+#pragma unroll
+  for (int k = 0; k <= kParCtx; k++) {
+    h[k] = ng_finish(ng_mix(cx.hp[k], word), k + 1);
+    idx[k] = (uint32_t)h[k] & lm.ngmask;
+    prob[k] = 0.f;
+    // (only if the context is listed and lists the word among its continuations)
+    if (k >= 1 && k <= n && (cx.hit >> k & 1u) && (cx.cont[k] >> bit & 1ULL)) { open |= 1u << k; e[k] = tab[2 * (size_t)idx[k]]; }
+  }
+  {
+    const uint4 u = reinterpret_cast<const uint4*>(lm.uni)[word < lm.nwords ? word : 0];
+    if (__uint_as_float(u.x) <= 0.f && word < lm.nwords) { hit |= 1u; prob[0] = __uint_as_float(u.x); }
+  }
+  while (open) {
+#pragma unroll
+    for (int k = 1; k <= kParCtx; k++) {
+      if (open >> k & 1u) {
+        const uint64_t sig = ((uint64_t)e[k].y << 32) | e[k].x;
+        if (sig == h[k]) { hit |= 1u << k; open &= ~(1u << k); prob[k] = __uint_as_float(e[k].z); }
+        else if (sig == 0) open &= ~(1u << k);
+        else { idx[k] = (idx[k] + 1) & lm.ngmask; e[k] = tab[2 * (size_t)idx[k]]; }
       }
     }
   }
@@ -489,10 +563,10 @@ __device__ __forceinline__ float lm_score_parallel(const LmView& lm, const uint3
   float result = lm.unk_prob;
 #pragma unroll
   for (int k = 0; k <= kParCtx; k++)
-    if (k <= n && (hit >> k & 1u)) { result = e[k].prob; found_k = k; }
+    if (k <= n && (hit >> k & 1u)) { result = prob[k]; found_k = k; }
 #pragma unroll
   for (int k = 1; k <= kParCtx; k++)
-    if (k > found_k && k <= n && (hit >> (kParCtx + k) & 1u)) result += e[kParCtx + k].backoff;
+    if (k > found_k && k <= n && (cx.hit >> k & 1u)) result += cx.backoff[k];
   return result;
 }
 // FAST: the model has signature tables and at most kParCtx words of context (checked by the host): only the round-probed
@@ -502,20 +576,27 @@ __device__ __forceinline__ LmAnswer lm_query(const BeamParams& p, const LabelTab
   const bool new_word = pr.num_words == 0 || parent_last == p.space_id;                           // :258-259 (c != space)
   LmAnswer a;
   uint64_t h = spell(p, lt, new_word ? kFnvInit : pr.word_hash, c);
+
   int cn = new_word ? pr.st_n : pr.stb_n;
   if (FAST) {
     uint32_t ctx[kCtx];
 #pragma unroll
     for (int s2 = 0; s2 < kCtx; s2++) ctx[s2] = new_word ? pr.st[s2] : pr.stb[s2];
     if (h == 0) h = 1;
-    a.wi = 0;
-    for (uint32_t i = (uint32_t)h & p.lm.vmask;; i = (i + 1) & p.lm.vmask) {
-      const VEntry e = p.lm.vt[i];
-      if (e.key == h) { a.wi = e.val; break; }
-      if (e.key == 0) break;                      // NotFound() == <unk> == 0
-    }
     if (cn > p.lm.order - 1) cn = p.lm.order - 1;
-    a.sc = lm_score_parallel(p.lm, ctx, cn, a.wi);
+    a.wi = 0;
+    uint32_t vi = (uint32_t)h & p.lm.vmask;
+    uint4 ve = reinterpret_cast<const uint4*>(p.lm.vt)[vi];          // (in flight beside the context lookups)
+    LmContexts cx;
+    lm_contexts(p.lm, ctx, cn, cx);
+    for (;;) {
+      const uint64_t key = ((uint64_t)ve.y << 32) | ve.x;
+      if (key == h) { a.wi = ve.z; break; }
+      if (key == 0) break;                        // NotFound() == <unk> == 0
+      vi = (vi + 1) & p.lm.vmask;
+      ve = reinterpret_cast<const uint4*>(p.lm.vt)[vi];
+    }
+    a.sc = lm_score_parallel(p.lm, cx, cn, a.wi);
   } else {
     a.wi = lm_word_lookup(p.lm, h);
     a.sc = lm_base_score(p.lm, new_word ? pr.st : pr.stb, cn, a.wi, nullptr, nullptr);
@@ -633,7 +714,7 @@ struct BeamLds {
   static size_t bytes(int W, int V, int CMAX, int WP2, int HS, bool lm) {
     return sizeof(double) * ((size_t)CMAX + 2 * V + WP2 + kSelSmall) +
            sizeof(int) * ((size_t)WP2 + kSelSmall + 2 * (size_t)W * V + 2 * kSelBins + 64 + 4 * (size_t)HS) +
-           2 * Members::bytes(W) + (lm ? 2 * sizeof(LmAnswer) * (size_t)W * V + sizeof(int) * (size_t)(V + 2) + kLabelLdsBytes : 0) + 64;
+           2 * Members::bytes(W) + (lm ? 2 * sizeof(LmAnswer) * (size_t)W * V + sizeof(int) * (size_t)(2 * V + 2) + kLabelLdsBytes : 0) + 64;
   }
 };
 
@@ -699,7 +780,8 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
   LmAnswer* const lmc0 = (LmAnswer*)q8; if (LM) q8 += 2 * sizeof(LmAnswer) * (size_t)W * V;   // [set][member][V] the LM's answers
   int* const lab_off = (int*)q8; if (LM) q8 += sizeof(int) * (size_t)(V + 2);
   unsigned char* const lab_bytes = q8; if (LM) q8 += kLabelLdsBytes;
-  LabelTab lt; lt.off = p.lm.label_off; lt.bytes = p.lm.label_bytes;
+  int* const lab_one = (int*)q8; if (LM) q8 += sizeof(int) * (size_t)V;
+  LabelTab lt; lt.off = p.lm.label_off; lt.bytes = p.lm.label_bytes; lt.one = nullptr;
   auto slot_map = [&](int set) { SlotMap m; m.key = sm0 + set * 2 * p.HS; m.val = m.key + p.HS; m.mask = p.HS - 1; return m; };
   __shared__ int s_next_node, s_err, s_krem, s_done, s_bin;
   // per-step accumulators, double-buffered by step parity: a step resets the NEXT step's set while nobody uses it, so
@@ -724,6 +806,16 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       for (int i = tid; i < nbytes; i += kThreads) lab_bytes[i] = p.lm.label_bytes[i];
       lt.off = lab_off; lt.bytes = lab_bytes;
     }
+    for (int c = tid; c < V; c += kThreads) {
+      const int o0 = p.lm.label_off[c];
+      int ch = -1;
+      if (p.lm.label_off[c + 1] == o0 + 1) {
+        ch = p.lm.label_bytes[o0];
+        if (p.lm.fold_case && ch >= 'A' && ch <= 'Z') ch += 32;
+      }
+      lab_one[c] = ch;
+    }
+    lt.one = lab_one;
   }
   if (tid == 0) {
     s_next_node = 1; s_err = 0;                                                     // node 0 is taken
@@ -1263,7 +1355,7 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
   __shared__ unsigned s_fmax, s_ckey;
   __shared__ unsigned s_hi, s_lo;
   __shared__ unsigned long long s_prefix;
-  LabelTab lt; lt.off = p.lm.label_off; lt.bytes = p.lm.label_bytes;
+  LabelTab lt; lt.off = p.lm.label_off; lt.bytes = p.lm.label_bytes; lt.one = nullptr;
 
   BeamNode* nodes = p.nodes + (size_t)b * p.NCAP;
   const IO* lp = reinterpret_cast<const IO*>(p.lp) + (int64_t)b * p.sB;
