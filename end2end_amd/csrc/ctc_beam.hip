@@ -972,21 +972,20 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     int* const tval = hist + 2 * kStateSlots;
     // candidate d takes place j of the new beam (the other member set): a member that stays is copied, a pair becomes a
     // prefix -- node, LM state, its own guard.  Called by the thread that has just worked out the candidate's rank.
-    auto place = [&](int j, int d) {
+    // ... in two halves that touch different fields of the new member: what the lattice needs (probabilities, node, guard,
+    // slot map) and the LM state -- with a language model they run on different waves (below).
+    auto place_core = [&](int j, int d) {
       if (d < n) {
         const int i = d;
         A.kept[i] = 1; A.newpos[i] = j; Bm.from[j] = i;
         Bm.ppb[j] = A.npb[i]; Bm.ppnb[j] = A.npnb[i]; Bm.full[j] = A.nfull[i];
-        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i]; copy_lm<LM>(Bm.lm[j], A.lm[i]);
+        Bm.node[j] = A.node[i]; Bm.last[j] = A.last[i];
         Bm.gown[j] = A.gown[i]; Bm.gchar[j] = A.gchar[i]; Bm.gnode[j] = A.gnode[i];     // (owner: position in A, for now)
         mapB.insert(A.node[i], j);
       } else {
         const int q = d - n;
         const int c = q / n, i = q - c * n;
         const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : A.full[i]);
-        LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
-        if (LM) ans = lmcA[i * V + c];
-        child_lm<LM>(p, lt, A.lm[i], A.last[i], c, ans, Bm.lm[j]);                 // (straight into LDS: a local LmFields lives in scratch)
         int k = atomicAdd(&s_next_node, 1);                                       // make_shared<Prefix>, :254
         if (k >= p.NCAP) { s_err = 1; k = 0; }
         else {
@@ -1000,6 +999,18 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         Bm.from[j] = -1;
       }
     };
+    auto place_lm = [&](int j, int d) {
+      if (d < n) {
+        copy_lm<LM>(Bm.lm[j], A.lm[d]);
+      } else {
+        const int q = d - n;
+        const int c = q / n, i = q - c * n;
+        LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
+        if (LM) ans = lmcA[i * V + c];
+        child_lm<LM>(p, lt, A.lm[i], A.last[i], c, ans, Bm.lm[j]);                 // (straight into LDS: a local LmFields lives in scratch)
+      }
+    };
+    auto place = [&](int j, int d) { place_core(j, d); place_lm(j, d); };
     if (nreal > W) {                                                             // :405-415
       // ---- radix select of the W-th largest score on the order-preserving 64-bit key, 11 bits per pass ----
       // Where to start: the threshold lies between the smallest score of a full beam's old members (W candidates are
@@ -1129,7 +1140,20 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
         cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
         cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x141, 0xf, 0xf, true);     // row_half_mirror: the other quad of the 8
-        if (e < M && part == 0 && cnt < W) place(cnt, sidx[e]);     // (no list of the selected in between: the ranking thread builds the member)
+        if (e < M && part == 0 && cnt < W) sel[cnt] = sidx[e];
+      }
+      // The members are built by W threads on two waves, not by the ranking threads (one lane in eight of all sixteen waves:
+      // every wave walked the whole of place() -- with a language model some 400 instructions -- for eight useful lanes,
+      // and the phase was bound by the instructions the four SIMDs had to issue).
+      lds_barrier();
+      if (LM) {
+        // blocks of 128 threads alternate between the two halves: waves 0-1 the lattice half of members 0..127, waves 2-3
+        // their LM half, ...
+        const int blk = tid >> 7, j0 = (tid & 127) + 128 * (blk >> 1);
+        if (blk & 1) { for (int j = j0; j < nsel; j += kThreads / 2) place_lm(j, sel[j]); }
+        else { for (int j = j0; j < nsel; j += kThreads / 2) place_core(j, sel[j]); }
+      } else {
+        for (int j = tid; j < nsel; j += kThreads) place(j, sel[j]);
       }
     } else {
       // nothing is pruned (the first steps of an utterance): old members, then the pairs that exist, in order
@@ -1147,7 +1171,15 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         if (ukey[n + q] != kNoCandKey) sel[pos++] = n + q;
       if (LM) for (int h = tid; h < kStateSlots; h += kThreads) { tsig[h] = 0ULL; tval[h] = 0x7fffffff; }
       lds_barrier();
-      for (int j = tid; j < nsel; j += kThreads) place(j, sel[j]);
+      if (LM) {
+        // blocks of 128 threads alternate between the two halves: waves 0-1 the lattice half of members 0..127, waves 2-3
+        // their LM half, ...
+        const int blk = tid >> 7, j0 = (tid & 127) + 128 * (blk >> 1);
+        if (blk & 1) { for (int j = j0; j < nsel; j += kThreads / 2) place_lm(j, sel[j]); }
+        else { for (int j = j0; j < nsel; j += kThreads / 2) place_core(j, sel[j]); }
+      } else {
+        for (int j = tid; j < nsel; j += kThreads) place(j, sel[j]);
+      }
     }
     lds_barrier();
     BPROF(3);
@@ -1186,7 +1218,8 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         cn = nw ? m.st_n : m.stb_n;
         wh = nw ? 0ULL : m.word_hash;
       };
-      for (int j2 = tid; j2 < nsel; j2 += kThreads) {
+      // (on the threads next to the ones that walk the guards above: tid ^ 128 -- the two loops are independent)
+      for (int j2 = tid ^ 128; j2 < nsel; j2 += kThreads) {
         bool nw; int cn; unsigned long long wh;
         state_of(j2, nw, cn, wh);
         unsigned long long h = wh;
@@ -1224,13 +1257,14 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         }
         ldr[j2] = leader;
       }
-      lds_barrier();
-      BPROF(13);
-      for (int e = tid; e < nsel * V; e += kThreads) {
+      // (the rows of the members that stay do not wait for the leaders: the waves behind the first two copy them meanwhile)
+      for (int e = tid - 128; e >= 0 && e < nsel * V; e += kThreads - 128) {
         const int j2 = e / V;
         const int f = Bm.from[j2];
         if (f >= 0) lmcB[e] = lmcA[f * V + (e - j2 * V)];
       }
+      lds_barrier();
+      BPROF(13);
       const int nnew = s_nnew;
       for (int t2 = tid; t2 < nnew * V; t2 += kThreads) {
         const int r = t2 / V, c = t2 - r * V, j2 = newlist[r];
