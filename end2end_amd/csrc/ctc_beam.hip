@@ -63,7 +63,17 @@ struct NgSig {                                                   // sig 0: empty
 // KB that stay in L2, where the hashed table (megabytes, one slot per random line) is a trip past it for every probe.
 struct UniEntry { float prob; float backoff; uint64_t cont; };
 __host__ __device__ inline int cont_bit(uint32_t w) { return (int)(((uint64_t)w * 0x9E3779B97F4A7C15ULL) >> 58); }
-struct VEntry { uint64_t key; uint32_t val; uint32_t pad; };     // key 0: empty
+struct VEntry { uint64_t key; uint32_t val; float prob; };       // key 0: empty; prob: the word's unigram log10 p (> 0: none listed)
+// The kernel's vocabulary table is a TWO-CHOICE (cuckoo) table: a spelling sits in one of the two slots its hash names, so a
+// probe is two loads issued together and never a second round (with linear probing the slowest of a wave's 64 lanes needed
+// three).  It is small -- 64 bytes per word -- and stays in L2, where a second line per probe is cheap; the n-gram table is
+// not, and is not (two-choice there doubled the lines a step pulls from beyond L2: 21 900 against 12 000 cycles).
+__host__ __device__ inline void two_slots(uint64_t h, uint32_t mask, uint32_t& i1, uint32_t& i2) {
+  // (the second slot from a re-mixed hash: bits 32.. of an FNV hash of a short spelling are far from uniform -- 7 191
+  //  distinct values for the bench model's 10 003 words -- and cuckoo insertion then fails)
+  i1 = (uint32_t)h & mask; i2 = (uint32_t)((h * 0x9E3779B97F4A7C15ULL) >> 32) & mask;
+  if (i2 == i1) i2 = i1 ^ 1u;
+}
 
 struct LmView {                    // what the kernel sees (device pointers) / what the host scorer sees
   int order;
@@ -328,8 +338,27 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
     }
     if (!contexts_listed) { for (auto& e : ngs) e.cont = ~0ULL; for (auto& e : uni) e.cont = ~0ULL; }
   }
-  std::vector<VEntry> vt(lm->vkeys.size());
-  for (size_t i = 0; i < vt.size(); i++) vt[i] = VEntry{lm->vkeys[i], lm->vvals[i], 0u};
+  std::vector<VEntry> vt(lm->vkeys.size(), VEntry{0, 0u, 1.f});
+  for (size_t i = 0; i < lm->vkeys.size() && sig_ok; i++) {      // (one entry per distinct folded spelling already)
+    if (lm->vkeys[i] == 0) continue;
+    // cuckoo insertion: a free slot of the item's two, else evict the occupant of one and move that on
+    VEntry item{lm->vkeys[i], lm->vvals[i], uni[lm->vvals[i]].prob};
+    const uint32_t mask = (uint32_t)vt.size() - 1;
+    uint32_t i1, i2;
+    two_slots(item.key, mask, i1, i2);
+    if (vt[i1].key == 0) { vt[i1] = item; continue; }
+    if (vt[i2].key == 0) { vt[i2] = item; continue; }
+    uint32_t pos = i1;
+    bool placed = false;
+    for (int kick = 0; kick < 2000 && !placed; kick++) {
+      std::swap(item, vt[pos]);
+      if (item.key == 0) { placed = true; break; }
+      two_slots(item.key, mask, i1, i2);
+      pos = pos == i1 ? i2 : i1;
+    }
+    if (!placed) sig_ok = false;                                  // (never seen at load <= 1/4; the id-keyed walk takes over)
+  }
+  if (getenv("E2E_LM_DEBUG")) fprintf(stderr, "e2e_lm: %zu entries, %zu words, signature tables %s\n", entries.size(), words.size(), sig_ok ? "ok" : "NOT usable");
   bool ok = (!sig_ok || up((void**)&lm->d_ngs, ngs.data(), ngs.size() * sizeof(NgSig))) &&
             up((void**)&lm->d_vt, vt.data(), vt.size() * sizeof(VEntry)) &&
             up((void**)&lm->d_uni, uni.data(), uni.size() * sizeof(UniEntry)) &&
@@ -529,7 +558,7 @@ __device__ __forceinline__ void lm_contexts(const LmView& lm, const uint32_t (&c
     }
   }
 }
-__device__ __forceinline__ float lm_score_parallel(const LmView& lm, const LmContexts& cx, int n, uint32_t word) {
+__device__ __forceinline__ float lm_score_parallel(const LmView& lm, const LmContexts& cx, int n, uint32_t word, float uni_prob) {
   const uint4* tab = reinterpret_cast<const uint4*>(lm.ngs);
   uint64_t h[kParCtx + 1]; uint32_t idx[kParCtx + 1]; uint4 e[kParCtx + 1];
   float prob[kParCtx + 1];
@@ -543,10 +572,7 @@ __device__ __forceinline__ float lm_score_parallel(const LmView& lm, const LmCon
     // (only if the context is listed and lists the word among its continuations)
     if (k >= 1 && k <= n && (cx.hit >> k & 1u) && (cx.cont[k] >> bit & 1ULL)) { open |= 1u << k; e[k] = tab[2 * (size_t)idx[k]]; }
   }
-  {
-    const uint4 u = reinterpret_cast<const uint4*>(lm.uni)[word < lm.nwords ? word : 0];
-    if (__uint_as_float(u.x) <= 0.f && word < lm.nwords) { hit |= 1u; prob[0] = __uint_as_float(u.x); }
-  }
+  if (uni_prob <= 0.f) { hit |= 1u; prob[0] = uni_prob; }          // (the unigram came with the vocabulary entry)
   while (open) {
 #pragma unroll
     for (int k = 1; k <= kParCtx; k++) {
@@ -584,19 +610,15 @@ __device__ __forceinline__ LmAnswer lm_query(const BeamParams& p, const LabelTab
     for (int s2 = 0; s2 < kCtx; s2++) ctx[s2] = new_word ? pr.st[s2] : pr.stb[s2];
     if (h == 0) h = 1;
     if (cn > p.lm.order - 1) cn = p.lm.order - 1;
-    a.wi = 0;
-    uint32_t vi = (uint32_t)h & p.lm.vmask;
-    uint4 ve = reinterpret_cast<const uint4*>(p.lm.vt)[vi];          // (in flight beside the context lookups)
+    uint32_t v1, v2;
+    two_slots(h, p.lm.vmask, v1, v2);
+    const uint4 e1 = reinterpret_cast<const uint4*>(p.lm.vt)[v1], e2 = reinterpret_cast<const uint4*>(p.lm.vt)[v2];   // (in flight beside the context lookups)
     LmContexts cx;
     lm_contexts(p.lm, ctx, cn, cx);
-    for (;;) {
-      const uint64_t key = ((uint64_t)ve.y << 32) | ve.x;
-      if (key == h) { a.wi = ve.z; break; }
-      if (key == 0) break;                        // NotFound() == <unk> == 0
-      vi = (vi + 1) & p.lm.vmask;
-      ve = reinterpret_cast<const uint4*>(p.lm.vt)[vi];
-    }
-    a.sc = lm_score_parallel(p.lm, cx, cn, a.wi);
+    const bool in1 = (((uint64_t)e1.y << 32) | e1.x) == h, in2 = (((uint64_t)e2.y << 32) | e2.x) == h;
+    a.wi = in1 ? e1.z : in2 ? e2.z : 0u;                             // NotFound() == <unk> == 0
+    const float uni_prob = in1 ? __uint_as_float(e1.w) : in2 ? __uint_as_float(e2.w) : p.lm.unk_prob;
+    a.sc = lm_score_parallel(p.lm, cx, cn, a.wi, uni_prob);
   } else {
     a.wi = lm_word_lookup(p.lm, h);
     a.sc = lm_base_score(p.lm, new_word ? pr.st : pr.stb, cn, a.wi, nullptr, nullptr);
