@@ -66,8 +66,8 @@ __host__ __device__ inline int cont_bit(uint32_t w) { return (int)(((uint64_t)w 
 struct VEntry { uint64_t key; uint32_t val; float prob; };       // key 0: empty; prob: the word's unigram log10 p (> 0: none listed)
 // The kernel's vocabulary table is a TWO-CHOICE (cuckoo) table: a spelling sits in one of the two slots its hash names, so a
 // probe is two loads issued together and never a second round (with linear probing the slowest of a wave's 64 lanes needed
-// three).  It is small -- 64 bytes per word -- and stays in L2, where a second line per probe is cheap; the n-gram table is
-// not, and is not (two-choice there doubled the lines a step pulls from beyond L2: 21 900 against 12 000 cycles).
+// three).  It is small -- 64 bytes per word -- and stays in L2, where a second line per probe is cheap.  (The n-gram table
+// keeps linear probing: since the continuation bits its probes are rare or shared by a state's characters.)
 __host__ __device__ inline void two_slots(uint64_t h, uint32_t mask, uint32_t& i1, uint32_t& i2) {
   // (the second slot from a re-mixed hash: bits 32.. of an FNV hash of a short spelling are far from uniform -- 7 191
   //  distinct values for the bench model's 10 003 words -- and cuckoo insertion then fails)
