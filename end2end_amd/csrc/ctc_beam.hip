@@ -989,9 +989,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     // the candidate keys)
     int* const newlist = sidx;                                                        // new members that have to ask
     int* const ldr = reinterpret_cast<int*>(skey);                                    // leader of member j
-    unsigned long long* const sg = reinterpret_cast<unsigned long long*>(key);        // state signature of member j
     unsigned long long* const tsig = reinterpret_cast<unsigned long long*>(hist);     // open addressing: signature -> smallest rank
-    int* const tval = hist + 2 * kStateSlots;
     // candidate d takes place j of the new beam (the other member set): a member that stays is copied, a pair becomes a
     // prefix -- node, LM state, its own guard.  Called by the thread that has just worked out the candidate's rank.
     // ... in two halves that touch different fields of the new member: what the lattice needs (probabilities, node, guard,
@@ -1145,7 +1143,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       BPROF(8);
       // ---- rank the gathered candidates by (score desc, position asc): eight lanes count for one candidate; rank < W
       //      is the candidate's place in the new beam (the surplus of a small threshold bin falls off the end) ----
-      if (LM) for (int h = tid; h < kStateSlots; h += kThreads) { tsig[h] = 0ULL; tval[h] = 0x7fffffff; }
+      if (LM) for (int h = tid; h < kStateSlots; h += kThreads) tsig[h] = 0ULL;
       for (int e0 = 0; e0 < M; e0 += kThreads / 8) {
         const int e = e0 + (tid >> 3), part = tid & 7;
         int cnt = 0;
@@ -1191,7 +1189,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       for (int w = 0; w < wid; w++) pos += s_part[w];
       for (int q = q0; q < q1; q++)
         if (ukey[n + q] != kNoCandKey) sel[pos++] = n + q;
-      if (LM) for (int h = tid; h < kStateSlots; h += kThreads) { tsig[h] = 0ULL; tval[h] = 0x7fffffff; }
+      if (LM) for (int h = tid; h < kStateSlots; h += kThreads) tsig[h] = 0ULL;
       lds_barrier();
       if (LM) {
         // blocks of 128 threads alternate between the two halves: waves 0-1 the lattice half of members 0..127, waves 2-3
@@ -1228,11 +1226,10 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       // a word starts), and most new members share theirs with another member: prefixes that differ further back than
       // the model looks (measured: 70 new members per step, 22 distinct states).  A wave walks the whole query code as
       // soon as one of its lanes has a query, so the queries are packed: one (asking member, character) per thread.
-      //   1. every member enters its state's signature into a small hash table, keeping the smallest rank per state
-      //      (members that stay rank before new ones: their answers are already there);
-      //   2. a new member looks its state up; if the holder really has the same state (the signature is a filter) it
-      //      follows the holder, else it asks itself and joins the packed list;
-      //   3. rows are copied (staying members) / asked (list);  4. followers copy their leader's row.
+      //   1. every member looks its state's signature up in a small hash table: a member that stays enters itself (its
+      //      answers are already there), a new member follows the holder if there is one and it really has the same state
+      //      (the signature is a filter), else it enters itself, asks, and joins the packed list;
+      //   2. rows are copied (staying members) / asked (list);  3. followers copy their leader's row.
       BPROF(11);
       auto state_of = [&](int j2, bool& nw, int& cn, unsigned long long& wh) {
         const LmFields& m = Bm.lm[j2];
@@ -1240,47 +1237,45 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         cn = nw ? m.st_n : m.stb_n;
         wh = nw ? 0ULL : m.word_hash;
       };
-      // (on the threads next to the ones that walk the guards above: tid ^ 128 -- the two loops are independent)
+      // One pass, on the threads next to the ones that walk the guards above (tid ^ 128: the two loops are independent).  A
+      // table word is the state's signature with the holder's position in its low 12 bits.  A member that stays makes
+      // itself the holder (smallest position wins); a new member takes a free word -- it is then the one that asks -- or
+      // finds a holder and, if that really has the same state, follows it.  Whoever holds a state when a new member comes
+      // by will have its row in time (copied below, or asked in the next phase); which of several equal-state members
+      // that is changes nothing but who asks.
       for (int j2 = tid ^ 128; j2 < nsel; j2 += kThreads) {
         bool nw; int cn; unsigned long long wh;
         state_of(j2, nw, cn, wh);
         unsigned long long h = wh;
         for (int q2 = 0; q2 < cn; q2++) h = ng_mix(h, nw ? Bm.lm[j2].st[q2] : Bm.lm[j2].stb[q2]);
         h = ng_mix(h, (uint32_t)cn + (nw ? 100u : 0u));
-        if (h == 0) h = 1;
-        sg[j2] = h;
-        const int rank = Bm.from[j2] >= 0 ? j2 : j2 + 4096;
-        for (unsigned sl = (unsigned)(h >> 20) & (kStateSlots - 1);; sl = (sl + 1) & (kStateSlots - 1)) {
-          const unsigned long long old = atomicCAS(&tsig[sl], 0ULL, h);
-          if (old == 0ULL || old == h) { atomicMin(&tval[sl], rank); break; }
-        }
-      }
-      lds_barrier();
-      BPROF(12);
-      for (int j2 = tid; j2 < nsel; j2 += kThreads) {
+        unsigned long long hk = h & ~0xFFFULL;
+        if (hk == 0) hk = 0x1000ULL;
+        const bool stays = Bm.from[j2] >= 0;
         int leader = j2;
-        if (Bm.from[j2] < 0) {
-          const unsigned long long h = sg[j2];
-          unsigned sl = (unsigned)(h >> 20) & (kStateSlots - 1);
-          while (tsig[sl] != h) sl = (sl + 1) & (kStateSlots - 1);
-          const int o = tval[sl] & 4095;
-          if (o != j2) {
-            bool nw, nw2; int cn, cn2; unsigned long long wh, wh2;
-            state_of(j2, nw, cn, wh); state_of(o, nw2, cn2, wh2);
-            bool same = nw2 == nw && cn2 == cn && wh2 == wh;
-            for (int q2 = 0; q2 < cn && same; q2++)
-              same = (nw ? Bm.lm[o].st[q2] : Bm.lm[o].stb[q2]) == (nw ? Bm.lm[j2].st[q2] : Bm.lm[j2].stb[q2]);
-            if (same) leader = o;
-          }
-          if (leader == j2) newlist[atomicAdd(&s_nnew, 1)] = j2;
+        for (unsigned sl = (unsigned)(h >> 20) & (kStateSlots - 1);; sl = (sl + 1) & (kStateSlots - 1)) {
+          const unsigned long long old = atomicCAS(&tsig[sl], 0ULL, hk | (unsigned long long)j2);
+          if (old == 0ULL) break;                              // the word is this member's
+          if ((old & ~0xFFFULL) != hk) continue;
+          if (stays) { atomicMin(&tsig[sl], hk | (unsigned long long)j2); break; }
+          const int o = (int)(old & 0xFFFULL);
+          bool nw2; int cn2; unsigned long long wh2;
+          state_of(o, nw2, cn2, wh2);
+          bool same = nw2 == nw && cn2 == cn && wh2 == wh;
+          for (int q2 = 0; q2 < cn && same; q2++)
+            same = (nw ? Bm.lm[o].st[q2] : Bm.lm[o].stb[q2]) == (nw ? Bm.lm[j2].st[q2] : Bm.lm[j2].stb[q2]);
+          if (same) { leader = o; break; }                    // (else: another state behind the same signature bits -- next word)
+        }
+        if (!stays && leader == j2) {
+          newlist[atomicAdd(&s_nnew, 1)] = j2;
 #ifdef E2E_BEAM_PROFILE
-          if (leader == j2 && b == 0) { const int q9 = atomicAdd(&g_beam_nsig, 1); if (q9 < (1 << 17)) g_beam_sigs[q9] = sg[j2]; }
+          if (b == 0) { const int q9 = atomicAdd(&g_beam_nsig, 1); if (q9 < (1 << 17)) g_beam_sigs[q9] = h; }
 #endif
         }
         ldr[j2] = leader;
       }
-      // (the rows of the members that stay do not wait for the leaders: the waves behind the first two copy them meanwhile)
-      for (int e = tid - 128; e >= 0 && e < nsel * V; e += kThreads - 128) {
+      // (the rows of the members that stay: the waves behind those two copy them meanwhile)
+      for (int e = tid - 256; e >= 0 && e < nsel * V; e += kThreads - 256) {
         const int j2 = e / V;
         const int f = Bm.from[j2];
         if (f >= 0) lmcB[e] = lmcA[f * V + (e - j2 * V)];
