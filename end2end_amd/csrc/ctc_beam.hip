@@ -358,6 +358,36 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
     }
     if (!placed) sig_ok = false;                                  // (never seen at load <= 1/4; the id-keyed walk takes over)
   }
+  // Self-check of what the kernel will read, against the id tables it stands for: every spelling is found in one of its two
+  // vocabulary slots with the right id and unigram; every listed n-gram is found by its signature with the right numbers and
+  // its context lists its last word.  (What is NOT listed can only cost a wasted lookup: the filters have no false negatives.)
+  if (sig_ok) {
+    const uint32_t vmask2 = (uint32_t)vt.size() - 1;
+    for (size_t i = 0; i < lm->vkeys.size() && sig_ok; i++) {
+      if (lm->vkeys[i] == 0) continue;
+      uint32_t i1, i2;
+      two_slots(lm->vkeys[i], vmask2, i1, i2);
+      const VEntry* e = vt[i1].key == lm->vkeys[i] ? &vt[i1] : vt[i2].key == lm->vkeys[i] ? &vt[i2] : nullptr;
+      sig_ok = e && e->val == lm->vvals[i] && e->prob == uni[e->val].prob;
+    }
+    const LmView hv = lm->host_view();
+    for (size_t i = 0; i < lm->ng.size() && sig_ok; i++) {
+      const NgSlot& sl = lm->ng[i];
+      if (sl.n == 0) continue;
+      const uint64_t sig = ngram_hash(sl.ids, sl.n);
+      uint32_t j = (uint32_t)sig & ngmask;
+      while (ngs[j].sig != sig && ngs[j].sig != 0) j = (j + 1) & ngmask;
+      sig_ok = ngs[j].sig == sig && ngs[j].prob == sl.prob && ngs[j].backoff == sl.backoff;
+      if (sig_ok && sl.n == 1) sig_ok = uni[sl.ids[0]].prob == sl.prob && uni[sl.ids[0]].backoff == sl.backoff;
+      if (sig_ok && sl.n >= 2) {
+        const uint64_t bit = 1ULL << cont_bit(sl.ids[sl.n - 1]);
+        const NgSlot* c = lm_ngram_find(hv, sl.ids, sl.n - 1);
+        const uint64_t cont = sl.n == 2 ? uni[sl.ids[0]].cont : (c ? ngs[(size_t)(c - lm->ng.data())].cont : ~0ULL);
+        sig_ok = (cont & bit) != 0;
+      }
+    }
+    if (!sig_ok) fprintf(stderr, "e2e_lm: the kernel's tables failed their self-check; using the id tables (slower)\n");
+  }
   if (getenv("E2E_LM_DEBUG")) fprintf(stderr, "e2e_lm: %zu entries, %zu words, signature tables %s\n", entries.size(), words.size(), sig_ok ? "ok" : "NOT usable");
   bool ok = (!sig_ok || up((void**)&lm->d_ngs, ngs.data(), ngs.size() * sizeof(NgSig))) &&
             up((void**)&lm->d_vt, vt.data(), vt.size() * sizeof(VEntry)) &&

@@ -190,3 +190,24 @@ def test_workspace_of_the_headline_shape_stays_under_200_megabytes():
     # and it no longer grows with the batch beyond the fast path's own share
     n4 = L.e2e_ctc_loss_workspace_bytes(1024, 1000, 29, 200, _lib.F32, _lib.ALGO_AUTO)
     assert n4 - n < 3.2 * (n - 77e6), (n, n4)
+
+
+def test_language_model_kernel_tables_pass_their_self_check(tmp_path):
+    """The loader builds what the beam kernel reads -- a two-choice vocabulary table carrying each word's unigram, a
+    direct-indexed unigram array, hashed n-gram signatures with continuation bits -- and checks all of it against the id
+    tables (every spelling found with its id, every listed n-gram found with its numbers, every context listing its
+    continuations) before using it; a failed check (or a failed cuckoo insertion) falls back to the id tables.  Runs on the
+    host: no GPU needed."""
+    import bench
+    labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
+    big = str(tmp_path / "synthetic.arpa")
+    bench.synthetic_arpa(big, labels, n_words=20000, seed=5)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from end2end_amd.engines import LanguageModel\n"
+            "for path, cs in ((%r, False), (%r, True), (%r, False)):\n"
+            "    lm = LanguageModel(path, %r, cs)\n"
+            "    assert lm.order() == 3\n") % (ROOT, big, big, os.path.join(ROOT, "tests", "golden", "tiny_3gram.arpa"), labels)
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, "E2E_LM_DEBUG": "1"})
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stderr.splitlines() if l.startswith("e2e_lm:")]
+    assert len(lines) == 3 and all(l.endswith("signature tables ok") for l in lines), r.stderr
