@@ -11,7 +11,7 @@ files=${@:-ctc_loss_fast.hip}
 objs=
 for f in *.hip; do
   if [[ " $files " == *" $f "* ]]; then
-    extra=; [ $f = ctc_loss_fast.hip ] && extra=-fno-slp-vectorize
+    extra=; [[ $f == ctc_loss_fast*.hip ]] && extra=-fno-slp-vectorize
     /opt/rocm/bin/hipcc $extra -O3 -std=c++17 -fPIC --offload-arch=gfx950 $defs -ffp-contract=off -c $f -o /tmp/e2e_var_$name/${f%.hip}.o &
     objs="$objs /tmp/e2e_var_$name/${f%.hip}.o"
   else objs="$objs ${f%.hip}.o"; fi
