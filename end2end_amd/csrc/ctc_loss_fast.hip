@@ -800,6 +800,9 @@ constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before 
 #else
 #define F2_LDS_ORDER asm volatile("" ::: "memory");
 #endif
+#ifndef E2E_F2_HALF                 // four pairs per lane: keep eight of the segment's alpha rows and compute the other eight twice
+#define E2E_F2_HALF 1
+#endif
 #ifndef E2E_SMIN                    // (both overridable for tools/diag experiments)
 #define E2E_SMIN 0x1p-120f         // smallest row sum sum_j alpha*beta the gradient rows are trusted with
 #endif
@@ -1260,19 +1263,27 @@ __device__ __forceinline__ void segment_body_pk(const FastParams& p, int b, int 
   };
 
   // ---- alpha rows of the segment, kept in registers ----
-  h_f2 ABA[kSeg], ALA[kSeg], ABB[kSeg], ALB[kSeg];
+  // E2E_F2_HALF: only the eight rows of the half that beta is walking are kept -- the sweep below keeps rows 8..15, and rows
+  // 0..7 are computed a second time before beta reaches them: 64 registers less (three waves per SIMD) for 8 more alpha steps
+  constexpr int kKeep = E2E_F2_HALF ? kHalf : kSeg;
+  h_f2 ABA[kKeep], ALA[kKeep], ABB[kKeep], ALB[kKeep];
   h_f2 BA = {0.f, 0.f}, LA = {0.f, 0.f}, BB = {0.f, 0.f}, LB = {0.f, 0.f};
-  int eA = 0;
+  int eA = 0, shA = 0;
   if (seg != 0) {
     const int own = in.ownA;
     const bool nz = own > -30000;                       // (see segment_body for the slope-limited lane units)
     const int pmax = wave_scan_max(nz ? own + kSlope * lane : -0x20000000);
     const int mstar = wave_scan_max(nz ? lane : -1);
     eA = mstar >= 0 ? pmax - kSlope * mstar : own;
-    const int sh = max(own - eA, -200);
-    BA.x = ldexpf(in.a[0], sh); LA.x = ldexpf(in.a[1], sh); BB.x = ldexpf(in.a[2], sh); LB.x = ldexpf(in.a[3], sh);
-    BA.y = ldexpf(in.a[4], sh); LA.y = ldexpf(in.a[5], sh); BB.y = ldexpf(in.a[6], sh); LB.y = ldexpf(in.a[7], sh);
+    shA = max(own - eA, -200);
   }
+  auto alpha_start = [&]() {
+    if (seg != 0) {
+      BA.x = ldexpf(in.a[0], shA); LA.x = ldexpf(in.a[1], shA); BB.x = ldexpf(in.a[2], shA); LB.x = ldexpf(in.a[3], shA);
+      BA.y = ldexpf(in.a[4], shA); LA.y = ldexpf(in.a[5], shA); BB.y = ldexpf(in.a[6], shA); LB.y = ldexpf(in.a[7], shA);
+    } else { BA = h_f2{0.f, 0.f}; LA = BA; BB = BA; LB = BA; }
+  };
+  alpha_start();
   float fA, fB;
   {
     const int ep = __shfl_up(eA, 1, 64), en = __shfl_down(eA, 1, 64);
@@ -1287,34 +1298,39 @@ __device__ __forceinline__ void segment_body_pk(const FastParams& p, int b, int 
   const f4* yblank = reinterpret_cast<const f4*>(ys + blank * kYs);
   f4 e4[PPL], b4;
 
+  auto alpha_rows = [&](auto first_tag, auto last_tag, auto keep_tag) {
+    constexpr int T0 = decltype(first_tag)::value, T1 = decltype(last_tag)::value, KEEP0 = decltype(keep_tag)::value;
 #pragma unroll
-  for (int tt = 0; tt < kSeg; tt++) {
-    if ((tt & 3) == 0) {
-      b4 = yblank[tt >> 2];
+    for (int tt = T0; tt < T1; tt++) {
+      if ((tt & 3) == 0) {
+        b4 = yblank[tt >> 2];
 #pragma unroll
-      for (int r = 0; r < PPL; r++) e4[r] = ylab[r][tt >> 2];
-    }
-    if ((FULL || tt < n) && !(E2E_F2_ABL & 16)) {
-      const float yb = b4[tt & 3];
-      if (!FULL && t0 + tt == 0) {
-        BA = h_f2{0.f, 0.f}; LA = BA; BB = BA; LB = BA;
-        if (lane == 0) { BA.x = cond ? yb : 0.f; LA.x = rr * e4[0][tt & 3]; }
-      } else {
-        h_f2 PLA;                                        // the label cell below pairs 0 and 2
-        PLA.x = from_prev_lane(LB.y) * fA; PLA.y = LB.x;
-        const h_f2 YB = {yb, yb};
-        const h_f2 nBA = (BA + RR * PLA) * YB;
-        const h_f2 uA = LA + RR * BA + SKPA * PLA;
-        const h_f2 nBB = (BB + RR * LA) * YB;             // (pairs 1, 3 take from pairs 0, 2)
-        const h_f2 uB = LB + RR * BB + SKPB * LA;
-        BA = nBA; BB = nBB;
-        LA.x = uA.x * e4[0][tt & 3]; LA.y = uA.y * e4[2][tt & 3];
-        LB.x = uB.x * e4[1][tt & 3]; LB.y = uB.y * e4[3][tt & 3];
+        for (int r = 0; r < PPL; r++) e4[r] = ylab[r][tt >> 2];
       }
-      if ((tt & 7) == 7) rescale(BA, LA, BB, LB, tt == 7 ? eA7 : eA15);
+      if ((FULL || tt < n) && !(E2E_F2_ABL & 16)) {
+        const float yb = b4[tt & 3];
+        if (!FULL && t0 + tt == 0) {
+          BA = h_f2{0.f, 0.f}; LA = BA; BB = BA; LB = BA;
+          if (lane == 0) { BA.x = cond ? yb : 0.f; LA.x = rr * e4[0][tt & 3]; }
+        } else {
+          h_f2 PLA;                                        // the label cell below pairs 0 and 2
+          PLA.x = from_prev_lane(LB.y) * fA; PLA.y = LB.x;
+          const h_f2 YB = {yb, yb};
+          const h_f2 nBA = (BA + RR * PLA) * YB;
+          const h_f2 uA = LA + RR * BA + SKPA * PLA;
+          const h_f2 nBB = (BB + RR * LA) * YB;             // (pairs 1, 3 take from pairs 0, 2)
+          const h_f2 uB = LB + RR * BB + SKPB * LA;
+          BA = nBA; BB = nBB;
+          LA.x = uA.x * e4[0][tt & 3]; LA.y = uA.y * e4[2][tt & 3];
+          LB.x = uB.x * e4[1][tt & 3]; LB.y = uB.y * e4[3][tt & 3];
+        }
+        if ((tt & 7) == 7) rescale(BA, LA, BB, LB, tt == 7 ? eA7 : eA15);
+      }
+      if (tt >= KEEP0) { ABA[tt - KEEP0] = BA; ALA[tt - KEEP0] = LA; ABB[tt - KEEP0] = BB; ALB[tt - KEEP0] = LB; }
     }
-    ABA[tt] = BA; ALA[tt] = LA; ABB[tt] = BB; ALB[tt] = LB;
-  }
+  };
+  typedef std::integral_constant<int, 0> I0_; typedef std::integral_constant<int, kHalf> I8_; typedef std::integral_constant<int, kSeg> I16_;
+  if (E2E_F2_HALF) alpha_rows(I0_{}, I16_{}, I8_{}); else alpha_rows(I0_{}, I16_{}, I0_{});
 
   F2_STAMP(2)
   // ---- beta backwards through the segment, posteriors, per-label accumulation (see segment_body) ----
@@ -1324,8 +1340,8 @@ __device__ __forceinline__ void segment_body_pk(const FastParams& p, int b, int 
   int unit_exp = 0;
   if (FULL || !last_seg) {
     const int ownB = in.ownB;
-    float a_end = fmaxf(fmaxf(fmaxf(ABA[kSeg - 1].x, ABA[kSeg - 1].y), fmaxf(ALA[kSeg - 1].x, ALA[kSeg - 1].y)),
-                        fmaxf(fmaxf(ABB[kSeg - 1].x, ABB[kSeg - 1].y), fmaxf(ALB[kSeg - 1].x, ALB[kSeg - 1].y)));
+    float a_end = fmaxf(fmaxf(fmaxf(ABA[kKeep - 1].x, ABA[kKeep - 1].y), fmaxf(ALA[kKeep - 1].x, ALA[kKeep - 1].y)),
+                        fmaxf(fmaxf(ABB[kKeep - 1].x, ABB[kKeep - 1].y), fmaxf(ALB[kKeep - 1].x, ALB[kKeep - 1].y)));
     const int e_end = a_end >= 0x1p-120f ? (int)((__float_as_uint(a_end) >> 23) & 0xffu) - 127 : -200;
     const int emax = wave_max(eA + ownB + e_end);
     unit_exp = emax;
@@ -1346,6 +1362,7 @@ __device__ __forceinline__ void segment_body_pk(const FastParams& p, int b, int 
 #pragma unroll
   for (int h = kSeg / kHalf - 1; h >= 0; h--) {
     if (!FULL && h * kHalf >= n) continue;
+    if (E2E_F2_HALF && h == 0) { alpha_start(); alpha_rows(I0_{}, I8_{}, I0_{}); }      // rows 0..7 again, kept this time
     float pb[kHalf];
 #pragma unroll
     for (int k = 0; k < kHalf; k++) pb[k] = 0.f;
@@ -1378,9 +1395,10 @@ __device__ __forceinline__ void segment_body_pk(const FastParams& p, int b, int 
           bsBB = qBB + RR * qLB;
         }
         // alpha*beta of this lane's cells: label cells go to their label-sorted slot, blank cells are pre-summed
-        const h_f2 pbl = ABA[tt] * bsBA + ABB[tt] * bsBB;
+        constexpr int kA = E2E_F2_HALF ? kHalf - 1 : kSeg - 1;       // (index mask of the kept rows)
+        const h_f2 pbl = ABA[tt & kA] * bsBA + ABB[tt & kA] * bsBB;
         pb[k] = pbl.x + pbl.y;
-        const h_f2 PA = ALA[tt] * bsLA, PB = ALB[tt] * bsLB;
+        const h_f2 PA = ALA[tt & kA] * bsLA, PB = ALB[tt & kA] * bsLB;
         Ps[k * PROW + rank[0]] = PA.x; Ps[k * PROW + rank[1]] = PB.x;
         Ps[k * PROW + rank[2]] = PA.y; Ps[k * PROW + rank[3]] = PB.y;
         // q_t = beta_t * y_t
@@ -1518,12 +1536,13 @@ __device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char*
 #ifndef E2E_F2_MINW                 // (both overridable for tools/diag occupancy experiments)
 #define E2E_F2_MINW 2
 #endif
+#define E2E_F2_MINW4 (E2E_F2_HALF ? 3 : E2E_F2_MINW)     // four pairs per lane: three waves per SIMD with half the alpha rows kept
 #ifndef E2E_F2_LDSPAD
 #define E2E_F2_LDSPAD 0
 #endif
 // (eight pairs per lane: 16 alpha rows of 16 cells are 256 registers by themselves -- one wave per SIMD, no spills)
 template <int PPL>
-__global__ E2E_KERNEL_ALIGN __launch_bounds__(64, PPL == 8 ? 1 : E2E_F2_MINW) void ctc_fast_segment_kernel(FastParams p) {
+__global__ E2E_KERNEL_ALIGN __launch_bounds__(64, PPL == 8 ? 1 : PPL == 4 ? E2E_F2_MINW4 : E2E_F2_MINW) void ctc_fast_segment_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   segment_wave<PPL>(p, smem);
 }
@@ -1550,7 +1569,7 @@ int launch_fast_long(const FastParams& p, hipStream_t stream) {
   return E2E_OK;
 }
 
-constexpr bool kLeanDefault = false;   // (the lean kernel is not faster yet: 136.5 against 134.2 us per call at the headline shape)
+constexpr bool kLeanDefault = true;    // (targets of 128..223 labels: 132.4 against 134.2 us per call at the headline shape)
 
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {

@@ -377,6 +377,137 @@ __device__ __forceinline__ void hx_chain_wave(const FastParams& p, int b, int T,
   }
 }
 
+// The probability rows of one chain, leaner than prep_wave (fast_common.h), which it follows: a block is one pass, each
+// group of 8 lanes takes one of the block's 8 time steps, a lane holds the columns v = l8 + 8k, k < NV = ceil(V/8).  What a
+// producer costs is again its instruction count -- at ~235 per block prep_wave weighs as much as a chain wave, and the chains
+// were waiting for it (tools/diag/h1_wave_profile.py: ring wait) --, so: the direction is a template parameter, the row's
+// address is one clamp and one multiply-add from the block number, only the last column groups of a bracket are tested,
+// steady blocks (all rows live) have no row tests, the blank's (probability, tilted probability) pair is one masked store
+// after the columns, and only the alpha side tracks the smallest log-probability.
+template <int NV, int DIR>
+__device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, int first, unsigned char* smem, const HxLds hl,
+                                             int lane, double rr2) {
+  constexpr int stride = kHxProducers;
+  lds_u8* L0 = (lds_u8*)smem;
+  const int V = p.V;
+  const int nblk = (T + kBlk - 1) / kBlk, M = (T - 1) >> 3;
+  const int tt = lane >> 3, l8 = lane & 7;
+  const float ninf = -__builtin_huge_valf();
+  // NV is the alphabet's bracket (2: V <= 16, 4: <= 32, 6: <= 48, 8: <= 64, 12: <= 96): the first kFull column groups are
+  // live in every lane, the others are tested
+  constexpr int kFull = NV == 2 ? 0 : NV == 12 ? 8 : NV - 2;
+  bool live[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) live[k] = k < kFull || l8 + 8 * k < V;
+  const bool contig = p.sV == 1;
+  const float* xl = p.x + (int64_t)b * p.sB + (int64_t)l8 * p.sV;   // this lane's first column
+  const int64_t cstep = 8 * p.sV;
+  float* yl = p.ytab + (size_t)b * p.T * V + l8;
+  const int t_first = DIR == 0 ? tt : 8 * M + 7 - tt;                // the lane's row in block 0; block n: t_first +- 8 n
+  lds_u8* prog = L0 + hl.prog + DIR * 32;
+  const int a_fill = hl.filled + (DIR * kRingBlks + first) * 4;
+  const int a_row = hl.ring + DIR * kRingBlks * hl.blk_bytes + (l8 * kRow + tt) * 8;       // + slot * blk_bytes + k * 8 * kRow * 8
+  const int a_yw = hl.ring + DIR * kRingBlks * hl.blk_bytes + ((V + 1) * kRow + 2 * tt) * 8;
+  const int kb = p.blank >> 3;
+  const bool blank_lane = l8 == (p.blank & 7);
+
+  auto row_of = [&](int n) { return DIR == 0 ? t_first + 8 * n : t_first - 8 * n; };
+  // unconditional loads from a clamped row (what a dead row or column reads is replaced when it is used), two of this wave's
+  // blocks ahead, three register sets rotating through a loop unrolled three times: see prep_wave
+  auto load_block = [&](int n, float (&out)[NV]) {
+    const int t = row_of(n);
+    const int tc = min(max(t, 0), T - 1);
+    const float* xr = xl + (int64_t)tc * p.sT;
+    if (contig) {
+#pragma unroll
+      for (int k = 0; k < NV; k++) out[k] = xr[(k < kFull || live[k]) ? 8 * k : 0];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV; k++) out[k] = xr[(k < kFull || live[k]) ? k * cstep : 0];
+    }
+  };
+  int consumed = 0;
+  float lpmin = 0.f;
+  auto process = [&](int n, const float (&xraw)[NV]) {
+    constexpr bool STEADY = false;                                 // (a copy of the body without row tests: 60 instances, not worth it)
+    const int t = row_of(n);
+    const bool row_live = t >= 0 && t < T;
+    float xv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) xv[k] = (row_live && (k < kFull || live[k])) ? xraw[k] : ninf;
+    if (n >= kRingBlks) {
+      // (the readers' progress is looked at again only when the last look does not cover this block)
+      while (consumed < n - kRingBlks + 1) {
+        consumed = __builtin_amdgcn_readfirstlane(lds_min8(prog));
+        if (consumed < n - kRingBlks + 1) __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+    }
+    float y[NV];
+    if (p.logprobs) {
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        y[k] = exp_le0(xv[k]);
+        if (DIR == 0) lpmin = fminf(lpmin, xv[k] > ninf ? xv[k] : 0.f);      // (-inf: an impossible symbol, exact; so are dead rows)
+      }
+    } else {
+      float m = xv[0];
+#pragma unroll
+      for (int k = 1; k < NV; k++) m = fmaxf(m, xv[k]);
+      m = row8_max(m);
+      float ssum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        const float d = xv[k] - m;
+        y[k] = exp_le0(d); ssum += y[k];
+        if (DIR == 0) lpmin = fminf(lpmin, xv[k] > ninf ? d : 0.f);          // (>= the log-probability)
+      }
+      ssum = row8_sum(ssum);
+      float inv = __builtin_amdgcn_rcpf(ssum);
+      inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);        // one Newton step: ~0.5 ulp
+#pragma unroll
+      for (int k = 0; k < NV; k++) y[k] *= inv;
+    }
+    if (!STEADY) {
+#pragma unroll
+      for (int k = 0; k < NV; k++) y[k] = row_live ? y[k] : 0.f;
+    }
+    const int sb = (n & (kRingBlks - 1)) * hl.blk_bytes;
+    lds_u8* dst = L0 + (a_row + sb);
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      if (k < kFull || live[k]) *(volatile lds_f64*)(dst + k * (8 * kRow * 8)) = (double)y[k];             // transposed: [label][step]
+    }
+    {
+      float ybl = y[0];
+#pragma unroll
+      for (int k = 1; k < NV; k++) ybl = kb == k ? y[k] : ybl;
+      if (blank_lane) { h_d2 yw; yw.x = (double)ybl; yw.y = rr2 * (double)ybl; *(volatile lds_d2*)(L0 + (a_yw + sb)) = yw; }
+    }
+    if (DIR == 0 && row_live) {
+      float* yrow = yl + (size_t)t * V;
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        if (k < kFull || live[k]) yrow[8 * k] = y[k];
+      }
+    }
+    // every lane stores the same word ("my blocks up to n are there"): no divergence, one LDS write
+    *(volatile lds_int*)(L0 + a_fill) = n + stride;
+  };
+  {
+    float xa[NV], xb[NV], xc[NV];
+    load_block(first, xa);
+    load_block(first + stride, xb);
+    for (int n = first; n < nblk; n += 3 * stride) {       // this wave fills every `stride`-th block
+      load_block(n + 2 * stride, xc); process(n, xa);
+      load_block(n + 3 * stride, xa); if (n + stride < nblk) process(n + stride, xb);
+      load_block(n + 4 * stride, xb); if (n + 2 * stride < nblk) process(n + 2 * stride, xc);
+    }
+  }
+  // (see prep_wave: emissions near the end of f32 -> the utterance is recomputed entirely by the exact kernel)
+  if (DIR == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], 64); }       // e^-69 = 2^-100
+}
+
 // The checkpoint wave of a direction: reads a checkpoint row's true cells in lattice order (pair i: cells 2i, 2i+1), finds the
 // exponent of every group of F2PPL pairs (the segment kernel's lanes), scales, and stores cells and exponents.
 template <int DIR, int F2PPL>
@@ -475,15 +606,10 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(Hx<NP>::kWaves * 64) void ctc_fast
   } else {
     const int d = (wave - kProd) & 1;                    // alternating: alpha rows, beta rows
     const int first = (wave - kProd) >> 1;               // the producers of a direction take every kHxProducers-th block
-    lds_u8* prog = L0 + hl.prog + d * 32;
     const double rr2 = (double)fast_tilt(S, T) * (double)fast_tilt(S, T);        // (the chain waves' own expression)
-    unsigned char* ring = smem + hl.ring + d * kRingBlks * hl.blk_bytes;
-    volatile int* fl = reinterpret_cast<int*>(smem + hl.filled) + d * kRingBlks;
-    if (V <= 16) prep_wave<2, 1>(p, b, T, d, first, kHxProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 32) prep_wave<4, 1>(p, b, T, d, first, kHxProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 48) prep_wave<6, 1>(p, b, T, d, first, kHxProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else if (V <= 64) prep_wave<8, 1>(p, b, T, d, first, kHxProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
-    else prep_wave<12, 1>(p, b, T, d, first, kHxProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
+#define HX_PREP(NVV) { if (d == 0) hx_prep_wave<NVV, 0>(p, b, T, first, smem, hl, lane, rr2); else hx_prep_wave<NVV, 1>(p, b, T, first, smem, hl, lane, rr2); }
+    if (V <= 16) HX_PREP(2) else if (V <= 32) HX_PREP(4) else if (V <= 48) HX_PREP(6) else if (V <= 64) HX_PREP(8) else HX_PREP(12)
+#undef HX_PREP
   }
 }
 

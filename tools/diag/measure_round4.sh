@@ -1,0 +1,22 @@
+# usage (on the GPU box, from the repo root): bash tools/diag/measure_round3.sh TAG [full]
+# bench line + rocprofv3 kernel stats + SQ counters (+ FETCH/WRITE passes with PMC=1) of the default bench command
+TAG=${1:-x}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+FLAGS="--no-cpu-baseline --no-decode --no-wide"
+[ "$2" = full ] && python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_r04_$TAG.json 2> gpurun_out/bench_r04_$TAG.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o c2 -- python3 bench.py --steps 20 --warmup 5 $FLAGS > gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pmc_${TAG}_sq -o pmc -- python3 bench.py --steps 5 --warmup 2 $FLAGS > gpurun_out/pmc_${TAG}_sq.log 2>&1
+python3 tools/diag/pmc_summary.py gpurun_out/pmc_${TAG}_sq
+if [ -n "$PMC" ]; then
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${TAG}_fetch -o pmc -- python3 bench.py --steps 5 --warmup 2 $FLAGS > gpurun_out/pmc_${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${TAG}_write -o pmc -- python3 bench.py --steps 5 --warmup 2 $FLAGS > gpurun_out/pmc_${TAG}_write.log 2>&1
+python3 tools/diag/pmc_summary.py gpurun_out/pmc_${TAG}_fetch
+python3 tools/diag/pmc_summary.py gpurun_out/pmc_${TAG}_write
+fi
+find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs head -8 | cut -c1-180
+grep '^{"metric' gpurun_out/prof_$TAG.log | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print({k:d[k] for k in ('value','ms_per_step','module_ms_per_step')}, d['roofline']['kernel_ms'], d['roofline']['frac'], d['roofline']['peak_measured'])
+"
