@@ -320,8 +320,10 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
     }
     std::sort(seen.begin(), seen.end());
     sig_ok = std::adjacent_find(seen.begin(), seen.end()) == seen.end();
-    // continuation bits: (w1 .. wn) sets bit cont_bit(wn) of its context (w1 .. wn-1).  An n-gram whose context is not
-    // listed (ARPA files written by the usual tools always list it) switches the filter off: every bit set.
+    // continuation bits: (w1 .. wn) sets bit cont_bit(wn) of its context (w1 .. wn-1).  The kernel's scorer
+    // (lm_score_parallel) looks an n-gram up only behind a HIT of its context, so a model that lists an n-gram without its
+    // context (SRILM-pruned files do; KenLM inserts blank entries for them) cannot use these tables: the id-keyed walk
+    // (lm_base_score), which probes every order, takes over.
     bool contexts_listed = true;
     const LmView hv = lm->host_view();
     for (size_t i = 0; i < lm->ng.size(); i++) {
@@ -336,7 +338,10 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
       const uint64_t bit = 1ULL << cont_bit(sl.ids[sl.n - 1]);
       if (sl.n == 2) uni[sl.ids[0]].cont |= bit; else ngs[(size_t)(c - lm->ng.data())].cont |= bit;
     }
-    if (!contexts_listed) { for (auto& e : ngs) e.cont = ~0ULL; for (auto& e : uni) e.cont = ~0ULL; }
+    if (!contexts_listed) {
+      sig_ok = false;
+      if (getenv("E2E_LM_DEBUG")) fprintf(stderr, "e2e_lm: an n-gram's context is not listed; using the id tables (slower)\n");
+    }
   }
   std::vector<VEntry> vt(lm->vkeys.size(), VEntry{0, 0u, 1.f});
   for (size_t i = 0; i < lm->vkeys.size() && sig_ok; i++) {      // (one entry per distinct folded spelling already)
@@ -382,8 +387,8 @@ extern "C" int e2e_lm_load_arpa(const char* path, const char* const* labels, int
       if (sig_ok && sl.n >= 2) {
         const uint64_t bit = 1ULL << cont_bit(sl.ids[sl.n - 1]);
         const NgSlot* c = lm_ngram_find(hv, sl.ids, sl.n - 1);
-        const uint64_t cont = sl.n == 2 ? uni[sl.ids[0]].cont : (c ? ngs[(size_t)(c - lm->ng.data())].cont : ~0ULL);
-        sig_ok = (cont & bit) != 0;
+        const uint64_t cont = sl.n == 2 ? uni[sl.ids[0]].cont : (c ? ngs[(size_t)(c - lm->ng.data())].cont : 0ULL);
+        sig_ok = (sl.n == 2 || c) && (cont & bit) != 0;         // (an unlisted context fails: the kernel would never probe the n-gram)
       }
     }
     if (!sig_ok) fprintf(stderr, "e2e_lm: the kernel's tables failed their self-check; using the id tables (slower)\n");

@@ -533,7 +533,12 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
         const double a1 = ldexp((p01 * f0[1] + p11 * f1[1] + p21 * f2[1]) * y1, -e);
         if (live[0] && valid) { cur[tid] = a0; warow[tid] = a0; }
         if (live[1] && valid) { cur[tid + NT] = a1; warow[tid + NT] = a1; }
-        int mt = max(live[0] ? __double2hiint(a0) : 0, live[1] ? __double2hiint(a1) : 0);
+        // the row's scale comes from the cells INSIDE the reference's window only (here: cells that can still reach the end,
+        // j >= L - 2 (T - t)).  A doomed cell below it -- the all-blank path at j = 0 when T is barely long enough -- may be
+        // far larger than everything feasible; scaled by it, feasible cells would lose bits or flush to zero mid-sequence.
+        // Doomed mass never enters the window; if it overflows, the NaN it leaves ends in the log-domain walk below.
+        const int wlo = L - 2 * (T - t);
+        int mt = max((live[0] && tid >= wlo) ? __double2hiint(a0) : 0, (live[1] && tid + NT >= wlo) ? __double2hiint(a1) : 0);
         mt = wave_max_nonneg_lane63(mt);
         if (lane == 63 && valid) rmax[(t & 1) * 8 + wid] = mt;
       }
@@ -549,7 +554,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
           double a = 0.0;
           if ((j == 0 && (T > 1 || L == 1)) || j == 1) a = exp(lp(0, ext[j]));
           buf0[j] = a; wa[j] = a;
-          mt = max(mt, __double2hiint(a));
+          if (j >= L - 2 * T) mt = max(mt, __double2hiint(a));
         }
       }
       mt = wave_max_nonneg_lane63(mt);
@@ -617,7 +622,8 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
             if (tid & 1) ps[rk[1]] = pj1; else blank_part += pj1;          // (NT is even: same parity as tid)
           }
           F += e;
-          int mt = max(live[0] ? __double2hiint(bc0) : 0, live[1] ? __double2hiint(bc1) : 0);
+          const int whi = 2 * t + 2;                          // (beta's side of the window: cells the start can reach, j < 2t + 2)
+          int mt = max((live[0] && tid < whi) ? __double2hiint(bc0) : 0, (live[1] && tid + NT < whi) ? __double2hiint(bc1) : 0);
           mt = wave_max_nonneg_lane63(mt);
           blank_part = wave_sum_lane63(blank_part);
           if (lane == 63 && valid) { redb[(t & 1) * 8 + wid] = blank_part; rmax[(t & 1) * 8 + wid] = mt; }

@@ -159,8 +159,9 @@ class CTCDecoderEngine:
         self.keep_on_device = bool(keep_on_device)
         # index of " " among the labels, else -1 (src/decoders/ctc_decoder.cpp:55-59)
         self.space_id = self.labels.index(" ") if " " in self.labels else -1
+        # (a lone surrogate is a legal one-character label, but not legal UTF-32: such alphabets take the per-id join)
         self._codes = (np.array([ord(c) for c in self.labels], dtype="<u4")
-                       if self.labels and all(len(c) == 1 for c in self.labels) else None)
+                       if self.labels and all(len(c) == 1 and not 0xD800 <= ord(c) <= 0xDFFF for c in self.labels) else None)
         self.lm = None
         if self.labels and self.beam_width > 1:
             # the beam lives in one workgroup's LDS: a width / alphabet it cannot hold is reported now, not at the first

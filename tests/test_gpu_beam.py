@@ -90,6 +90,25 @@ def test_lm_scored_beam_matches_oracle(W, lmwt, wip, oov, case_sensitive):
                    case_sensitive=case_sensitive)
 
 
+def test_model_with_an_unlisted_context_matches_oracle(tmp_path):
+    """An ARPA file that lists the trigram 'a b a' but not its context 'a b' (SRILM-pruned models do; KenLM inserts blank
+    entries): the kernel's signature tables gate an n-gram behind a hit of its context, so the loader must hand such a
+    model to the id-keyed walk -- the decoded sentences and the host scorer agree with the oracle's back-off scorer."""
+    src = open(ARPA).read()
+    pruned = src.replace("-0.6\ta b\t-0.2\n", "").replace("ngram 2=5", "ngram 2=4")
+    assert pruned != src
+    path = str(tmp_path / "pruned.arpa")
+    open(path, "w").write(pruned)
+    labels = ["_", "a", "b", " "]
+    lm = LanguageModel(path, labels, True)
+    olm = O.OracleLM(path)
+    a, b = lm.word_index("a"), lm.word_index("b")
+    assert abs(lm.score([b, a], a) - (-0.25)) < 1e-6 and abs(olm.base_score([olm.word_index("b"), olm.word_index("a")], olm.word_index("a"))[0] + 0.25) < 1e-6
+    for seed, W in ((5, 10), (6, 40), (7, 100)):
+        lp = rand_lp(seed, 4, 30, 4, sharp=1.5)
+        same_as_oracle(lp, [30, 30, 21, 12], 0, W, labels, lm, olm, lmwt=1.5, wip=0.5, oov_penalty=-5.0, case_sensitive=True)
+
+
 def test_lm_changes_the_answer():
     # acoustically "b a" and "a b" are close; the LM (which has "<s> a b" but no "<s> b") decides
     labels = ["_", "a", "b", " "]

@@ -520,6 +520,32 @@ def test_scaled_exact_form_hands_over_to_the_log_domain_beyond_f64_range():
     U.assert_same(ge, grads, 1e-6, 1e-9, "grads: scaled / handed-over against the log-domain kernel")
 
 
+def test_scaled_exact_form_scales_rows_by_their_feasible_cells():
+    """A transcript barely shorter than the utterance with the blank dominating every frame: the all-blank path at j = 0 is
+    doomed (outside the reference's [start, end) window almost from the beginning) and ~2^500 above everything feasible.  The
+    scaled form takes each row's power of two from the cells inside the window, so the feasible cells keep their bits; both
+    utterances reach the exact kernel through a blank-valued label (AUTO) and are compared with the oracle and with the
+    log-domain kernel."""
+    B, T, V, S = 2, 96, 8, 90
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 0.3, size=(B, T, V)).astype(np.float32)
+    x[:, :, 0] += 6.0                                              # blank probability ~0.98, labels ~0.003
+    tg = rng.integers(1, V, size=(B, S)); tg[:, 1::2] = 1; tg[:, 0::2] = 2          # no repeats: T - S = 6 spare frames
+    tg[0, 40] = 0                                                  # a blank-valued label: the fast path hands the utterance over
+    tg[1, 10] = 0
+    xl = [T, T - 2]; tl = [S, S - 3]
+    lp = torch.log_softmax(torch.from_numpy(x).double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg, xl, tl, 0)
+    assert np.isfinite(l_o).all() and (l_o > 400).all()
+    losses, grads = U.c_abi_loss(torch.from_numpy(lp.astype(np.float32)), tg, xl, tl, 0, True, _lib.ALGO_AUTO)
+    l32, g32 = O.ctc_loss(lp.astype(np.float32).astype(np.float64), tg, xl, tl, 0)
+    U.assert_same(losses, l32, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads, g32, F32_RTOL, F32_ATOL, "grads")
+    le, ge = U.c_abi_loss(torch.from_numpy(lp.astype(np.float32)), tg, xl, tl, 0, True, _lib.ALGO_EXACT)
+    U.assert_same(le, losses, 1e-6, 0, "losses: scaled form against the log-domain kernel")
+    U.assert_same(ge, grads, 1e-6, 1e-9, "grads: scaled form against the log-domain kernel")
+
+
 @pytest.mark.parametrize("shape", [(3, 700, 29, 300), (2, 2000, 29, 400), (2, 1100, 48, 447)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)
 def test_long_transcripts_take_the_fast_path(shape):
     """Targets of 256..447 labels: the halo chains on four waves per direction and the segment kernel with

@@ -211,3 +211,36 @@ def test_language_model_kernel_tables_pass_their_self_check(tmp_path):
     assert r.returncode == 0, r.stderr
     lines = [l for l in r.stderr.splitlines() if l.startswith("e2e_lm:")]
     assert len(lines) == 3 and all(l.endswith("signature tables ok") for l in lines), r.stderr
+
+
+def test_language_model_with_an_unlisted_context_uses_the_id_tables(tmp_path):
+    """SRILM-pruned ARPA files can list an n-gram whose context is missing (KenLM inserts blank entries for those).  The beam
+    kernel's signature tables look an n-gram up only behind a hit of its context, so such a model must fall back to the
+    id-keyed walk, and the host scorer must still find the n-gram (here: trigram 'a b a' without bigram 'a b')."""
+    src = open(os.path.join(ROOT, "tests", "golden", "tiny_3gram.arpa")).read()
+    pruned = src.replace("-0.6\ta b\t-0.2\n", "").replace("ngram 2=5", "ngram 2=4")
+    assert pruned != src
+    path = str(tmp_path / "pruned.arpa")
+    open(path, "w").write(pruned)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from end2end_amd.engines import LanguageModel\n"
+            "lm = LanguageModel(%r, ['_', 'a', 'b', ' '], True)\n"
+            "a, b = lm.word_index('a'), lm.word_index('b')\n"
+            "print('SCORE %%.6f' %% lm.score([b, a], a))\n") % (ROOT, path)
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, "E2E_LM_DEBUG": "1"})
+    assert r.returncode == 0, r.stderr
+    assert "SCORE -0.250000" in r.stdout, r.stdout              # the trigram itself, not the backed-off -0.5
+    lines = [l for l in r.stderr.splitlines() if l.startswith("e2e_lm:")]
+    assert any("context is not listed" in l for l in lines) and any(l.endswith("signature tables NOT usable") for l in lines), r.stderr
+
+
+def test_one_character_labels_that_are_lone_surrogates_still_spell():
+    """indices2str for the whole batch goes through a UTF-32 table; a lone surrogate (a legal one-character Python label) is not
+    valid UTF-32, so such alphabets keep the per-id join instead of raising UnicodeDecodeError."""
+    import torch
+    from end2end_amd.engines import CTCDecoderEngine as DecoderEngine
+    eng = DecoderEngine(0, 1, ["_", "\ud800", "a"])
+    assert eng._codes is None
+    assert eng._strings(torch.tensor([[1, 2, 0], [2, 2, 2]]), [2, 3]) == ["\ud800a", "aaa"]
+    plain = DecoderEngine(0, 1, ["_", "b", "a"])
+    assert plain._codes is not None and plain._strings(torch.tensor([[1, 2, 0], [2, 2, 2]]), [2, 3]) == ["ba", "aaa"]
