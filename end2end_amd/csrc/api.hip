@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -19,6 +21,27 @@ void set_error(const char* fmt, ...) {
 int hip_fail(hipError_t e, const char* what) {
   set_error("%s: %s", what, hipGetErrorString(e));
   return E2E_ERR_HIP;
+}
+
+hipError_t allow_dynamic_lds(const void* fn, int bytes) {
+  // the largest size asked for so far per (kernel, device); the attribute is raised only when a launch needs more
+  struct Seen { const void* fn; int dev; int bytes; };
+  static std::mutex mu;
+  static std::vector<Seen> seen;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& s : seen)
+    if (s.fn == fn && s.dev == dev) {
+      if (s.bytes >= bytes) return hipSuccess;
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e == hipSuccess) s.bytes = bytes;
+      return e;
+    }
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) seen.push_back(Seen{fn, dev, bytes});
+  return e;
 }
 
 int launch_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV, const int64_t* x_len,

@@ -18,6 +18,10 @@ int hip_fail(hipError_t e, const char* what);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize = `bytes` for kernel `fn`, set once per (kernel, device, size class) and process --
+// not on every launch: a host call that an entry point meant to be captured into a graph should not repeat.  Returns a hipError_t.
+hipError_t allow_dynamic_lds(const void* fn, int bytes);
+
 // -- launchers implemented in the .hip files ---------------------------------
 struct LossArgs {
   const void* x; int dtype; int logprobs;

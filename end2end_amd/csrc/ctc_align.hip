@@ -283,12 +283,10 @@ extern "C" int e2e_ctc_align(const void* lp, int dtype, int64_t sB, int64_t sT, 
   p.is_ctc = is_ctc ? 1 : 0; p.out = out; p.pad = pad_value; p.bp = reinterpret_cast<unsigned char*>(aligned);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == E2E_F32) {
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_align_kernel<float>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+    E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_align_kernel<float>), (int)lds), "hipFuncSetAttribute");
     hipLaunchKernelGGL(ctc_align_kernel<float>, dim3(B), dim3(kThreads), lds, s, p);
   } else {
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_align_kernel<double>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+    E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_align_kernel<double>), (int)lds), "hipFuncSetAttribute");
     hipLaunchKernelGGL(ctc_align_kernel<double>, dim3(B), dim3(kThreads), lds, s, p);
   }
   E2E_HIP_CHECK(hipGetLastError(), "ctc_align_kernel launch");

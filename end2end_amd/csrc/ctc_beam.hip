@@ -1991,7 +1991,7 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
     else
       gfn = !lm ? (const void*)&ctc_beam_general_kernel<double, 0>
                 : fast_lm ? (const void*)&ctc_beam_general_kernel<double, 2> : (const void*)&ctc_beam_general_kernel<double, 1>;
-    E2E_HIP_CHECK(hipFuncSetAttribute(gfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gl.lds), "hipFuncSetAttribute");
+    E2E_HIP_CHECK(allow_dynamic_lds(gfn, (int)gl.lds), "hipFuncSetAttribute");
     void* gargs[] = { &p, &g };
     E2E_HIP_CHECK(hipLaunchKernel(gfn, dim3(B), dim3(kGenThreads), gargs, gl.lds, s), "ctc_beam_general_kernel launch");
     E2E_HIP_CHECK(hipGetLastError(), "ctc_beam_general_kernel launch");
@@ -2005,7 +2005,7 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
     fn = !lm ? (const void*)&ctc_beam_kernel<double, 0, kThreadsNoLm>
              : fast_lm ? (const void*)&ctc_beam_kernel<double, 2, kThreadsLm> : (const void*)&ctc_beam_kernel<double, 1, kThreadsLm>;
   const int nthreads = lm ? kThreadsLm : kThreadsNoLm;
-  E2E_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds), "hipFuncSetAttribute");
+  E2E_HIP_CHECK(allow_dynamic_lds(fn, (int)l.lds), "hipFuncSetAttribute");
   void* args[] = { &p };
   E2E_HIP_CHECK(hipLaunchKernel(fn, dim3(B), dim3(nthreads), args, l.lds, s), "ctc_beam_kernel launch");
   E2E_HIP_CHECK(hipGetLastError(), "ctc_beam_kernel launch");

@@ -1025,7 +1025,7 @@ int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetr
   const int grid = mode == 0 ? slabs : (a.B < kFallbackGrid ? a.B : kFallbackGrid);
   if (a.B == 0) return E2E_OK;
   auto go = [&](auto kernel) -> int {
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+    E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds),
                   "hipFuncSetAttribute");
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), lds, a.stream, p);
     return E2E_OK;

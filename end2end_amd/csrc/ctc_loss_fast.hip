@@ -1560,8 +1560,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(64, PPL == 8 ? 1 : PPL == 4 ? E2E_
 // targets of 256..447 labels: the halo chains on four waves per direction, the segment kernel with eight pairs per lane
 int launch_fast_long(const FastParams& p, hipStream_t stream) {
   const HfLds hl = HfLds::of<ChainF64L>(p.V);
-  E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<8, ChainF64L>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
+  E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<8, ChainF64L>), hl.total), "hipFuncSetAttribute");
   hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<8, ChainF64L>), dim3(p.B), dim3(ChainF64L::kWaves * 64), hl.total, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
   hipLaunchKernelGGL(ctc_fast_segment_kernel<8>, dim3(p.NS, p.B), dim3(64), F2Lds<8>::bytes(p.V), stream, p);
@@ -1574,8 +1573,7 @@ constexpr bool kLeanDefault = true;    // (targets of 128..223 labels: 132.4 aga
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   const size_t lds1 = F1Lds::bytes(p.V);
-  E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1), "hipFuncSetAttribute");
+  E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL>), (int)lds1), "hipFuncSetAttribute");
   const size_t lds2 = F2Lds<PPL>::bytes(p.V) + E2E_F2_LDSPAD;
   // f32 chains: where the caller allows them (e2e_ctc_loss_opts.chains) and they are faster, i.e. at the widest rows
   // (145 against 165 us per step at S <= 200, but 115 / 93 against 120 / 94 us at S <= 127 / 63, with looser gradients: not
@@ -1583,8 +1581,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   static const bool force_f32_chains = getenv("E2E_F1_F32") != nullptr;
   if (force_f32_chains || (p.chains == E2E_CHAINS_F32 && PPL == 4)) {
     const HfLds hl = HfLds::of<ChainF32>(p.V);
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL, ChainF32>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
+    E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL, ChainF32>), hl.total), "hipFuncSetAttribute");
     hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<PPL, ChainF32>), dim3(p.B), dim3(ChainF32::kWaves * 64), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
     FastParams q = p; q.ztol = kZTolF32;                          // (trkA / trkB: written by the frame waves)
@@ -1608,8 +1605,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   // E2E_F1_SINGLE=1: the single-wave chains everywhere, E2E_F1_HALO=1: the halo chains wherever they fit (A/B, tests)
   if (!force_single && (PPL == 4 || (force_halo && PPL >= 1)) && p.Smax + 1 <= ChainF64::kMaxW * kHfOwn) {
     const HfLds hl = HfLds::of<ChainF64>(p.V);
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL, ChainF64>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, hl.total), "hipFuncSetAttribute");
+    E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL, ChainF64>), hl.total), "hipFuncSetAttribute");
     hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<PPL, ChainF64>), dim3(p.B), dim3(ChainF64::kWaves * 64), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
     hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);     // (trkA / trkB: the frame waves')

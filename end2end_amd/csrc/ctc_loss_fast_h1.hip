@@ -616,12 +616,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(Hx<NP>::kWaves * 64) void ctc_fast
 template <int PPL, int NP>
 int launch_hx(const FastParams& p, hipStream_t stream) {
   const HxLds hl(p.V);
-  static bool attr_set = false;              // (once per process and instance: the attribute is a property of the function)
-  if (!attr_set) {
-    E2E_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_fast_chain_hx_kernel<PPL, NP>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
-    attr_set = true;
-  }
+  E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hx_kernel<PPL, NP>), hl.total), "hipFuncSetAttribute");
   hipLaunchKernelGGL((ctc_fast_chain_hx_kernel<PPL, NP>), dim3(p.B), dim3(Hx<NP>::kWaves * 64), hl.total, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hx_kernel launch");
   return E2E_OK;

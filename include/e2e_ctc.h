@@ -142,6 +142,17 @@ int e2e_ctc_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV,
  * :275-278,:291-294 BaseScore).  Host-side ARPA reader (plain or .gz) that
  * builds a device-resident hash table.  `labels` are the decoder's V label
  * strings (UTF-8): words are spelled with them.
+ *
+ * Hashed matching: on the device a word is found by the 64-bit FNV hash of its
+ * spelling and an n-gram by a 64-bit signature of its word ids; the entries keep
+ * the hash, not the spelling / ids.  What the model lists is always found.  A
+ * query the model does NOT list -- an out-of-vocabulary spelling, an unseen
+ * n-gram -- is taken for a listed one if the two hashes collide: about 2^-64
+ * per probe, i.e. correct with overwhelming probability, not by construction
+ * (KenLM's probing model matches on 64-bit hashes in the same way).  The host
+ * scorer below (e2e_lm_score) compares ids and is exact.  A model that lists an
+ * n-gram without its context (SRILM-pruned ARPA files) is served from id-keyed
+ * tables, which are slower.
  */
 typedef struct e2e_lm e2e_lm;
 /* Reads the model and uploads its tables to the CURRENT HIP device (this call allocates and synchronises; it is
