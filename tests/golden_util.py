@@ -32,6 +32,18 @@ def beam_bruteforce_cases():
     return cases
 
 
+def beam_q7_cases():
+    """Hand-built vectors whose answer quirk Q7 decides (tests/golden/make_beam_q7_golden.py: derivation on paper + an
+    independent Python model of the reference's shared_ptr / weak_ptr ownership)."""
+    with open(os.path.join(GOLDEN, "beam_q7.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        V = len(c["log_probs"][0])
+        c["labels"] = [chr(ord("a") + i) for i in range(V)]
+        c["labels"][c["blank"]] = "_"
+    return cases
+
+
 def encoder_cases():
     with open(os.path.join(GOLDEN, "encoder.json")) as f:
         return json.load(f)

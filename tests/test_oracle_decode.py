@@ -91,6 +91,18 @@ def test_beam_against_exhaustive_enumeration(case):
         assert ids[0, : lens[0]].tolist() == case["want_ids"]
 
 
+@pytest.mark.parametrize("case", G.beam_q7_cases(), ids=lambda c: c["name"])
+def test_pruned_but_living_child_is_found_not_ranked(case):
+    """Quirk Q7 decides these answers (src/decoders/ctc_decoder.cpp:247-252, 397-415): a prefix dropped from the beam whose
+    descendant survives is still found by its parent's weak pointer and therefore never ranked again.  Expected sentences:
+    tests/golden/make_beam_q7_golden.py (paper derivation + an independent Python model of the ownership rules); the
+    answer of a search WITHOUT the quirk is stored beside them and must not be what the oracle returns."""
+    lp = np.array(case["log_probs"])[None]
+    ids, lens, _ = O.ctc_beam(lp, [lp.shape[1]], case["blank"], case["beam_width"], case["labels"], None)
+    got = ids[0, :lens[0]].tolist()
+    assert got == case["expected"] and got != case["without_q7"]
+
+
 @pytest.mark.parametrize("case", G.align_cases(), ids=lambda c: c["name"])
 def test_forced_alignment_against_the_reference_functions(case):
     """oracle_ctc_align vs the outputs of the reference's own _get_alignment_ctc_1d / _asg_1d / get_alignment_3d
