@@ -285,9 +285,32 @@ def decode_numbers(dev, with_cpu):
         del xd
     xb = torch.log_softmax(x[:64], -1)
     xlb = xl[:64]
+    phases = recorded_beam_phases()
+
+    def beam_leg(eng, workload, lm_key):
+        """One beam-search leg: wall time of the engine call over 5 repetitions (what a caller sees: kernel + the copy of the
+        ids to the host + the sentences), HIP events around each call on its stream (the device side alone), the HBM
+        fraction from the ALGORITHMIC bytes (SURVEY 8d: the V log-probabilities of every frame are read once, 4 B each;
+        the decoded ids leave) and the serial bound: the search is one workgroup per utterance and serial in t, so
+        cycles per frame -- not bytes -- is what the number is made of."""
+        dt = timed(lambda: eng.decode(xb, xlb), 5)
+        kms = time_events(torch, lambda: eng.decode(xb, xlb), 5)
+        bytes_alg = 64 * 1500 * 29 * 4 + 64 * 1501 * 8
+        leg = {"workload": workload, "utterances_per_s": 64 / dt, "ms": dt * 1e3, "kernel_ms": kms, "repetitions": 5,
+               "roofline": {"bound": "hbm", "achieved": bytes_alg / (kms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": bytes_alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_alg,
+                            "note": "HIP events around each engine call on its stream (mean of 5); the bound that matters "
+                                    "is serial_bound below: 64 workgroups, T dependent frames each"},
+               "serial_bound": {"frames": 1500, "us_per_frame": kms * 1e3 / 1500,
+                                "workgroups": 64, "compute_units": 256}}
+        if phases and lm_key in phases:
+            leg["serial_bound"]["cycles_per_step"] = phases[lm_key].get("cycles_per_step")
+            leg["serial_bound"]["phase_cycles"] = phases[lm_key].get("phase_cycles")
+            leg["serial_bound"]["source"] = "profiles/r04_beam_phases.json (tools/diag/beam_phase_profile.py, s_memtime stamps of workgroup 0)"
+        return leg
+
     eng = CTCDecoder(beam_width=100, blank_idx=0, after_logsoftmax=True, labels=labels, wip=1.0)._decoder
-    dt = timed(lambda: eng.decode(xb, xlb), 2)
-    out["beam100"] = {"workload": "B=64 T=1500 V=29 beam=100, no LM", "utterances_per_s": 64 / dt, "ms": dt * 1e3}
+    out["beam100"] = beam_leg(eng, "B=64 T=1500 V=29 beam=100, no LM", "no_lm")
     xbh = xb.double().cpu().numpy() if with_cpu else None
     if with_cpu:
         out["beam100"]["cpu_baseline"] = cpu_timed(
@@ -297,9 +320,7 @@ def decode_numbers(dev, with_cpu):
         synthetic_arpa(path, labels)
         eng = CTCDecoder(beam_width=100, blank_idx=0, after_logsoftmax=True, labels=labels, lm_path=path, lmwt=1.0,
                          wip=1.0, oov_penalty=-10.0)._decoder
-        dt = timed(lambda: eng.decode(xb, xlb), 2)
-        out["beam100_lm"] = {"workload": "B=64 T=1500 V=29 beam=100 + synthetic 3-gram ARPA (10k words)",
-                             "utterances_per_s": 64 / dt, "ms": dt * 1e3}
+        out["beam100_lm"] = beam_leg(eng, "B=64 T=1500 V=29 beam=100 + synthetic 3-gram ARPA (10k words)", "lm")
         if with_cpu:
             olm = O.OracleLM(path)
             out["beam100_lm"]["cpu_baseline"] = cpu_timed(
@@ -376,9 +397,18 @@ def shape_cliff_numbers(dev):
     return out
 
 
+def recorded_beam_phases():
+    """Per-phase s_memtime cycles of the fast beam kernel from the committed record (tools/diag/beam_phase_profile.py), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_beam_phases.json")) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
 def recorded_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)

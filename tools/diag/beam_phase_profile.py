@@ -30,6 +30,20 @@ tot = sum(buf[k] for k in range(15) if k != 10)
 for k, nm in enumerate(names):
     if k != 10 and buf[k]: print("%-30s %8.0f ticks/step (%4.1f%%)" % (nm, buf[k] / T, 100.0 * buf[k] / tot))
 print("total %.0f s_memtime ticks/step; radix passes per step %.2f" % (tot / T, buf[10] / T))
+if os.environ.get("BEAM_PHASES_JSON"):
+    # one record per configuration, merged into the file: {"no_lm": {...}, "lm": {...}}
+    import json
+    path = os.environ["BEAM_PHASES_JSON"]
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        rec = {}
+    rec["lm" if lm is not None else "no_lm"] = {
+        "workload": "B=64 T=%d V=29 beam=%d%s, workgroup 0" % (T, W, " + synthetic 3-gram ARPA" if lm is not None else ""),
+        "cycles_per_step": tot / T, "radix_passes_per_step": buf[10] / T,
+        "phase_cycles": {nm: buf[k] / T for k, nm in enumerate(names) if k != 10 and buf[k]},
+        "unit": "s_memtime ticks (shader cycles) per frame"}
+    json.dump(rec, open(path, "w"), indent=1)
 if lm is not None and hasattr(L, "e2e_debug_beam_sigs"):
     # how often does an LM state that has to ask come back later in the same utterance?
     L.e2e_debug_beam_sigs.argtypes = [C.c_void_p, C.c_int]
