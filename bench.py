@@ -91,9 +91,10 @@ class HotPath:
         self.dev = self.x.device
         B, T, V = self.x.shape
         self.B, self.T, self.V, self.S = B, T, V, self.targets.shape[1]
+        self.code = _lib.dtype_code(self.x.dtype)          # (16-bit logits: gradient in the same dtype, losses f32)
         self.losses = torch.empty(B, dtype=torch.float32, device=self.dev)
-        self.grads = torch.empty((B, T, V), dtype=torch.float32, device=self.dev)
-        n = self.L.e2e_ctc_loss_workspace_bytes(B, T, V, self.S, _lib.F32, _lib.ALGO_AUTO)
+        self.grads = torch.empty((B, T, V), dtype=self.x.dtype, device=self.dev)
+        n = self.L.e2e_ctc_loss_workspace_bytes(B, T, V, self.S, self.code, _lib.ALGO_AUTO)
         self.ws = torch.empty(n, dtype=torch.uint8, device=self.dev)
         self.blank = blank
         self.chains = chains                               # e2e_ctc_loss_opts.chains
@@ -110,7 +111,7 @@ class HotPath:
                               mean_out.data_ptr() if mean_out is not None else None,
                               self.lib.REDUCE_MEAN if mean_out is not None else self.lib.REDUCE_NONE, self.chains)
         self.lib.check(self.L.e2e_ctc_loss_fwd_bwd_opt(
-            self.x.data_ptr(), self.lib.F32, 0, sB, sT, sV,
+            self.x.data_ptr(), self.code, 0, sB, sT, sV,
             self.targets.data_ptr(), self.targets.stride(0), self.x_len.data_ptr(), self.t_len.data_ptr(),
             self.B, self.T, self.V, self.S, self.blank,
             self.losses.data_ptr(), self.grads.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
@@ -552,7 +553,7 @@ def main():
     c_abi_loss = float(hp.means[0, 0].item())
 
     # ---- leg 3: one GPU's share of configs[4] (V=8000), the HBM-bound shape, at every N ------------------------------
-    wide = None
+    wide = wide_bf16 = None
     if not args.no_wide:
         ww = WIDE
         _, wb = make_batch(5000 + rank, ww["B"], ww["T"], ww["V"], ww["S"], dev)
@@ -578,7 +579,22 @@ def main():
                              "frac": walgo / (wms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "note": "same C-ABI call as the headline; ms = device time per call (max over ranks), frames_per_s = "
                         "whole job over the wall clock of %d back-to-back calls" % reps}
-        del wp, wb
+        # the same share with bf16 logits, read and written natively: 2 * V * 2 algorithmic bytes per frame
+        wb16 = (wb[0].to(torch.bfloat16),) + tuple(wb[1:])
+        del wp
+        wp = HotPath(wb16)
+        for _ in range(2):
+            wp.call()
+        fence()
+        wms16 = max_over_ranks(time_events(torch, wp.call, reps))
+        walgo16 = 2.0 * ww["V"] * 2 * ww["B"] * ww["T"]
+        wide_bf16 = {"workload": "B=512 per GPU, T=256 V=8000 S<=64 bf16 logits in, bf16 gradient out (f32 lattice on the compact columns)",
+                     "n_gpus": n_gpus, "ms": wms16, "frames_per_s": n_gpus * ww["B"] * ww["T"] / (wms16 * 1e-3),
+                     "algorithmic_bytes_per_gpu": walgo16,
+                     "roofline": {"bound": "hbm", "achieved": walgo16 / (wms16 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": walgo16 / (wms16 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "note": "HIP events around each call (mean of %d); no f32 copy of the logits or of the gradient exists" % reps}
+        del wp, wb, wb16
         torch.cuda.empty_cache()
 
     if rank == 0:
@@ -625,6 +641,7 @@ def main():
             "max_grad_abs_dev_from_default": f32_grad_dev, "max_loss_rel_dev_from_default": f32_loss_dev}
         if wide is not None:
             out["wide_alphabet"] = wide
+            out["wide_alphabet_bf16"] = wide_bf16
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_loss(host_batch, frames)
         if n_gpus == 1 and not args.no_decode:

@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libe2e_ctc.so")
 
-F32, F64 = 0, 1
+F32, F64, F16, BF16 = 0, 1, 2, 3
 ALGO_AUTO, ALGO_EXACT, ALGO_FAST = 0, 1, 2
 ABI_VERSION = 2
 
@@ -114,6 +114,10 @@ def dtype_code(dt):
         return F32
     if dt == torch.float64:
         return F64
+    if dt == torch.float16:
+        return F16
+    if dt == torch.bfloat16:
+        return BF16
     raise TypeError("unsupported dtype %s" % dt)
 
 

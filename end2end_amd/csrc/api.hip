@@ -55,7 +55,7 @@ __global__ void scale_rows_kernel(IO* g, const IO* s, int64_t row_elems) {
   if (f == (IO)1) return;                  // nothing to do for this row: no pass over it
   IO* row = g + (size_t)blockIdx.y * (size_t)row_elems;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_elems; i += (int64_t)gridDim.x * blockDim.x)
-    row[i] *= f;
+    row[i] = (IO)(row[i] * f);             // (16-bit: the product in the source dtype's precision, as torch multiplies it)
 }
 
 // sum / mean of the B losses in a fixed order (deterministic), f64 accumulation
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void reduce_losses_kernel(const IO* losses, in
 int launch_reduce_losses(const LossArgs& a) {
   if (!a.reduced || a.reduction == E2E_REDUCE_NONE || a.B == 0) return E2E_OK;
   const int mean = a.reduction == E2E_REDUCE_MEAN;
-  if (a.dtype == E2E_F32)
+  if (a.dtype == E2E_F32 || dtype_is_16bit(a.dtype))          // (16-bit I/O keeps losses and their reduction in f32)
     hipLaunchKernelGGL(reduce_losses_kernel<float>, dim3(1), dim3(256), 0, a.stream, (const float*)a.losses, a.B, mean, (float*)a.reduced);
   else
     hipLaunchKernelGGL(reduce_losses_kernel<double>, dim3(1), dim3(256), 0, a.stream, (const double*)a.losses, a.B, mean, (double*)a.reduced);
@@ -95,6 +95,12 @@ int launch_scale(void* grads, int dtype, const void* scale, int B, int64_t row_e
   if (dtype == E2E_F32)
     hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(gx, B), dim3(256), 0, stream,
                        (float*)grads, (const float*)scale, row_elems);
+  else if (dtype == E2E_F16)
+    hipLaunchKernelGGL(scale_rows_kernel<f16_t>, dim3(gx, B), dim3(256), 0, stream,
+                       (f16_t*)grads, (const f16_t*)scale, row_elems);
+  else if (dtype == E2E_BF16)
+    hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, stream,
+                       (bf16_t*)grads, (const bf16_t*)scale, row_elems);
   else
     hipLaunchKernelGGL(scale_rows_kernel<double>, dim3(gx, B), dim3(256), 0, stream,
                        (double*)grads, (const double*)scale, row_elems);
@@ -143,7 +149,7 @@ static bool use_wide(int dtype, int T, int V, int Smax) {
 static int resolve_algo(int algo, int dtype, int T, int V, int Smax) {
   if (algo == E2E_ALGO_EXACT) return E2E_ALGO_EXACT;
   if (algo == E2E_ALGO_FAST) return E2E_ALGO_FAST;
-  return (dtype == E2E_F32 && (fast_supported(T, V, Smax, dtype) || wide_supported(T, V, Smax, dtype))) ? E2E_ALGO_AUTO : E2E_ALGO_EXACT;
+  return ((dtype == E2E_F32 || dtype_is_16bit(dtype)) && (fast_supported(T, V, Smax, dtype) || wide_supported(T, V, Smax, dtype))) ? E2E_ALGO_AUTO : E2E_ALGO_EXACT;
 }
 
 size_t e2e_ctc_loss_workspace_bytes(int B, int T, int V, int Smax, int dtype, int algo) {
@@ -184,7 +190,7 @@ int e2e_ctc_loss_fwd_bwd_opt(const void* x, int dtype, int input_is_logprobs,
   if (opts && opts->chains != E2E_CHAINS_F64 && opts->chains != E2E_CHAINS_F32) {
     set_error("bad e2e_ctc_loss_opts: chains %d", opts->chains); return E2E_ERR_ARG;
   }
-  if (dtype != E2E_F32 && dtype != E2E_F64) { set_error("dtype must be E2E_F32 or E2E_F64"); return E2E_ERR_ARG; }
+  if (dtype != E2E_F32 && dtype != E2E_F64 && !dtype_is_16bit(dtype)) { set_error("dtype must be E2E_F32, E2E_F64, E2E_F16 or E2E_BF16"); return E2E_ERR_ARG; }
   if (B < 0 || T < 1 || V < 1 || Smax < 0) { set_error("bad sizes B=%d T=%d V=%d Smax=%d", B, T, V, Smax); return E2E_ERR_ARG; }
   if (blank < 0 || blank >= V) { set_error("blank=%d outside [0,%d)", blank, V); return E2E_ERR_ARG; }
   if (B > 0 && (!x || !x_len || !t_len || !losses || !grads || (Smax > 0 && !targets))) {
@@ -201,8 +207,12 @@ int e2e_ctc_loss_fwd_bwd_opt(const void* x, int dtype, int input_is_logprobs,
   // AUTO with f32 I/O: wherever the exact kernel stands in for (or finishes) an f32 path it may use its scaled f64 form;
   // E2E_ALGO_EXACT and f64 always run the reference's log-domain arithmetic.  (E2E_EXACT_LOGDOMAIN=1: everywhere.)
   static const bool logdomain_only = [] { const char* e = getenv("E2E_EXACT_LOGDOMAIN"); return e && e[0] == '1'; }();
-  a.scaled_exact = (algo == E2E_ALGO_AUTO && dtype == E2E_F32 && !logdomain_only) ? 1 : 0;
+  a.scaled_exact = (algo == E2E_ALGO_AUTO && (dtype == E2E_F32 || dtype_is_16bit(dtype)) && !logdomain_only) ? 1 : 0;
   const int r = resolve_algo(algo, dtype, T, V, Smax);
+  if (dtype_is_16bit(dtype) && r == E2E_ALGO_EXACT) {
+    set_error("16-bit logits are taken by the fast and wide paths only (algo AUTO / FAST, shapes they support): up-cast to f32");
+    return E2E_ERR_UNSUPPORTED;
+  }
   if (r == E2E_ALGO_EXACT) { const int rc = launch_exact(a); return rc != E2E_OK ? rc : launch_reduce_losses(a); }
   if (use_wide(dtype, T, V, Smax)) {
     if (r == E2E_ALGO_FAST && !wide_takes_fast_lattice(T, V, Smax, dtype)) {
@@ -220,7 +230,7 @@ int e2e_ctc_loss_fwd_bwd_opt(const void* x, int dtype, int input_is_logprobs,
 }
 
 int e2e_ctc_scale_grads(void* grads, int dtype, const void* scale, int B, int64_t row_elems, void* stream) {
-  if (dtype != E2E_F32 && dtype != E2E_F64) { set_error("dtype must be E2E_F32 or E2E_F64"); return E2E_ERR_ARG; }
+  if (dtype != E2E_F32 && dtype != E2E_F64 && !dtype_is_16bit(dtype)) { set_error("dtype must be E2E_F32, E2E_F64, E2E_F16 or E2E_BF16"); return E2E_ERR_ARG; }
   if (B < 0 || row_elems < 0 || (B > 0 && row_elems > 0 && (!grads || !scale))) { set_error("bad argument"); return E2E_ERR_ARG; }
   return launch_scale(grads, dtype, scale, B, row_elems, (hipStream_t)stream);
 }
@@ -228,7 +238,7 @@ int e2e_ctc_scale_grads(void* grads, int dtype, const void* scale, int B, int64_
 int e2e_ctc_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV,
                    const int64_t* x_len, int B, int T, int V, int blank,
                    int64_t* out, int64_t* out_len, void* stream) {
-  if (dtype != E2E_F32 && dtype != E2E_F64) { set_error("dtype must be E2E_F32 or E2E_F64"); return E2E_ERR_ARG; }
+  if (dtype != E2E_F32 && dtype != E2E_F64 && !dtype_is_16bit(dtype)) { set_error("dtype must be E2E_F32, E2E_F64, E2E_F16 or E2E_BF16"); return E2E_ERR_ARG; }
   if (B < 0 || T < 1 || V < 1) { set_error("bad sizes B=%d T=%d V=%d", B, T, V); return E2E_ERR_ARG; }
   if (B > 0 && (!x || !x_len || !out || !out_len)) { set_error("null pointer argument"); return E2E_ERR_ARG; }
   return launch_greedy(x, dtype, sB, sT, sV, x_len, B, T, V, blank, out, out_len, (hipStream_t)stream);

@@ -12,6 +12,27 @@ namespace e2e {
 
 constexpr int kWave = 64;
 
+// 16-bit I/O types of the kernels (E2E_F16 / E2E_BF16): plain arithmetic types of the compiler, converted on load / store
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+inline bool dtype_is_16bit(int dtype) { return dtype == E2E_F16 || dtype == E2E_BF16; }
+// losses / reduced of a call: the I/O dtype, except that 16-bit calls keep them in f32 (include/e2e_ctc.h)
+template <typename IO> struct LossOf { typedef IO type; };
+template <> struct LossOf<f16_t> { typedef float type; };
+template <> struct LossOf<bf16_t> { typedef float type; };
+// one element of a tensor whose dtype is known at run time only (wave-uniform `dt`): used where a kernel is not worth an
+// instance per dtype
+__device__ __forceinline__ float load_elem(const void* base, int64_t idx, int dt) {
+  if (dt == E2E_F32) return reinterpret_cast<const float*>(base)[idx];
+  if (dt == E2E_BF16) return (float)reinterpret_cast<const bf16_t*>(base)[idx];
+  return (float)reinterpret_cast<const f16_t*>(base)[idx];
+}
+__device__ __forceinline__ void store_elem(void* base, size_t idx, float v, int dt) {
+  if (dt == E2E_F32) reinterpret_cast<float*>(base)[idx] = v;
+  else if (dt == E2E_BF16) reinterpret_cast<bf16_t*>(base)[idx] = (bf16_t)v;
+  else reinterpret_cast<f16_t*>(base)[idx] = (f16_t)v;
+}
+
 // thread-local error text behind e2e_last_error()
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);

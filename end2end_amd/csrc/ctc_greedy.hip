@@ -26,6 +26,11 @@ __device__ __forceinline__ bool better(F cand, int cand_i, F best, int best_i) {
   return cand > best || (cand == best && cand_i < best_i);
 }
 
+// (16-bit values travel between lanes as floats: the conversion is exact both ways)
+template <typename IO> __device__ __forceinline__ IO shfl_xor_io(IO v, int o) {
+  if constexpr (sizeof(IO) == 2) return (IO)__shfl_xor((float)v, o, 64); else return __shfl_xor(v, o, 64);
+}
+
 template <typename IO>
 __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(GreedyParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(GreedyParams p) {
         IO bv = row[0]; int bi = 0;   // every lane starts from element 0: a valid candidate
         for (int v = lane; v < V; v += 64) { const IO c = row[(int64_t)v * p.sV]; if (better(c, v, bv, bi)) { bv = c; bi = v; } }
         for (int o = 32; o > 0; o >>= 1) {
-          const IO ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+          const IO ov = shfl_xor_io(bv, o); const int oi = __shfl_xor(bi, o, 64);
           if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
         }
         if (lane == 0) sym[r] = bi;
@@ -238,7 +243,7 @@ int launch_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV, 
                   int B, int T, int V, int blank, int64_t* out, int64_t* out_len, hipStream_t stream) {
   GreedyParams p{x, sB, sT, sV, x_len, B, T, V, blank, out, out_len};
   if (B == 0) return E2E_OK;
-  const size_t esz = dtype == E2E_F32 ? 4 : 8;
+  const size_t esz = dtype == E2E_F32 ? 4 : dtype_is_16bit(dtype) ? 2 : 8;
   {
     // contiguous 16-byte aligned rows of a small alphabet: the streaming kernel
     const size_t lds_stream = (size_t)kStreamWaves * kChunk * (V | 1) * esz + 2 * kSuper;
@@ -251,6 +256,12 @@ int launch_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV, 
       if (dtype == E2E_F32) {
         if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<float, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
         else hipLaunchKernelGGL((ctc_greedy_stream_kernel<float, 16>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+      } else if (dtype == E2E_F16) {          // (16-bit logits: compared as they are -- the ordering of the source dtype, as torch.argmax sees it)
+        if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<f16_t, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        else hipLaunchKernelGGL((ctc_greedy_stream_kernel<f16_t, 16>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+      } else if (dtype == E2E_BF16) {
+        if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<bf16_t, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        else hipLaunchKernelGGL((ctc_greedy_stream_kernel<bf16_t, 16>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
       } else {
         if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<double, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
         else hipLaunchKernelGGL((ctc_greedy_stream_kernel<double, 16>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
@@ -262,6 +273,10 @@ int launch_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV, 
   const size_t lds = V <= kSmallV ? (size_t)kThreads * (V | 1) * esz : 16;
   if (dtype == E2E_F32)
     hipLaunchKernelGGL(ctc_greedy_kernel<float>, dim3(B), dim3(kThreads), lds, stream, p);
+  else if (dtype == E2E_F16)
+    hipLaunchKernelGGL(ctc_greedy_kernel<f16_t>, dim3(B), dim3(kThreads), lds, stream, p);
+  else if (dtype == E2E_BF16)
+    hipLaunchKernelGGL(ctc_greedy_kernel<bf16_t>, dim3(B), dim3(kThreads), lds, stream, p);
   else
     hipLaunchKernelGGL(ctc_greedy_kernel<double>, dim3(B), dim3(kThreads), lds, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_greedy_kernel launch");

@@ -348,7 +348,8 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
 
   const IO* x = reinterpret_cast<const IO*>(p.x) + (int64_t)b * p.sB;
   IO* grads = reinterpret_cast<IO*>(p.grads) + (size_t)b * (size_t)Tmax * (size_t)V;
-  IO* losses = reinterpret_cast<IO*>(p.losses);
+  typedef typename LossOf<IO>::type LT;
+  LT* losses = reinterpret_cast<LT*>(p.losses);
   double* wa = p.ws_alpha + (size_t)slot * (size_t)Tmax * (size_t)Lmax;
   double* wl = p.ws_lse + (size_t)slot * (size_t)Tmax;
 
@@ -356,7 +357,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   if (p.mode == 2 || Tq < 1 || Tq > Tmax || Sq < 0 || Sq > Smax) {   // invalid lengths: poison, do not crash
     const double qnan = __builtin_nan("");
-    if (tid == 0) losses[b] = (IO)qnan;
+    if (tid == 0) losses[b] = (LT)qnan;
     for (size_t i = tid; i < (size_t)Tmax * V; i += kThreads) grads[i] = (IO)qnan;
     return;
   }
@@ -378,7 +379,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
     // a target outside [0,V) would index the row and the per-label sums out of bounds (the reference reads garbage
     // there): poison like invalid lengths, do not crash
     const double qnan = __builtin_nan("");
-    if (tid == 0) losses[b] = (IO)qnan;
+    if (tid == 0) losses[b] = (LT)qnan;
     for (size_t i = tid; i < (size_t)Tmax * V; i += kThreads) grads[i] = (IO)qnan;
     __syncthreads();
     return;
@@ -404,7 +405,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
     blank_valued_label = any_blank != 0;
     if (!any_blank && T < total) {
       const double qnan = __builtin_nan("");
-      if (tid == 0) losses[b] = (IO)__builtin_huge_val();
+      if (tid == 0) losses[b] = (LT)__builtin_huge_val();
       for (size_t i = tid; i < (size_t)Tmax * V; i += kThreads) grads[i] = (IO)qnan;
       return;
     }
@@ -660,7 +661,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
       for (int t = T - 1; t >= 0; t -= kAhead) { bstep(t, br[0]); bstep(t - 1, br[1]); bstep(t - 2, br[2]); bstep(t - 3, br[3]); }
       ok = !__syncthreads_or(bad);
       if (ok) {
-        if (tid == 0) losses[b] = (IO)(-logZ);
+        if (tid == 0) losses[b] = (LT)(-logZ);
         // columns that are neither a label nor the blank: y itself, every row at once (nothing of the lattice in them)
         for (int t = wid; t < T; t += kThreads / 64) {
           const IO* row = x + (int64_t)t * p.sT;
@@ -714,7 +715,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
   // ---- P2: loss, ctc_loss.cpp:63-70 ----
   const double* last = ((T - 1) & 1) ? buf1 : buf0;
   const double logZ = (L > 1) ? lse2(last[L - 1], last[L - 2]) : last[L - 1];
-  if (tid == 0) losses[b] = (IO)(-logZ);
+  if (tid == 0) losses[b] = (LT)(-logZ);
   __syncthreads();
 
   const double qnan = __builtin_nan("");
@@ -853,12 +854,13 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   const bool reduce = p.reduced && p.reduction != E2E_REDUCE_NONE;
   auto write_reduction = [&](bool coherent) {
     if (reduce && tid < 64) {
-      const IO* losses = reinterpret_cast<const IO*>(p.losses);
+      typedef typename LossOf<IO>::type LT;
+      const LT* losses = reinterpret_cast<const LT*>(p.losses);
       double s = 0.0;
       for (int b = tid; b < p.B; b += 64)
         s += coherent ? (double)__hip_atomic_load(&losses[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (double)losses[b];
       for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      if (tid == 0) *reinterpret_cast<IO*>(p.reduced) = (IO)(p.reduction == E2E_REDUCE_MEAN ? s / (double)p.B : s);
+      if (tid == 0) *reinterpret_cast<LT*>(p.reduced) = (LT)(p.reduction == E2E_REDUCE_MEAN ? s / (double)p.B : s);
     }
   };
   if (!any) {
@@ -1013,14 +1015,15 @@ int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetr
   p.gscale = a.grad_scale; p.reduced = mode != 0 ? a.reduced : nullptr; p.reduction = a.reduction;
   if (mode != 0 && !p.ctl) { set_error("internal: flagged exact launch without control words"); return E2E_ERR_ARG; }
   // (eight pairs per lane -- targets beyond 255 labels -- have no f64 redo of the segments: the full recomputation takes them)
-  p.has_retry = (mode == 1 && retry && a.dtype == E2E_F32 && retry_waves(a.V) > 0 && retry->PPL <= 4) ? 1 : 0;
+  const bool f32_lattice = a.dtype == E2E_F32 || dtype_is_16bit(a.dtype);      // (16-bit I/O: the fast path's f32 lattice behind it)
+  p.has_retry = (mode == 1 && retry && f32_lattice && retry_waves(a.V) > 0 && retry->PPL <= 4) ? 1 : 0;
   p.redo_waves = retry_waves(a.V);
   if (p.has_retry) p.retry = *retry; else memset(&p.retry, 0, sizeof(p.retry));
   p.ws_alpha = reinterpret_cast<double*>(a.ws);
   p.ws_lse = reinterpret_cast<double*>(reinterpret_cast<char*>(a.ws) +
                                        align_up((size_t)slabs * a.T * p.Lmax * sizeof(double), 256));
   p.ws_exp = reinterpret_cast<int*>(reinterpret_cast<char*>(p.ws_lse) + align_up((size_t)slabs * a.T * sizeof(double), 256));
-  const bool scaled = a.scaled_exact && a.dtype == E2E_F32;
+  const bool scaled = a.scaled_exact && f32_lattice;
   p.scaled = scaled ? 1 : 0;
   const int grid = mode == 0 ? slabs : (a.B < kFallbackGrid ? a.B : kFallbackGrid);
   if (a.B == 0) return E2E_OK;
@@ -1031,7 +1034,12 @@ int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetr
     return E2E_OK;
   };
   int rc;
-  if (mode == 0) {
+  if (dtype_is_16bit(a.dtype)) {
+    // 16-bit I/O exists behind the fast / wide paths only (flagged utterances of an AUTO or FAST call)
+    if (mode == 0) { set_error("the exact kernel takes f32 / f64 logits (16-bit logits: algo AUTO)"); return E2E_ERR_UNSUPPORTED; }
+    if (a.dtype == E2E_F16) rc = scaled ? go(&ctc_exact_kernel<f16_t, true>) : go(&ctc_exact_kernel<f16_t, false>);
+    else rc = scaled ? go(&ctc_exact_kernel<bf16_t, true>) : go(&ctc_exact_kernel<bf16_t, false>);
+  } else if (mode == 0) {
     if (a.dtype != E2E_F32) rc = go(&ctc_exact_all_kernel<double, false>);
     else if (scaled) rc = go(&ctc_exact_all_kernel<float, true>);
     else rc = go(&ctc_exact_all_kernel<float, false>);

@@ -924,8 +924,11 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
   // gradient rows: y - posterior (d loss/d logits in fused mode; exp(lp) - posterior otherwise).  Lane v writes column
   // v of every row: its label's slots, its row of the probability tile and whether it is the blank are the same for
   // all rows (GradLanes); per row that leaves three LDS reads at constant offsets, three VALU operations and a store.
-  float* grads = p.grads + ((size_t)b * p.T + t0 + h * kHalf) * V;
-  if (!(E2E_F2_ABL & 2)) {
+  const size_t g0 = ((size_t)b * p.T + t0 + h * kHalf) * V;
+  // (the gradient has the logits' dtype: one copy of the passes per dtype, chosen by a uniform branch outside the row loops)
+  auto write_rows = [&](auto elem_tag) {
+    typedef decltype(elem_tag) E;
+    E* grads = reinterpret_cast<E*>(p.grads) + g0;
     // RPP rows per pass: the lane's row is k + rsel; the rows' normalisers and blank sums are wave-uniform, the lane picks its row's
     auto pass = [&](auto rpp_tag) {
       constexpr int RPP = decltype(rpp_tag)::value;
@@ -940,7 +943,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
           for (int j = 1; j < RPP; j++) { st = gl.rsel == j ? st8[k + j] : st; bt = gl.rsel == j ? btot8[k + j] : bt; }
           const float pv = (pre_hi[k * PROW] - pre_lo[k * PROW]) + gl.isblank[0] * bt;
           const float g = (yrow[k] - pv * __builtin_amdgcn_rcpf(st)) * p.gscale;
-          if (gl.goff >= 0 && (FULL || k + gl.rsel < rows)) grads[(size_t)k * V + gl.goff] = g;
+          if (gl.goff >= 0 && (FULL || k + gl.rsel < rows)) grads[(size_t)k * V + gl.goff] = (E)g;
         }
       }
     };
@@ -960,12 +963,15 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
             if (FULL || k < rows) {
               const float pv = (pre_hi[k * PROW] - pre_lo[k * PROW]) + gl.isblank[s] * btot8[k];
               const float g = (yrow[k] - pv * __builtin_amdgcn_rcpf(st8[k])) * p.gscale;
-              if (v < V) grads[(size_t)k * V + v] = g;
+              if (v < V) grads[(size_t)k * V + v] = (E)g;
             }
           }
         }
       }
     }
+  };
+  if (!(E2E_F2_ABL & 2)) {
+    if (p.xdt == E2E_F32) write_rows(float{}); else if (p.xdt == E2E_BF16) write_rows(bf16_t{}); else write_rows(f16_t{});
   }
   F2_LDS_ORDER   // Ps is rewritten by the next half
 }
@@ -1459,12 +1465,13 @@ __device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char*
   const int T = (int)Tq, S = (int)Sq;
   {
     // frames past the utterance's end: exp(lp) in log-prob mode (quirk Q1), zero for fused logits
-    float* grads = p.grads + (size_t)b * Tmax * V;
-    const float* x = p.x + (int64_t)b * p.sB;
+    const size_t g0 = (size_t)b * Tmax * V;
+    const int64_t xo = (int64_t)b * p.sB;
     const int tend = min(t0 + kSeg, Tmax);
     for (int t = max(t0, T); t < tend; t++)
       for (int v = lane; v < V; v += 64)
-        grads[(size_t)t * V + v] = p.logprobs ? expf(x[(int64_t)t * p.sT + (int64_t)v * p.sV]) * p.gscale : 0.f;
+        store_elem(p.grads, g0 + (size_t)t * V + v,
+                   p.logprobs ? expf(load_elem(p.x, xo + (int64_t)t * p.sT + (int64_t)v * p.sV, p.xdt)) * p.gscale : 0.f, p.xdt);
   }
   if (t0 >= T) return;
   const int n = min(t0 + kSeg, T) - t0;
@@ -1663,7 +1670,8 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
 
 bool fast_supported(int T, int V, int Smax, int dtype) {
   // (T: the halo chains tag their frame words with the block index in 19 bits)
-  return dtype == E2E_F32 && V >= 2 && V <= kMaxSmallV && ppl_for(Smax) != 0 && T < (1 << 22);
+  // (16-bit logits: read and written in their dtype around the same f32 lattice)
+  return (dtype == E2E_F32 || dtype_is_16bit(dtype)) && V >= 2 && V <= kMaxSmallV && ppl_for(Smax) != 0 && T < (1 << 22);
 }
 
 size_t fast_workspace_bytes(int B, int T, int V, int Smax) {
@@ -1680,10 +1688,10 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   if (a.B == 0) return E2E_OK;
   char* ws = reinterpret_cast<char*>(a.ws);
   FastParams p;
-  p.x = reinterpret_cast<const float*>(a.x); p.sB = a.sB; p.sT = a.sT; p.sV = a.sV; p.logprobs = a.logprobs;
+  p.x = a.x; p.xdt = a.dtype; p.sB = a.sB; p.sT = a.sT; p.sV = a.sV; p.logprobs = a.logprobs;
   p.targets = a.targets; p.tgt_stride = a.tgt_stride; p.x_len = a.x_len; p.t_len = a.t_len;
   p.B = a.B; p.T = a.T; p.V = a.V; p.Smax = a.Smax; p.blank = a.blank;
-  p.losses = reinterpret_cast<float*>(a.losses); p.grads = reinterpret_cast<float*>(a.grads);
+  p.losses = reinterpret_cast<float*>(a.losses); p.grads = a.grads;
   p.ytab = reinterpret_cast<float*>(ws + l.ytab);
   p.ckA = reinterpret_cast<float*>(ws + l.ckA); p.ckQ = reinterpret_cast<float*>(ws + l.ckQ);
   p.ckE = reinterpret_cast<short*>(ws + l.ckE);

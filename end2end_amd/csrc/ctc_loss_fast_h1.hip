@@ -400,7 +400,7 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
 #pragma unroll
   for (int k = 0; k < NV; k++) live[k] = k < kFull || l8 + 8 * k < V;
   const bool contig = p.sV == 1;
-  const float* xl = p.x + (int64_t)b * p.sB + (int64_t)l8 * p.sV;   // this lane's first column
+  const int64_t xl = (int64_t)b * p.sB + (int64_t)l8 * p.sV;        // this lane's first column (element offset)
   const int64_t cstep = 8 * p.sV;
   float* yl = p.ytab + (size_t)b * p.T * V + l8;
   const int t_first = DIR == 0 ? tt : 8 * M + 7 - tt;                // the lane's row in block 0; block n: t_first +- 8 n
@@ -417,14 +417,19 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
   auto load_block = [&](int n, float (&out)[NV]) {
     const int t = row_of(n);
     const int tc = min(max(t, 0), T - 1);
-    const float* xr = xl + (int64_t)tc * p.sT;
-    if (contig) {
+    const int64_t xr = xl + (int64_t)tc * p.sT;
+    auto rows = [&](auto elem_tag) {
+      typedef decltype(elem_tag) E;
+      const E* src = reinterpret_cast<const E*>(p.x) + xr;
+      if (contig) {
 #pragma unroll
-      for (int k = 0; k < NV; k++) out[k] = xr[(k < kFull || live[k]) ? 8 * k : 0];
-    } else {
+        for (int k = 0; k < NV; k++) out[k] = (float)src[(k < kFull || live[k]) ? 8 * k : 0];
+      } else {
 #pragma unroll
-      for (int k = 0; k < NV; k++) out[k] = xr[(k < kFull || live[k]) ? k * cstep : 0];
-    }
+        for (int k = 0; k < NV; k++) out[k] = (float)src[(k < kFull || live[k]) ? k * cstep : 0];
+      }
+    };
+    if (p.xdt == E2E_F32) rows(float{}); else if (p.xdt == E2E_BF16) rows(bf16_t{}); else rows(f16_t{});
   };
   int consumed = 0;
   float lpmin = 0.f;

@@ -12,6 +12,8 @@
 //   wide_rows_kernel + wide_emit_kernel  (any stride / width): the two-pass form, logits read twice (3*V*4 bytes per
 //                      frame): online max / sum-exp first, the dense gradient with the label columns afterwards
 // Reference semantics: src/losses/ctc_loss.cpp:102-117 (gradient over the full (T,V) slab, quirks Q1/Q2).
+#include <type_traits>
+
 #include "common.h"
 
 #pragma clang fp contract(fast)
@@ -22,7 +24,7 @@ namespace {
 constexpr int kWaves = 4;      // frames per workgroup
 
 struct WideParams {
-  const float* x; int64_t sB, sT, sV; int logprobs;
+  const float* x; int64_t sB, sT, sV; int logprobs;   // (16-bit logits: the dense kernels' instances reinterpret x / grads)
   const int64_t* targets; int64_t tgt_stride; const int64_t* x_len; const int64_t* t_len;
   int B, T, V, Smax, VC, blank;
   float gscale;         // every gradient element is multiplied by this as it is written
@@ -267,78 +269,110 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
 
 // ---- single-read form: the row stays in registers between the softmax's two passes ----
 typedef float vf4 __attribute__((ext_vector_type(4)));
-template <int NV4>          // float4 per lane: rows of up to 256*NV4 columns
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2)))      // (<= 256 VGPRs: two rows per SIMD in flight)
-void wide_rows_dense_kernel(WideParams p) {
+// E: the logits' (and the gradient's) element type -- float, or f16_t / bf16_t read and written 16 bytes (8 elements) at a
+// time and converted in registers: 2*V*sizeof(E) bytes per frame.  NV4: float4-equivalents of registers per lane, rows of
+// up to 256*NV4 columns either way.
+template <int NV4, typename E>
+__device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
+  constexpr int EPC = 16 / (int)sizeof(E);            // elements per 16-byte chunk
+  constexpr int NCH = NV4 * 4 / EPC;                  // chunks per lane
+  constexpr bool PACKED = sizeof(E) == 2;             // 16-bit rows stay packed in registers between the passes (below)
+  typedef E ev __attribute__((ext_vector_type(EPC)));
+  typedef float fv __attribute__((ext_vector_type(EPC)));
   // (the wave's row is made visibly uniform: the row pointers then live in scalar registers and every load / store is
-  // `scalar base + lane offset + immediate` -- with per-lane 64-bit addresses the 2*NV4 of them cost more VGPRs than the row)
+  // `scalar base + lane offset + immediate` -- with per-lane 64-bit addresses the 2*NCH of them cost more VGPRs than the row)
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row = (int64_t)blockIdx.x * kWaves + w;
   if (row >= (int64_t)p.B * p.T) return;
   const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
-  const float* xr = p.x + (int64_t)b * p.sB + (int64_t)t * p.sT;
-  vf4* g4 = reinterpret_cast<vf4*>(p.grads + (size_t)row * p.V);
-  const vf4* x4 = reinterpret_cast<const vf4*>(xr);
-  const int n4 = p.V >> 2;
+  const E* xr = reinterpret_cast<const E*>(p.x) + (int64_t)b * p.sB + (int64_t)t * p.sT;
+  ev* g4 = reinterpret_cast<ev*>(reinterpret_cast<E*>(p.grads) + (size_t)row * p.V);
+  const ev* x4 = reinterpret_cast<const ev*>(xr);
+  const int n4 = p.V / EPC;
   const bool bad_len = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
   const bool live = !bad_len && t < Tq;
   if (bad_len || (!live && !p.logprobs)) {         // invalid lengths: NaN; padded frame of fused logits: 0 (else exp(lp), Q1)
     const float f = bad_len ? __builtin_nanf("") : 0.f;
-    const vf4 o = {f, f, f, f};
+    fv of;
+#pragma unroll
+    for (int e = 0; e < EPC; e++) of[e] = f;
+    const ev o = __builtin_convertvector(of, ev);
     for (int i = lane; i < n4; i += 64) __builtin_nontemporal_store(o, &g4[i]);
     return;
   }
   const float ninf = -__builtin_huge_valf();
-  // Groups of 64 float4: all but at most one are complete (unconditional accesses at `scalar base + lane + immediate`);
+  // Groups of 64 chunks: all but at most one are complete (unconditional accesses at `scalar base + lane + immediate`);
   // in the one partial group the lanes past the row re-read -- and later re-write, with the same value -- the row's last
-  // float4 and are left out of the sum; groups past the row (a narrower alphabet than the instantiation holds) are
+  // chunk and are left out of the sum; groups past the row (a narrower alphabet than the instantiation holds) are
   // skipped by uniform branches.
-  vf4 v[NV4];
+  // f32 rows are held as they are.  16-bit rows are held PACKED (half the registers: four to five rows per SIMD in flight
+  // instead of two, which a row of half the bytes needs to keep the same number of bytes in flight -- converted to f32 the
+  // kernel ran 1.70 ms against the f32 kernel's 1.62 at V = 8000): every pass converts the chunk it works on, and the
+  // exponentials exp(x - max) in [0, 1] go back into the same registers in the row's own 16-bit type (the sum is taken
+  // from the unrounded values; the gradient is that value times 1/sum, rounded once more: <= 1.5 ulp of the output type).
+  typedef typename std::conditional<PACKED, ev, fv>::type held;
+  held v[NCH];
   const int last = n4 - 1;
-  const int part_idx = min(lane + (n4 & ~63), last);      // this lane's float4 in the partial group
+  const int part_idx = min(lane + (n4 & ~63), last);      // this lane's chunk in the partial group
   const bool part_in = lane + (n4 & ~63) <= last;
+  auto as_f32 = [](const held& h) -> fv { if constexpr (PACKED) return __builtin_convertvector(h, fv); else return h; };
+  auto to_held = [](const fv& f) -> held { if constexpr (PACKED) return __builtin_convertvector(f, ev); else return f; };
 #pragma unroll
-  for (int u = 0; u < NV4; u++) {
-    const vf4 none = {ninf, ninf, ninf, ninf};
-    if (64 * u + 64 <= n4) v[u] = __builtin_nontemporal_load(&x4[64 * u + lane]);
-    else if (64 * u < n4) v[u] = __builtin_nontemporal_load(&x4[part_idx]);
-    else v[u] = none;
+  for (int u = 0; u < NCH; u++) {
+    if (64 * u + 64 <= n4) { const ev r = __builtin_nontemporal_load(&x4[64 * u + lane]); if constexpr (PACKED) v[u] = r; else v[u] = __builtin_convertvector(r, fv); }
+    else if (64 * u < n4) { const ev r = __builtin_nontemporal_load(&x4[part_idx]); if constexpr (PACKED) v[u] = r; else v[u] = __builtin_convertvector(r, fv); }
+    else {
+      fv none;
+#pragma unroll
+      for (int e = 0; e < EPC; e++) none[e] = ninf;
+      v[u] = to_held(none);
+    }
   }
   float lse = 0.f;
   if (!p.logprobs) {
     float m = ninf;
 #pragma unroll
-    for (int u = 0; u < NV4; u++) m = fmaxf(m, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+    for (int u = 0; u < NCH; u++) {
+      const fv f = as_f32(v[u]);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) m = fmaxf(m, f[e]);
+    }
     const float M = wave_max_f(m);
     float sum = 0.f;
 #pragma unroll
-    for (int u = 0; u < NV4; u++) {
+    for (int u = 0; u < NCH; u++) {
       if (64 * u < n4) {
-        v[u].x = exp_acc(v[u].x - M); v[u].y = exp_acc(v[u].y - M); v[u].z = exp_acc(v[u].z - M); v[u].w = exp_acc(v[u].w - M);
-        const float part = (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        fv f = as_f32(v[u]);
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPC; e++) { f[e] = exp_acc(f[e] - M); part += f[e]; }
+        v[u] = to_held(f);
         sum += (64 * u + 64 <= n4 || part_in) ? part : 0.f;
       }
-      if (u & 1) __builtin_amdgcn_sched_barrier(0);       // (8 exps in flight are enough; interleaving all of them costs registers)
+      if ((u * EPC / 4) & 1) __builtin_amdgcn_sched_barrier(0);       // (8 exps in flight are enough; interleaving all of them costs registers)
     }
     sum = wave_sum_f(sum);
     const float inv = 1.f / sum;
     const float invg = inv * p.gscale;
     lse = M + logf(sum);
 #pragma unroll
-    for (int u = 0; u < NV4; u++) {
-      if (64 * u + 64 <= n4) __builtin_nontemporal_store(v[u] * invg, &g4[64 * u + lane]);
-      else if (64 * u < n4) __builtin_nontemporal_store(v[u] * invg, &g4[part_idx]);
+    for (int u = 0; u < NCH; u++) {
+      if (64 * u + 64 <= n4) __builtin_nontemporal_store(__builtin_convertvector(as_f32(v[u]) * invg, ev), &g4[64 * u + lane]);
+      else if (64 * u < n4) __builtin_nontemporal_store(__builtin_convertvector(as_f32(v[u]) * invg, ev), &g4[part_idx]);
       if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     if (lane == 0) p.lse[row] = lse;
   } else {
 #pragma unroll
-    for (int u = 0; u < NV4; u++) {
+    for (int u = 0; u < NCH; u++) {
       if (64 * u < n4) {
-        const vf4 o = {exp_acc(v[u].x), exp_acc(v[u].y), exp_acc(v[u].z), exp_acc(v[u].w)};
-        if (64 * u + 64 <= n4) __builtin_nontemporal_store(o * p.gscale, &g4[64 * u + lane]);
-        else __builtin_nontemporal_store(o * p.gscale, &g4[part_idx]);
+        const fv f = as_f32(v[u]);
+        fv o;
+#pragma unroll
+        for (int e = 0; e < EPC; e++) o[e] = exp_acc(f[e]);
+        if (64 * u + 64 <= n4) __builtin_nontemporal_store(__builtin_convertvector(o * p.gscale, ev), &g4[64 * u + lane]);
+        else __builtin_nontemporal_store(__builtin_convertvector(o * p.gscale, ev), &g4[part_idx]);
       }
       if (u & 1) __builtin_amdgcn_sched_barrier(0);
     }
@@ -350,7 +384,7 @@ void wide_rows_dense_kernel(WideParams p) {
   float cm = ninf;
   for (int k = lane; k < p.VC; k += 64) {
     const int l = cl[k];
-    const float val = l >= 0 ? xr[l] - lse : ninf;
+    const float val = l >= 0 ? (float)xr[l] - lse : ninf;
     xc[k] = val;
     cm = fmaxf(cm, val);
   }
@@ -360,7 +394,16 @@ void wide_rows_dense_kernel(WideParams p) {
   if (lane == 0) p.shift[row] = cm;
 }
 
+template <int NV4, typename E>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(2)))      // (<= 256 VGPRs: two rows per SIMD in flight)
+void wide_rows_dense_kernel(WideParams p) { wide_rows_dense_body<NV4, E>(p); }
+// 16-bit rows (held packed: see the body): three rows per SIMD in flight (four: 76 bytes of scratch per lane at V > 4096)
+template <int NV4, typename E>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(3)))
+void wide_rows_dense_kernel_16(WideParams p) { wide_rows_dense_body<NV4, E>(p); }
+
 // after the lattice: the label columns of the live frames; the slab of an utterance that turned out infeasible
+template <typename E>
 __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * kWaves + w;
@@ -368,12 +411,15 @@ __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
   const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   if (Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax) return;         // (poisoned by wide_rows_dense_kernel already)
-  float* gr = p.grads + (size_t)row * p.V;
+  E* gr = reinterpret_cast<E*>(p.grads) + (size_t)row * p.V;
   if (!(p.losses[b] < __builtin_huge_valf())) {                      // infeasible (Q2) / NaN: the whole slab
-    const float f = __builtin_nanf("");
-    const vf4 o = {f, f, f, f};
-    vf4* g4 = reinterpret_cast<vf4*>(gr);
-    for (int i = lane; i < (p.V >> 2); i += 64) __builtin_nontemporal_store(o, &g4[i]);
+    constexpr int EPC = 16 / (int)sizeof(E);
+    typedef E ev __attribute__((ext_vector_type(EPC)));
+    ev o;
+#pragma unroll
+    for (int e = 0; e < EPC; e++) o[e] = (E)__builtin_nanf("");
+    ev* g4 = reinterpret_cast<ev*>(gr);
+    for (int i = lane; i < p.V / EPC; i += 64) __builtin_nontemporal_store(o, &g4[i]);
     if (t < Tq) {
       // (no alignment AND a target equal to the blank id: the reference leaves -inf in the columns that have a cell with a
       //  finite alpha + beta -- see ctc_exact_one -- and the compact gradient carries that pattern)
@@ -382,7 +428,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the row's NaN stores have landed)
       for (int k = lane; k < p.VC; k += 64) {
         const int l = cl[k];
-        if (l >= 0 && gc[k] == -__builtin_huge_valf()) gr[l] = -__builtin_huge_valf();
+        if (l >= 0 && gc[k] == -__builtin_huge_valf()) gr[l] = (E)(-__builtin_huge_valf());
       }
     }
     return;
@@ -397,7 +443,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
   const float sh = p.shift[row];
   for (int k = lane; k < p.VC; k += 64) {
     const int l = cl[k];
-    if (l >= 0) gr[l] = (exp_acc(xc[k] + sh) - (exp_acc(xc[k]) - gc[k])) * p.gscale;
+    if (l >= 0) gr[l] = (E)((exp_acc(xc[k] + sh) - (exp_acc(xc[k]) - gc[k])) * p.gscale);
   }
 }
 
@@ -435,7 +481,7 @@ WideLayout wide_layout(int B, int T, int V, int Smax, bool with_exact) {
 }  // namespace
 
 bool wide_supported(int T, int V, int Smax, int dtype) {
-  if (!(dtype == E2E_F32 && V > 1 && Smax >= 0)) return false;
+  if (!((dtype == E2E_F32 || dtype_is_16bit(dtype)) && V > 1 && Smax >= 0)) return false;
   // (with the lattice left to the exact kernel the compaction must at least halve the columns to be worth its passes)
   return fast_supported(T, Smax + 1, Smax, dtype) || V >= 2 * (Smax + 1);
 }
@@ -462,9 +508,15 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
   p.lse = reinterpret_cast<float*>(ws + l.lse); p.shift = reinterpret_cast<float*>(ws + l.shift);
   p.xc = reinterpret_cast<float*>(ws + l.xc);
   p.gc = reinterpret_cast<const float*>(ws + l.gc);
-  const bool vec4 = a.sV == 1 && (a.sT % 4 == 0) && (a.sB % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0) &&
-                    (a.V % 4 == 0) && (reinterpret_cast<uintptr_t>(a.grads) % 16 == 0);
+  const bool io16 = dtype_is_16bit(a.dtype);
+  const int esz = io16 ? 2 : 4, epc = 16 / esz;    // element size, elements per 16-byte access
+  const bool vec4 = a.sV == 1 && (a.sT % epc == 0) && (a.sB % epc == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0) &&
+                    (a.V % epc == 0) && (reinterpret_cast<uintptr_t>(a.grads) % 16 == 0);
   const bool dense = vec4 && a.V <= 8192;          // the row fits a wave's registers: logits read once
+  if (io16 && !dense) {
+    set_error("16-bit logits on the wide path need contiguous rows of a multiple of 8 (<= 8192) columns, 16-byte aligned");
+    return E2E_ERR_UNSUPPORTED;
+  }
   hipLaunchKernelGGL(wide_compact_kernel, dim3(a.B), dim3(256), sizeof(int) * 3 * (a.Smax > 0 ? a.Smax : 1), a.stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "wide_compact_kernel launch");
 
@@ -472,15 +524,26 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
   // correction and the label-column fix-up on stream `s_lat`
   auto rows_part = [&](int b0, int nb, hipStream_t s_rows) -> int {
     WideParams q = p;
-    q.B = nb; q.x = p.x + (int64_t)b0 * a.sB; q.x_len = a.x_len + b0; q.t_len = a.t_len + b0;
-    q.grads = p.grads + (size_t)b0 * a.T * a.V; q.losses = p.losses + b0;
+    q.B = nb; q.x_len = a.x_len + b0; q.t_len = a.t_len + b0;
+    q.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.x) + (int64_t)b0 * a.sB * esz);
+    q.grads = reinterpret_cast<float*>(reinterpret_cast<char*>(p.grads) + (size_t)b0 * a.T * a.V * esz); q.losses = p.losses + b0;
     q.clabel = p.clabel + (size_t)b0 * l.VC; q.lse = p.lse + (size_t)b0 * a.T; q.shift = p.shift + (size_t)b0 * a.T;
     q.xc = p.xc + (size_t)b0 * a.T * l.VC; q.gc = p.gc + (size_t)b0 * a.T * l.VC;
     const dim3 grid_rows((unsigned)(((int64_t)nb * a.T + kWaves - 1) / kWaves));
     if (dense) {
-      if (a.V <= 2048) hipLaunchKernelGGL(wide_rows_dense_kernel<8>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
-      else if (a.V <= 4096) hipLaunchKernelGGL(wide_rows_dense_kernel<16>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
-      else hipLaunchKernelGGL(wide_rows_dense_kernel<32>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+      auto rows = [&](auto elem_tag) {
+        typedef decltype(elem_tag) E;
+        if constexpr (sizeof(E) == 2) {
+          if (a.V <= 2048) hipLaunchKernelGGL((wide_rows_dense_kernel_16<8, E>), grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+          else if (a.V <= 4096) hipLaunchKernelGGL((wide_rows_dense_kernel_16<16, E>), grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+          else hipLaunchKernelGGL((wide_rows_dense_kernel_16<32, E>), grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+        } else {
+          if (a.V <= 2048) hipLaunchKernelGGL((wide_rows_dense_kernel<8, E>), grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+          else if (a.V <= 4096) hipLaunchKernelGGL((wide_rows_dense_kernel<16, E>), grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+          else hipLaunchKernelGGL((wide_rows_dense_kernel<32, E>), grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+        }
+      };
+      if (a.dtype == E2E_F16) rows(f16_t{}); else if (a.dtype == E2E_BF16) rows(bf16_t{}); else rows(float{});
     } else if (vec4) hipLaunchKernelGGL(wide_rows_kernel<true>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
     else hipLaunchKernelGGL(wide_rows_kernel<false>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
     E2E_HIP_CHECK(hipGetLastError(), "wide rows kernel launch");
@@ -488,8 +551,9 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
   };
   auto lattice_part = [&](int b0, int nb, hipStream_t s_lat) -> int {
     WideParams q = p;
-    q.B = nb; q.x = p.x + (int64_t)b0 * a.sB; q.x_len = a.x_len + b0; q.t_len = a.t_len + b0;
-    q.grads = p.grads + (size_t)b0 * a.T * a.V; q.losses = p.losses + b0;
+    q.B = nb; q.x_len = a.x_len + b0; q.t_len = a.t_len + b0;
+    q.x = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.x) + (int64_t)b0 * a.sB * esz);
+    q.grads = reinterpret_cast<float*>(reinterpret_cast<char*>(p.grads) + (size_t)b0 * a.T * a.V * esz); q.losses = p.losses + b0;
     q.clabel = p.clabel + (size_t)b0 * l.VC; q.lse = p.lse + (size_t)b0 * a.T; q.shift = p.shift + (size_t)b0 * a.T;
     q.xc = p.xc + (size_t)b0 * a.T * l.VC; q.gc = p.gc + (size_t)b0 * a.T * l.VC;
     const dim3 grid_rows((unsigned)(((int64_t)nb * a.T + kWaves - 1) / kWaves));
@@ -521,7 +585,11 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
     }
     hipLaunchKernelGGL(wide_loss_fix_kernel, dim3(nb), dim3(64), 0, s_lat, q);
     E2E_HIP_CHECK(hipGetLastError(), "wide_loss_fix_kernel launch");
-    if (dense) hipLaunchKernelGGL(wide_fix_kernel, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
+    if (dense) {
+      if (a.dtype == E2E_F16) hipLaunchKernelGGL(wide_fix_kernel<f16_t>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
+      else if (a.dtype == E2E_BF16) hipLaunchKernelGGL(wide_fix_kernel<bf16_t>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
+      else hipLaunchKernelGGL(wide_fix_kernel<float>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
+    }
     else if (vec4) hipLaunchKernelGGL(wide_emit_kernel<true>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
     else hipLaunchKernelGGL(wide_emit_kernel<false>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
     E2E_HIP_CHECK(hipGetLastError(), "wide emit kernel launch");

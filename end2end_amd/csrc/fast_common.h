@@ -28,11 +28,12 @@ constexpr int kRow = 10;        // doubles per label row of a ring block: 8 step
 constexpr int kMaxSmallV = 96;  // alphabet columns the lattice kernels take (prep: <= 12 columns per lane)
 
 struct FastParams {
-  const float* x; int64_t sB, sT, sV; int logprobs;
+  const void* x; int xdt;          // logits / log-probabilities and their dtype (E2E_F32 / E2E_F16 / E2E_BF16); the gradient has the same
+  int64_t sB, sT, sV; int logprobs;
   const int64_t* targets; int64_t tgt_stride;
   const int64_t* x_len; const int64_t* t_len;
   int B, T, V, Smax, blank;
-  float* losses; float* grads;
+  float* losses; void* grads;     // (losses: f32 also for 16-bit I/O)
   float* ytab;     // [B][T][V]  probabilities y_t[v]
   float* ckA;      // [B][NS][CELLS]  row k: alpha row at t = 16k-1 (k >= 1)
   float* ckQ;      // [B][NS][CELLS]  row k: beta-with-emission row at t = 16k (k >= 1)
@@ -400,7 +401,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
   constexpr bool HALO = MODE != 0;
   const int V = p.V;
   const int nblk = (T + kBlk - 1) / kBlk;
-  const float* x = p.x + (int64_t)b * p.sB;
+  const int64_t xo = (int64_t)b * p.sB;
   float* ytab = p.ytab + (size_t)b * p.T * V;
   const int tt = lane >> 3, l8 = lane & 7;
   const float ninf = -__builtin_huge_valf();
@@ -418,9 +419,17 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
   auto load_block = [&](int n, float (&out)[NV]) {
     const int t = block_time(dir, n, tt, T);
     const bool row_live = n < nblk && t < T;
-    const float* xr = x + (int64_t)(row_live ? t : 0) * p.sT;
+    const int64_t xr = xo + (int64_t)(row_live ? t : 0) * p.sT;
+    if (p.xdt == E2E_F32) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) out[k] = xr[col_off[k]];
+      for (int k = 0; k < NV; k++) out[k] = reinterpret_cast<const float*>(p.x)[xr + col_off[k]];
+    } else if (p.xdt == E2E_BF16) {
+#pragma unroll
+      for (int k = 0; k < NV; k++) out[k] = (float)reinterpret_cast<const bf16_t*>(p.x)[xr + col_off[k]];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV; k++) out[k] = (float)reinterpret_cast<const f16_t*>(p.x)[xr + col_off[k]];
+    }
   };
   int consumed = 0;                 // blocks the ring's readers are known to have finished with (HALO)
   float lpmin = 0.f;                // smallest FINITE log-probability this wave has seen (alpha-side producers)

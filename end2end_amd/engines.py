@@ -50,11 +50,27 @@ class CTCLossEngine:
             raise ValueError("logits must be (batch, time, alphabet)")
         src_device, src_dtype = logits.device, logits.dtype
         dev = R.compute_device(logits)
-        x = logits.detach()
+        x = logits.detach().to(dev)
+        if x.dtype in (torch.float16, torch.bfloat16) and self.algo != R.ALGO_EXACT:
+            # 16-bit logits (raw autocast outputs): the fast and wide paths read them as they are and write the gradient in
+            # the same dtype -- no f32 copy of the (B,T,V) tensors (the reference converts once to double,
+            # src/losses/forward_backward.cpp:15,55-56).  Shapes those paths do not take are up-cast below.
+            try:
+                return self._compute_on_device(x, src_device, src_dtype, dev, targets, logits_lengths, targets_lengths,
+                                               input_is_logprobs, grad_scale, reduction)
+            except R.E2EError as err:
+                if "up-cast" not in str(err) and "16-bit" not in str(err):
+                    raise
         if x.dtype not in (torch.float32, torch.float64):
             x = x.to(torch.float32)
-        x = x.to(dev)
+        return self._compute_on_device(x, src_device, src_dtype, dev, targets, logits_lengths, targets_lengths,
+                                       input_is_logprobs, grad_scale, reduction)
+
+    def _compute_on_device(self, x, src_device, src_dtype, dev, targets, logits_lengths, targets_lengths,
+                           input_is_logprobs, grad_scale, reduction):
         B, T, V = x.shape
+        half = x.dtype in (torch.float16, torch.bfloat16)
+        loss_dtype = torch.float32 if half else x.dtype        # (16-bit I/O: the library keeps losses in f32)
         targets = _as_long(targets, dev)
         if targets.dim() != 2 or targets.shape[0] != B:
             raise ValueError("targets must be (batch, max_target_length)")
@@ -63,14 +79,14 @@ class CTCLossEngine:
         if xl.numel() != B or tl.numel() != B:
             raise ValueError("lengths must have one entry per utterance")
         Smax = targets.shape[1]
-        losses = torch.empty(B, dtype=x.dtype, device=dev)
+        losses = torch.empty(B, dtype=loss_dtype, device=dev)
         grads = torch.empty((B, T, V), dtype=x.dtype, device=dev)
         if reduction not in (None, "sum", "mean"):
             raise ValueError("reduction must be None, 'sum' or 'mean'")
         if B == 0:
             out = (losses.to(src_device, src_dtype), grads.to(src_device, src_dtype))
             return out if reduction is None else out + (getattr(out[0], reduction)(),)
-        reduced = torch.empty((), dtype=x.dtype, device=dev) if reduction else None
+        reduced = torch.empty((), dtype=loss_dtype, device=dev) if reduction else None
         code = R.dtype_code(x.dtype)
         with torch.cuda.device(dev):
             nbytes = _C.ctc_loss_workspace_bytes(B, T, V, Smax, code, self.algo)
@@ -84,11 +100,12 @@ class CTCLossEngine:
                                 reduced.data_ptr() if reduction else 0,
                                 {None: _C.REDUCE_NONE, "sum": _C.REDUCE_SUM, "mean": _C.REDUCE_MEAN}[reduction],
                                 _C.CHAINS_F32 if self.f32_chains else _C.CHAINS_F64)
-        if src_device != dev or src_dtype != x.dtype:
+        if src_device != dev or src_dtype != losses.dtype:
             losses = losses.to(src_device, src_dtype)
-            grads = grads.to(src_device, src_dtype)
             if reduction:
                 reduced = reduced.to(src_device, src_dtype)
+        if src_device != dev or src_dtype != grads.dtype:
+            grads = grads.to(src_device, src_dtype)
         return (losses, grads) if reduction is None else (losses, grads, reduced)
 
     @staticmethod
@@ -194,12 +211,13 @@ class CTCDecoderEngine:
             rows = rows.tolist()
         return ["".join(self.labels[k] for k in row[:n] if k >= 0) for row, n in zip(rows, lens)]
 
-    def _prep(self, logits_, logits_lengths_):
+    def _prep(self, logits_, logits_lengths_, native16=False):
         if logits_.dim() != 3:
             raise ValueError("logits must be (batch, time, alphabet)")
         dev = R.compute_device(logits_)
         x = logits_.detach()
-        if x.dtype not in (torch.float32, torch.float64):
+        # (16-bit logits: the greedy kernels compare them as they are; the beam search takes f32 / f64 log-probabilities)
+        if x.dtype not in ((torch.float32, torch.float64, torch.float16, torch.bfloat16) if native16 else (torch.float32, torch.float64)):
             x = x.to(torch.float32)
         x = x.to(dev)
         xl = _as_long(logits_lengths_, dev)
@@ -218,7 +236,7 @@ class CTCDecoderEngine:
 
     def decode_greedy(self, logits_, logits_lengths_):
         """argmax + blank/repeat collapse -> (targets (B,Tmax) int64 zero padded, lengths (B), sentences)."""
-        x, xl, dev = self._prep(logits_, logits_lengths_)
+        x, xl, dev = self._prep(logits_, logits_lengths_, native16=True)
         B, T, V = x.shape
         out = torch.empty((B, T), dtype=torch.long, device=dev)
         out_len = torch.empty(B, dtype=torch.long, device=dev)

@@ -48,11 +48,11 @@ class ForwardBackwardLossFunction(Function):
         if grads is None:          # a retained graph walked again: the first walk gave the buffer to autograd
             grads = ForwardBackwardLossFunction._compute(ctx.engine, ctx.args, ctx.fused_logits, ctx.reduction)[1]
         ctx.grads = None
-        if (grads.is_cuda and grads.is_contiguous() and grads.dtype in (torch.float32, torch.float64)
+        if (grads.is_cuda and grads.is_contiguous()
+                and grads.dtype in (torch.float32, torch.float64, torch.float16, torch.bfloat16)
                 and hasattr(ctx.engine, "scale_grads_")):
-            ctx.engine.scale_grads_(grads, grad_output)
-        else:                      # results moved back to a CPU source tensor, or to a half / bf16 source dtype (the
-                                   # in-place kernel takes f32 / f64; upstream multiplies in the source dtype as well)
+            ctx.engine.scale_grads_(grads, grad_output)      # (16-bit gradients: multiplied in their own dtype, as upstream)
+        else:                      # results moved back to a CPU source tensor
             go = grad_output.contiguous().to(device=grads.device, dtype=grads.dtype)
             grads = grads * (go.view(-1, 1, 1) if go.numel() > 1 else go)
         if grads.device != grad_output.device:

@@ -30,6 +30,13 @@ extern "C" {
 /* element types of the logits / log-prob tensor (losses and grads use the same) */
 #define E2E_F32 0
 #define E2E_F64 1
+/* 16-bit inputs (e2e_ctc_loss_fwd_bwd(_opt) under E2E_ALGO_AUTO / E2E_ALGO_FAST, e2e_ctc_greedy): the logits are read in
+ * their own dtype, the lattice runs in f32 (fast / wide path; reference: src/losses/forward_backward.cpp:15 converts once
+ * to double), and the gradient is written in the source dtype.  `losses` and `reduced` are FLOAT32 for these two -- a
+ * loss of a few hundred has three digits in bf16 --; the Python engine converts the B losses at the end.  Shapes the
+ * fast and wide paths do not take return E2E_ERR_UNSUPPORTED for these dtypes (up-cast and call again). */
+#define E2E_F16 2
+#define E2E_BF16 3
 
 #define E2E_OK 0
 #define E2E_ERR_ARG (-1)          /* bad argument (null pointer, bad size/dtype) */

@@ -41,6 +41,23 @@ def test_random_bit_exact(shape, dtype):
         assert np.array_equal(out, o_out)        # includes the zero padding (Q5)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(6, 500, 29), (3, 70, 5), (2, 40, 200), (2, 33, 8000), (3, 257, 64)])
+def test_sixteen_bit_logits_are_compared_as_they_are(shape, dtype):
+    """Native 16-bit input: argmax in the source dtype's ordering (what torch.argmax of that tensor gives), first maximum on
+    ties -- and rounding to 16 bits makes ties frequent --, bit-exact against the oracle on the same rounded values; both
+    the streaming kernel (contiguous small alphabets) and the general one (a strided view, wide alphabets)."""
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    B, T, V = shape
+    x = (torch.randn(B, T, V, generator=g) * 3).to(dtype)
+    xl = torch.randint(1, T + 1, (B,), generator=g)
+    xl[0] = T
+    for view in (x, x.permute(1, 0, 2).contiguous().permute(1, 0, 2)):
+        out, lens = U.c_abi_greedy(view, xl, 0)
+        o_out, o_len = O.ctc_greedy(x.double().numpy(), xl.numpy(), 0)
+        assert np.array_equal(lens, o_len) and np.array_equal(out, o_out)
+
+
 def test_time_major_view_and_full_c3_properties():
     g = torch.Generator().manual_seed(3)
     B, T, V = 1024, 1500, 29

@@ -235,7 +235,7 @@ def test_module_with_f32_chains_trains_like_the_default():
 @pytest.mark.parametrize("reduce", [False, True])
 def test_half_precision_logits_go_forward_and_backward(dtype, reduce):
     """Raw autocast outputs: the reference casts to double and back (src/losses/forward_backward.cpp:15,55-56); here the
-    lattice runs in f32 on the up-cast logits and loss / gradient come back in the source dtype."""
+    kernels read the 16-bit logits as they are, the lattice runs in f32 and loss / gradient come back in the source dtype."""
     g = torch.Generator().manual_seed(31)
     B, T, V, S = 3, 40, 11, 7
     x0 = torch.randn(B, T, V, generator=g).to(dtype)
@@ -256,3 +256,43 @@ def test_half_precision_logits_go_forward_and_backward(dtype, reduce):
     U.assert_same(x.grad.float().cpu().numpy(), want, 4 * eps, 4 * eps, "input grad")
     got_l = loss.detach().float().cpu().numpy()
     U.assert_same(got_l, l_o.mean() if reduce else l_o, 4 * eps, 4 * eps, "loss")
+
+
+@pytest.mark.parametrize("shape", [(8, 200, 48, 30), (4, 64, 8000, 20)], ids=["fast_path_V48", "wide_path_V8000"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_half_precision_logits_are_read_and_written_natively(dtype, shape):
+    """No f32 copy of the (B,T,V) logits or of the gradient is made for 16-bit inputs: the allocator's peak over a
+    forward + backward stays below what ONE f32 copy would add (the call allocates the 16-bit gradient, the B losses and
+    nothing of the tensor's size besides; the workspace is cached by the warm-up call).  Values against the oracle on the
+    rounded logits, at the source dtype's resolution."""
+    B, T, V, S = shape
+    g = torch.Generator().manual_seed(5)
+    x0 = (torch.randn(B, T, V, generator=g) * 1.5).to(dtype)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl = torch.full((B,), T); xl[1] = T - 9
+    tl = torch.randint(S // 2, S + 1, (B,), generator=g)
+    crit = CTCLoss(reduce=True, size_average=True)
+
+    def run():
+        x = x0.clone().cuda().requires_grad_()
+        loss = crit(x, tg, xl, tl)
+        loss.backward()
+        return x, loss
+    run()                                                   # warm-up: workspace, module state
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    x, loss = run()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    n16 = B * T * V * 2
+    # x (clone) + its gradient + small change; an f32 copy of either tensor would add 2 * n16 on top
+    assert peak < 2 * n16 + n16 // 2 + (1 << 16), "peak %d bytes for a %d-byte tensor: something of f32 size was allocated" % (peak, n16)
+    assert x.grad.dtype == dtype and loss.dtype == dtype
+    lp = torch.log_softmax(x0.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    U.assert_same(x.grad.float().cpu().numpy(), g_o / B, 4 * eps, 4 * eps / B, "input grad")
+    U.assert_same(loss.detach().float().cpu().numpy(), l_o.mean(), 4 * eps, 4 * eps, "loss")
