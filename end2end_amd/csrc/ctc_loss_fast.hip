@@ -789,6 +789,9 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
 #ifndef E2E_F2_ABL                  // tools/diag: timing builds with parts of the segment kernel switched off (results meaningless)
 #define E2E_F2_ABL 0
 #endif
+// the segment kernel's parameters with the gradient's element width as a compile-time fact (an instance per width: three
+// copies of the gradient passes behind a run-time test cost the f32 kernel 80 bytes of scratch and 5 us)
+template <bool O16> struct SegParams : FastParams { static constexpr bool kOut16 = O16; };
 constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before they are summed and written out
 // Between the segment wave's LDS phases (scatter -> scan -> per-label reads -> next half's scatter).  The LDS executes one
 // wave's operations in order, so a read issued after a write of the same wave sees it without a wait; only the compiler has
@@ -801,8 +804,8 @@ constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before 
 #define F2_LDS_ORDER asm volatile("" ::: "memory");
 #endif
 #ifndef E2E_F2_HALF                 // four pairs per lane: keep eight of the segment's alpha rows and compute the other eight twice
-#define E2E_F2_HALF 1
-#endif
+#define E2E_F2_HALF 0              // (three waves per SIMD, 92 bytes of scratch, 8 more alpha steps: the kernel takes 61.8 - 63.0 us
+#endif                             //  against 61.3 with all sixteen rows kept: not on)
 #ifndef E2E_SMIN                    // (both overridable for tools/diag experiments)
 #define E2E_SMIN 0x1p-120f         // smallest row sum sum_j alpha*beta the gradient rows are trusted with
 #endif
@@ -860,8 +863,8 @@ struct GradLanes {
 };
 
 // rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows.  FULL: all 8 rows are live.
-template <int PPL, bool FULL>
-__device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, int n, int h, const F2Lds<PPL>& lds,
+template <int PPL, bool FULL, typename P>
+__device__ __forceinline__ void finish_rows(const P& p, int b, int t0, int n, int h, const F2Lds<PPL>& lds,
                                             const GradLanes& gl, const float (&pb)[kHalf], int lane, float& smin, float& smax,
                                             int u_lo, int u_hi, float zfrac) {
   constexpr int PROW = F2Lds<PPL>::PROW;
@@ -925,10 +928,16 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
   // v of every row: its label's slots, its row of the probability tile and whether it is the blank are the same for
   // all rows (GradLanes); per row that leaves three LDS reads at constant offsets, three VALU operations and a store.
   const size_t g0 = ((size_t)b * p.T + t0 + h * kHalf) * V;
-  // (the gradient has the logits' dtype: one copy of the passes per dtype, chosen by a uniform branch outside the row loops)
-  auto write_rows = [&](auto elem_tag) {
-    typedef decltype(elem_tag) E;
-    E* grads = reinterpret_cast<E*>(p.grads) + g0;
+  // (the gradient has the logits' dtype: f32, or -- P::kOut16 -- one of the two 16-bit types, chosen per store without a branch)
+  const bool out_bf16 = p.xdt == E2E_BF16;
+  auto put = [&](size_t idx, float g) {
+    if constexpr (!P::kOut16) reinterpret_cast<float*>(p.grads)[g0 + idx] = g;
+    else {
+      const unsigned short hb = __builtin_bit_cast(unsigned short, (bf16_t)g), hh = __builtin_bit_cast(unsigned short, (f16_t)g);
+      reinterpret_cast<unsigned short*>(p.grads)[g0 + idx] = out_bf16 ? hb : hh;
+    }
+  };
+  if (!(E2E_F2_ABL & 2)) {
     // RPP rows per pass: the lane's row is k + rsel; the rows' normalisers and blank sums are wave-uniform, the lane picks its row's
     auto pass = [&](auto rpp_tag) {
       constexpr int RPP = decltype(rpp_tag)::value;
@@ -943,7 +952,7 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
           for (int j = 1; j < RPP; j++) { st = gl.rsel == j ? st8[k + j] : st; bt = gl.rsel == j ? btot8[k + j] : bt; }
           const float pv = (pre_hi[k * PROW] - pre_lo[k * PROW]) + gl.isblank[0] * bt;
           const float g = (yrow[k] - pv * __builtin_amdgcn_rcpf(st)) * p.gscale;
-          if (gl.goff >= 0 && (FULL || k + gl.rsel < rows)) grads[(size_t)k * V + gl.goff] = (E)g;
+          if (gl.goff >= 0 && (FULL || k + gl.rsel < rows)) put((size_t)k * V + gl.goff, g);
         }
       }
     };
@@ -963,15 +972,12 @@ __device__ __forceinline__ void finish_rows(const FastParams& p, int b, int t0, 
             if (FULL || k < rows) {
               const float pv = (pre_hi[k * PROW] - pre_lo[k * PROW]) + gl.isblank[s] * btot8[k];
               const float g = (yrow[k] - pv * __builtin_amdgcn_rcpf(st8[k])) * p.gscale;
-              if (v < V) grads[(size_t)k * V + v] = (E)g;
+              if (v < V) put((size_t)k * V + v, g);
             }
           }
         }
       }
     }
-  };
-  if (!(E2E_F2_ABL & 2)) {
-    if (p.xdt == E2E_F32) write_rows(float{}); else if (p.xdt == E2E_BF16) write_rows(bf16_t{}); else write_rows(f16_t{});
   }
   F2_LDS_ORDER   // Ps is rewritten by the next half
 }
@@ -1028,8 +1034,8 @@ struct SegIn {
 };
 
 // FULL: an interior segment (16 live steps, neither t = 0 nor t = T-1 inside): no guards in the loops.
-template <int PPL, bool FULL>
-__device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg, int T, int S, int n,
+template <int PPL, bool FULL, typename P>
+__device__ __forceinline__ void segment_body(const P& p, int b, int seg, int T, int S, int n,
                                              const LaneCells<PPL>& lc, const int (&rank)[PPL],
                                              const SegIn<PPL>& in,
                                              const F2Lds<PPL>& lds, const GradLanes& gl, int lane, float& smin, float& smax) {
@@ -1241,8 +1247,8 @@ __device__ __forceinline__ void segment_body(const FastParams& p, int b, int seg
 // from pairs 1, 3), and for the other group one DPP move and one plain move assemble it.  The emission factors stay
 // scalar multiplies (a lane's labels sit in different rows of the probability tile).  Same arithmetic as segment_body,
 // cell for cell; 14 + 21 vector instructions per row instead of 22 + 30.
-template <bool FULL>
-__device__ __forceinline__ void segment_body_pk(const FastParams& p, int b, int seg, int T, int S, int n,
+template <bool FULL, typename P>
+__device__ __forceinline__ void segment_body_pk(const P& p, int b, int seg, int T, int S, int n,
                                                 const LaneCells<4>& lc, const int (&rank)[4], const SegIn<4>& in,
                                                 const F2Lds<4>& lds, const GradLanes& gl, int lane, float& smin, float& smax) {
   constexpr int PPL = 4, NC = 8;
@@ -1423,8 +1429,8 @@ __device__ __forceinline__ void segment_body_pk(const FastParams& p, int b, int 
   }
 }
 
-template <int PPL>
-__device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char* smem) {
+template <int PPL, typename P>
+__device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   const int b = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
   const int V = p.V, Tmax = p.T, t0 = seg * kSeg;
   const F2Lds<PPL> lds(smem, V);
@@ -1548,10 +1554,21 @@ __device__ __forceinline__ void segment_wave(const FastParams& p, unsigned char*
 #define E2E_F2_LDSPAD 0
 #endif
 // (eight pairs per lane: 16 alpha rows of 16 cells are 256 registers by themselves -- one wave per SIMD, no spills)
-template <int PPL>
+template <int PPL, bool O16>
 __global__ E2E_KERNEL_ALIGN __launch_bounds__(64, PPL == 8 ? 1 : PPL == 4 ? E2E_F2_MINW4 : E2E_F2_MINW) void ctc_fast_segment_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  segment_wave<PPL>(p, smem);
+  SegParams<O16> q;
+  static_cast<FastParams&>(q) = p;
+  segment_wave<PPL>(q, smem);
+}
+
+// the segment kernel behind a chain kernel: the instance of the gradient's element width
+template <int PPL>
+int launch_segments(const FastParams& p, size_t lds, hipStream_t stream) {
+  if (dtype_is_16bit(p.xdt)) hipLaunchKernelGGL((ctc_fast_segment_kernel<PPL, true>), dim3(p.NS, p.B), dim3(64), lds, stream, p);
+  else hipLaunchKernelGGL((ctc_fast_segment_kernel<PPL, false>), dim3(p.NS, p.B), dim3(64), lds, stream, p);
+  E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
+  return E2E_OK;
 }
 
 // (Two waves per segment -- a 128-thread workgroup, two label pairs per lane, the waves' lattice halves overlapping by 18
@@ -1570,9 +1587,7 @@ int launch_fast_long(const FastParams& p, hipStream_t stream) {
   E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<8, ChainF64L>), hl.total), "hipFuncSetAttribute");
   hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<8, ChainF64L>), dim3(p.B), dim3(ChainF64L::kWaves * 64), hl.total, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
-  hipLaunchKernelGGL(ctc_fast_segment_kernel<8>, dim3(p.NS, p.B), dim3(64), F2Lds<8>::bytes(p.V), stream, p);
-  E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
-  return E2E_OK;
+  return launch_segments<8>(p, F2Lds<8>::bytes(p.V), stream);
 }
 
 constexpr bool kLeanDefault = true;    // (targets of 128..223 labels: 132.4 against 134.2 us per call at the headline shape)
@@ -1592,9 +1607,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<PPL, ChainF32>), dim3(p.B), dim3(ChainF32::kWaves * 64), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
     FastParams q = p; q.ztol = kZTolF32;                          // (trkA / trkB: written by the frame waves)
-    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
-    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
-    return E2E_OK;
+    return launch_segments<PPL>(q, lds2, stream);
   }
   static const bool force_single = getenv("E2E_F1_SINGLE") != nullptr, force_halo = getenv("E2E_F1_HALO") != nullptr;
   // the lean halo chains of ctc_loss_fast_h1.hip.  E2E_F1_LEAN=0 / 1: never / wherever they fit (A/B, tests)
@@ -1603,9 +1616,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   if (!no_h1 && !force_single && (kLeanDefault ? PPL == 4 || force_h1 : force_h1) && h1_supported(p.V, p.Smax, PPL)) {
     const int rc = launch_fast_h1_chain(p, PPL, stream);
     if (rc != E2E_OK) return rc;
-    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);     // (trkA / trkB: the frame waves')
-    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
-    return E2E_OK;
+    return launch_segments<PPL>(p, lds2, stream);
   }
   // f64 halo chains: two waves per direction hold 224 label pairs.  Where they win: the widest rows (158 against 166 us per
   // step at S <= 200; at S <= 127 the single wave carries two pairs per lane itself and wins, 120 against 131 us).
@@ -1615,16 +1626,12 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
     E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<PPL, ChainF64>), hl.total), "hipFuncSetAttribute");
     hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<PPL, ChainF64>), dim3(p.B), dim3(ChainF64::kWaves * 64), hl.total, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
-    hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, p);     // (trkA / trkB: the frame waves')
-    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
-    return E2E_OK;
+    return launch_segments<PPL>(p, lds2, stream);
   }
   hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
   FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB;          // (its frame follows the maximum itself)
-  hipLaunchKernelGGL(ctc_fast_segment_kernel<PPL>, dim3(p.NS, p.B), dim3(64), lds2, stream, q);
-  E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
-  return E2E_OK;
+  return launch_segments<PPL>(q, lds2, stream);
 }
 
 int ppl_for(int Smax) {

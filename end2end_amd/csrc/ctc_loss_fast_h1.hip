@@ -414,22 +414,29 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
   auto row_of = [&](int n) { return DIR == 0 ? t_first + 8 * n : t_first - 8 * n; };
   // unconditional loads from a clamped row (what a dead row or column reads is replaced when it is used), two of this wave's
   // blocks ahead, three register sets rotating through a loop unrolled three times: see prep_wave
-  auto load_block = [&](int n, float (&out)[NV]) {
+  // (F32IN: f32 logits -- the loop below exists twice, so that no test of the dtype sits between the loads)
+  auto load_block = [&](auto f32_tag, int n, float (&out)[NV]) {
+    constexpr bool F32IN = decltype(f32_tag)::value;
     const int t = row_of(n);
     const int tc = min(max(t, 0), T - 1);
     const int64_t xr = xl + (int64_t)tc * p.sT;
-    auto rows = [&](auto elem_tag) {
-      typedef decltype(elem_tag) E;
-      const E* src = reinterpret_cast<const E*>(p.x) + xr;
-      if (contig) {
+    int64_t off[NV];
 #pragma unroll
-        for (int k = 0; k < NV; k++) out[k] = (float)src[(k < kFull || live[k]) ? 8 * k : 0];
-      } else {
+    for (int k = 0; k < NV; k++) off[k] = (k < kFull || live[k]) ? (contig ? (int64_t)(8 * k) : k * cstep) : 0;
+    if (F32IN) {
+      const float* src = reinterpret_cast<const float*>(p.x) + xr;
 #pragma unroll
-        for (int k = 0; k < NV; k++) out[k] = (float)src[(k < kFull || live[k]) ? k * cstep : 0];
-      }
-    };
-    if (p.xdt == E2E_F32) rows(float{}); else if (p.xdt == E2E_BF16) rows(bf16_t{}); else rows(f16_t{});
+      for (int k = 0; k < NV; k++) out[k] = src[off[k]];
+    } else {
+      const unsigned short* src = reinterpret_cast<const unsigned short*>(p.x) + xr;
+      unsigned short h[NV];
+#pragma unroll
+      for (int k = 0; k < NV; k++) h[k] = src[off[k]];
+      const bool bf = p.xdt == E2E_BF16;
+#pragma unroll
+      for (int k = 0; k < NV; k++)
+        out[k] = bf ? __uint_as_float((unsigned)h[k] << 16) : (float)__builtin_bit_cast(f16_t, h[k]);
+    }
   };
   int consumed = 0;
   float lpmin = 0.f;
@@ -499,16 +506,17 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
     // every lane stores the same word ("my blocks up to n are there"): no divergence, one LDS write
     *(volatile lds_int*)(L0 + a_fill) = n + stride;
   };
-  {
+  auto run = [&](auto f32_tag) {
     float xa[NV], xb[NV], xc[NV];
-    load_block(first, xa);
-    load_block(first + stride, xb);
+    load_block(f32_tag, first, xa);
+    load_block(f32_tag, first + stride, xb);
     for (int n = first; n < nblk; n += 3 * stride) {       // this wave fills every `stride`-th block
-      load_block(n + 2 * stride, xc); process(n, xa);
-      load_block(n + 3 * stride, xa); if (n + stride < nblk) process(n + stride, xb);
-      load_block(n + 4 * stride, xb); if (n + 2 * stride < nblk) process(n + 2 * stride, xc);
+      load_block(f32_tag, n + 2 * stride, xc); process(n, xa);
+      load_block(f32_tag, n + 3 * stride, xa); if (n + stride < nblk) process(n + stride, xb);
+      load_block(f32_tag, n + 4 * stride, xb); if (n + 2 * stride < nblk) process(n + 2 * stride, xc);
     }
-  }
+  };
+  if (p.xdt == E2E_F32) run(std::true_type{}); else run(std::false_type{});
   // (see prep_wave: emissions near the end of f32 -> the utterance is recomputed entirely by the exact kernel)
   if (DIR == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], 64); }       // e^-69 = 2^-100
 }

@@ -416,19 +416,24 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
   // loads are unconditional (clamped addresses; what a dead row or column reads is replaced when it is used): a
   // conditional load becomes a branch per element and a full wait behind it.  Three register sets rotate through a loop
   // unrolled three times, so that no set is ever copied (a copy waits for the load it copies).
-  auto load_block = [&](int n, float (&out)[NV]) {
+  // (F32IN: the logits are f32 -- the loop below exists twice, so that no test of the dtype sits between the loads; 16-bit
+  //  logits take the copy whose loads choose between the two 16-bit types)
+  auto load_block = [&](auto f32_tag, int n, float (&out)[NV]) {
+    constexpr bool F32IN = decltype(f32_tag)::value;
     const int t = block_time(dir, n, tt, T);
     const bool row_live = n < nblk && t < T;
     const int64_t xr = xo + (int64_t)(row_live ? t : 0) * p.sT;
-    if (p.xdt == E2E_F32) {
+    if (F32IN) {
 #pragma unroll
       for (int k = 0; k < NV; k++) out[k] = reinterpret_cast<const float*>(p.x)[xr + col_off[k]];
-    } else if (p.xdt == E2E_BF16) {
-#pragma unroll
-      for (int k = 0; k < NV; k++) out[k] = (float)reinterpret_cast<const bf16_t*>(p.x)[xr + col_off[k]];
     } else {
+      unsigned short h[NV];
 #pragma unroll
-      for (int k = 0; k < NV; k++) out[k] = (float)reinterpret_cast<const f16_t*>(p.x)[xr + col_off[k]];
+      for (int k = 0; k < NV; k++) h[k] = reinterpret_cast<const unsigned short*>(p.x)[xr + col_off[k]];
+      const bool bf = p.xdt == E2E_BF16;
+#pragma unroll
+      for (int k = 0; k < NV; k++)
+        out[k] = bf ? __uint_as_float((unsigned)h[k] << 16) : (float)__builtin_bit_cast(f16_t, h[k]);
     }
   };
   int consumed = 0;                 // blocks the ring's readers are known to have finished with (HALO)
@@ -509,16 +514,17 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     if (MODE != 0) publish(&myfilled[first], n + stride);
     else publish(&myfilled[slot], n + 1);
   };
-  {
+  auto run = [&](auto f32_tag) {
     float xa[NV], xb[NV], xc[NV];
-    load_block(first, xa);
-    load_block(first + stride, xb);
+    load_block(f32_tag, first, xa);
+    load_block(f32_tag, first + stride, xb);
     for (int n = first; n < nblk; n += 3 * stride) {       // this wave fills every `stride`-th block
-      load_block(n + 2 * stride, xc); process(n, xa);
-      load_block(n + 3 * stride, xa); process(n + stride, xb);
-      load_block(n + 4 * stride, xb); process(n + 2 * stride, xc);
+      load_block(f32_tag, n + 2 * stride, xc); process(n, xa);
+      load_block(f32_tag, n + 3 * stride, xa); process(n + stride, xb);
+      load_block(f32_tag, n + 4 * stride, xb); process(n + 2 * stride, xc);
     }
-  }
+  };
+  if (p.xdt == E2E_F32) run(std::true_type{}); else run(std::false_type{});
   // Probabilities are f32: below ~2^-126 they are flushed, and a chain that ran through such frames carries a loss that
   // is off by the flushed amount (a symbol with log-probability -inf is exactly impossible and does not count).  Reason bit 64 ("emissions near the end of f32"): such an utterance is recomputed
   // entirely by the exact kernel, never by the f64 redo of the segments alone, which would keep the chains' loss.
