@@ -79,7 +79,8 @@ struct FastRetry {
   int* ctl;                        // the fast path's control words (see FastParams::ctl)
   const float* ytab; const float* ckA; const float* ckQ; const short* ckE; const int* cumA; const int* cumB;
   const double* logz;              // [B][2] the chains' log Z (alpha side, beta side)
-  int NS, NB, CELLS, PPL;
+  const unsigned* segmask;         // [B][MW] bit s: segment s failed its range / self-check in the segment kernel (only those are redone)
+  int NS, NB, CELLS, PPL, MW;
 };
 
 size_t exact_workspace_bytes(int B, int T, int V, int Smax);            // every utterance (algo EXACT)

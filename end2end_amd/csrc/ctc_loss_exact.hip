@@ -889,7 +889,12 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
     for (int c0 = 0; c0 < p.B && wid < p.redo_waves; c0 += 64) {
       const int bb = c0 + lane;
       const int f = bb < p.B ? flag_of(bb) : 0;
-      const int ns = range_only(f) ? nseg_of(bb) : 0;
+      // (only the segments that failed in the segment kernel: the others' rows passed their self-check and stay)
+      int ns = 0;
+      if (range_only(f)) {
+        const unsigned* mk = p.retry.segmask + (size_t)bb * p.retry.MW;
+        for (int i = 0; i < p.retry.MW; i++) ns += __builtin_popcount(mk[i]);
+      }
       const int incl = wave_incl_scan(ns, lane);
       const int tot = __builtin_amdgcn_readlane(incl, 63);
       if (tot != 0) {
@@ -900,7 +905,21 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
           const int l = __builtin_ctzll(work); work &= work - 1;
           const int ub = c0 + l;
           const int sfirst = __builtin_amdgcn_readlane(first, l), uns = __builtin_amdgcn_readlane(ns, l);
-          for (int seg = sfirst; seg < uns; seg += NW) {
+          for (int item = sfirst; item < uns; item += NW) {
+            // the item-th failed segment of the utterance
+            int seg = -1;
+            {
+              const unsigned* mk = p.retry.segmask + (size_t)ub * p.retry.MW;
+              int left = item;
+              for (int i = 0; i < p.retry.MW && seg < 0; i++) {
+                unsigned m = mk[i];
+                const int c = __builtin_popcount(m);
+                if (left >= c) { left -= c; continue; }
+                for (; left > 0; left--) m &= m - 1;
+                seg = 32 * i + __builtin_ctz(m);
+              }
+            }
+            if (seg < 0) continue;
             bool ok;
             if (p.retry.PPL == 1) ok = retry_segment_f64<IO, 1>(p, wsmem, ub, seg, lane);
             else if (p.retry.PPL == 2) ok = retry_segment_f64<IO, 2>(p, wsmem, ub, seg, lane);

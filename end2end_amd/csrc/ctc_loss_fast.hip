@@ -264,6 +264,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(512) void ctc_fast_chain_kernel(Fa
   }
   const int T = (int)Tq, S = (int)Sq;
   if (tid == 0) p.flags[b] = 0;    // (the barrier below orders this before the waves' atomicOr; saves a memset launch)
+  for (int i = tid; i < p.MW; i += blockDim.x) p.segmask[(size_t)b * p.MW + i] = 0u;
   if (tid < F1Lds::kSyncInts) lds.filled[tid] = 0;
   for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
     lds.ring[(size_t)(i / kBlk) * lds.blk_elems + V * kRow + (i % kBlk)] = 0.0;
@@ -743,6 +744,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
   constexpr int MAXW = (64 * PPL + kHfOwn - 1) / kHfOwn < X::kMaxW ? (64 * PPL + kHfOwn - 1) / kHfOwn : X::kMaxW;
   const int W = min(S / kHfOwn + 1, MAXW);                        // waves that hold a cell: pairs 0..S (pair S = the last blank)
   if (tid == 0) p.flags[b] = 0;
+  for (int i = tid; i < p.MW; i += blockDim.x) p.segmask[(size_t)b * p.MW + i] = 0u;
   if (tid < 2 * kRingBlks) reinterpret_cast<int*>(smem + hl.filled)[tid] = (tid & (kRingBlks - 1)) < X::kProducers ? (tid & (kRingBlks - 1)) : 0;
   if (tid < 16) reinterpret_cast<int*>(smem + hl.prog)[tid] = (tid & 7) < W ? 0 : kHaloIdle;
   if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHfLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;
@@ -920,6 +922,9 @@ __device__ __forceinline__ void finish_rows(const P& p, int b, int t0, int n, in
     // (smin / smax: see the range check at the end of the kernel)
     const bool bad = live && !(fabsf(dev) <= p.ztol && my_st >= E2E_SMIN);
     if (__any(bad)) smin = 0.f;
+    // borderline: within the tolerance, but beyond what rounding alone leaves (< 1e-6).  Not a reason to flag the utterance;
+    // if OTHER rows flag it for range, the f64 redo takes this segment along (smin == 1 marks it: see the kernel's end)
+    else if (__any(live && !(fabsf(dev) <= 0.25f * p.ztol))) smin = fminf(smin, 1.f);
     if (__any(live && !(my_st < __builtin_huge_valf()))) smax = __builtin_huge_valf();
   }
   F2_LDS_ORDER
@@ -1534,7 +1539,13 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   // redo for nothing, and with 2^-110 and no self-check a randomised sweep let gradients through that were off by 2e-3.
   // Rows between F1's rescales legitimately sit 2^-40 .. 2^-80 below the unit: alpha is rescaled at t%8 == 7 and beta
   // at t%8 == 0, so every row in between carries nine steps of decay.)
-  if (!(smin > 0.f) || !finite_ok) { if (lane == 0) atomicOr(&p.flags[b], finite_ok ? 8 : 16); }
+  // (the segment's bit in the mask: what the f64 redo of a range-flagged utterance takes -- the segments that failed and the
+  //  borderline ones; the rows of every other segment passed their self-check with room to spare and stay as written)
+  if (!(smin > 0.f) || !finite_ok) {
+    if (lane == 0) { atomicOr(&p.flags[b], finite_ok ? 8 : 16); atomicOr(&p.segmask[(size_t)b * p.MW + (seg >> 5)], 1u << (seg & 31)); }
+  } else if (smin < __builtin_huge_valf()) {
+    if (lane == 0) atomicOr(&p.segmask[(size_t)b * p.MW + (seg >> 5)], 1u << (seg & 31));
+  }
   if (seg == 0 && lane == 0) {
     const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
     if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
@@ -1644,8 +1655,8 @@ int ppl_for(int Smax) {
 }
 
 struct FastLayout {
-  size_t ytab, ckA, ckQ, ckE, cumA, cumB, trkA, trkB, logz, zt2, flags, cinfo, lstart, ctl, total;
-  int NS, NB, CELLS;
+  size_t ytab, ckA, ckQ, ckE, cumA, cumB, trkA, trkB, logz, zt2, flags, segmask, cinfo, lstart, ctl, total;
+  int NS, NB, CELLS, MW;
 };
 
 FastLayout fast_layout(int B, int T, int V, int Smax) {
@@ -1666,6 +1677,8 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
   l.zt2 = o; o += align_up((size_t)B * sizeof(double), 256);
   l.logz = o; o += align_up((size_t)B * 2 * sizeof(double), 256);
   l.flags = o; o += align_up((size_t)B * sizeof(int), 256);
+  l.MW = (l.NS + 31) / 32;
+  l.segmask = o; o += align_up((size_t)B * l.MW * sizeof(unsigned), 256);
   l.cinfo = o; o += align_up((size_t)B * (l.CELLS / 2) * sizeof(unsigned), 256);
   l.lstart = o; o += align_up((size_t)B * 130 * sizeof(int), 256);
   l.ctl = o; o += 256;
@@ -1706,6 +1719,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.trkA = reinterpret_cast<int*>(ws + l.trkA); p.trkB = reinterpret_cast<int*>(ws + l.trkB);
   p.zt2 = reinterpret_cast<double*>(ws + l.zt2);
   p.logz = reinterpret_cast<double*>(ws + l.logz); p.flags = reinterpret_cast<int*>(ws + l.flags);
+  p.segmask = reinterpret_cast<unsigned*>(ws + l.segmask); p.MW = l.MW;
   p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart);
   p.ctl = reinterpret_cast<int*>(ws + l.ctl);
   p.gscale = (float)a.grad_scale;
@@ -1727,6 +1741,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   FastRetry rt;
   rt.ytab = p.ytab; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.cumA = p.cumA; rt.cumB = p.cumB;
   rt.NS = p.NS; rt.NB = p.NB; rt.CELLS = p.CELLS; rt.PPL = ppl_for(a.Smax); rt.logz = p.logz; rt.ctl = p.ctl;
+  rt.segmask = p.segmask; rt.MW = p.MW;
   return launch_exact_flagged(e, p.flags, fallback_to_exact ? 1 : 2, &rt);
 }
 

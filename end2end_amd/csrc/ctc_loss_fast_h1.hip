@@ -589,6 +589,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(Hx<NP>::kWaves * 64) void ctc_fast
   const int T = (int)Tq, S = (int)Sq;
   const int W = min(S / Hx<NP>::kOwn + 1, Hx<NP>::kMaxW);         // waves that hold a cell: pairs 0..S (pair S = the last blank)
   if (tid == 0) p.flags[b] = 0;
+  for (int i = tid; i < p.MW; i += blockDim.x) p.segmask[(size_t)b * p.MW + i] = 0u;
   if (tid < 2 * kRingBlks) reinterpret_cast<int*>(smem + hl.filled)[tid] = (tid & (kRingBlks - 1)) < kHxProducers ? (tid & (kRingBlks - 1)) : 0;
   if (tid < 16) reinterpret_cast<int*>(smem + hl.prog)[tid] = (tid & 7) < W ? 0 : kHaloIdle;
   if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHaloLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;

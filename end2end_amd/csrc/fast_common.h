@@ -47,6 +47,8 @@ struct FastParams {
                    //           what sum_j alpha_t[j]*beta_t[j] * 2^(cumA + cumB) must equal at every t
   double* logz;    // [B][2]    alpha-side / beta-side log Z
   int* flags;      // [B]       != 0: redo with the exact kernel
+  unsigned* segmask; // [B][MW]  bit s of an utterance's words: segment s failed its range / self-check (flag bits 8 / 16): the
+  int MW;          //           f64 redo of the flagged-utterance launch takes those segments only; cleared by the chain kernel
   unsigned* cinfo; // [B][CELLS/2]  per label pair: label | sorted slot << 8 (10 bits) | alpha skip << 20 | beta skip << 21
   int* lstart;     // [B][130]  first label-sorted slot of every label (V+1 entries used)
   int* ctl;        // [4]  0: fallback workgroups that have finished (F1 clears it; the last one reduces the losses);
