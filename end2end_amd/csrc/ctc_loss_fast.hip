@@ -335,8 +335,9 @@ typedef __attribute__((address_space(3))) h_f4 lds_f4;
 //             chains give it (same recurrence, same f64 cells; powers of two apart), 2 waves per direction, 2 producers
 //             per direction, 12 waves.
 struct ChainF32 {
-  typedef float T; typedef h_f2 V2;
-  static constexpr bool kF32 = true;
+  typedef float T; typedef h_f2 V2; typedef float R;      // cells, packed cells, ring elements
+  static constexpr bool kF32 = true, kBigV = false;
+  static constexpr int kRing = kRingBlks, kRingElem = 4;
   static constexpr int kMaxW = 3, kProducers = 3, kRowElems = kRow32, kElem = 4;
   static constexpr int kWaves = 2 * kMaxW + 2 + 2 * kProducers + 2;
   static constexpr bool kPairedLoop = true;
@@ -347,8 +348,9 @@ struct ChainF32 {
   __device__ static float tilt2(float r) { return r * r; }
 };
 struct ChainF64 {
-  typedef double T; typedef h_d2 V2;
-  static constexpr bool kF32 = false;
+  typedef double T; typedef h_d2 V2; typedef double R;
+  static constexpr bool kF32 = false, kBigV = false;
+  static constexpr int kRing = kRingBlks, kRingElem = 8;
 #ifndef E2E_F64_PRODUCERS             // Two producers per direction: 12 waves, i.e. three per SIMD and 168 registers for the chain
 #define E2E_F64_PRODUCERS 2           // waves' paired interior loop (with three producers -- 14 waves, 128 registers -- that loop
 #endif                                // spills in the beta wave: 155 against 131 us per step at the headline shape)
@@ -372,12 +374,22 @@ struct ChainF64L : ChainF64 {
   static constexpr bool kPairedLoop = false;
 };
 
+//   ChainF64W: ChainF64 for alphabets of 97..224 columns (the compacted wide-alphabet targets of more than 95 word pieces, above
+//             all): the probability ring is f32 -- what the producers compute anyway -- and four blocks deep, 87 KB at 224
+//             columns (f64 and eight deep: 290 KB); a chain wave converts what it reads (four conversions per step) and forms
+//             the tilted blank probability itself.  Same cells, same recurrence, same results as ChainF64.
+struct ChainF64W : ChainF64 {
+  typedef float R;
+  static constexpr bool kBigV = true;
+  static constexpr int kRing = 4, kRingElem = 4, kRowElems = kRow32;
+};
+
 struct HfLds {
   // byte offsets from the start of the workgroup's LDS
   int ring;        // [2][kRingBlks] blocks of blk_bytes: (V+1) label rows of kRowElems cells (row V: zeros) + 16 cells (yb, wb) x 8 steps
   int blk_bytes;
   int filled;      // [2][kRingBlks] ints; used: [dir][f] = kProducers + the last block producer f of the direction has finished
-  int sortcnt;     // [130] ints (cellinfo_wave)
+  int sortcnt;     // [130] ints (cellinfo_wave; 258 for more than 127 columns)
   int bnd;         // [2][kMaxW][kHaloSlots][kHfHalo] x 4 cells: wave w's edge lanes (B0, L0, B1, L1) after block n
   int zacc;        // [8] doubles
   int prog;        // [2][8] ints
@@ -386,12 +398,12 @@ struct HfLds {
   int ckb;         // [2][2][kMaxW][64] x 4 cells: a checkpoint row's true cells (B0, L0, B1, L1 per lane), double-buffered
   int ckdone;      // [2] ints: checkpoint rows the direction's checkpoint wave has finished reading
   int total;
-  __host__ __device__ HfLds(int V, int row_elems, int elem, int maxw) {
+  __host__ __device__ HfLds(int V, int row_elems, int ring_elem, int elem, int maxw, int depth) {
     ring = 0;
-    blk_bytes = ((V + 1) * row_elems + 16) * elem;
-    filled = ring + 2 * kRingBlks * blk_bytes;
+    blk_bytes = ((V + 1) * row_elems + 16) * ring_elem;
+    filled = ring + 2 * depth * blk_bytes;
     sortcnt = filled + 2 * kRingBlks * 4;
-    bnd = (sortcnt + 130 * 4 + 15) & ~15;
+    bnd = (sortcnt + (V > 127 ? 258 : 130) * 4 + 15) & ~15;
     zacc = bnd + 2 * maxw * kHaloSlots * kHfHalo * 4 * elem;
     prog = zacc + 64;
     exw = prog + 2 * 8 * 4;
@@ -400,7 +412,7 @@ struct HfLds {
     ckdone = ckb + 2 * 2 * maxw * 64 * 4 * elem;
     total = ckdone + 16;
   }
-  template <typename X> __host__ __device__ static HfLds of(int V) { return HfLds(V, X::kRowElems, X::kElem, X::kMaxW); }
+  template <typename X> __host__ __device__ static HfLds of(int V) { return HfLds(V, X::kRowElems, X::kRingElem, X::kElem, X::kMaxW, X::kRing); }
 };
 
 template <int DIR, int F2PPL, typename X>
@@ -408,11 +420,11 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
                                               int lane, int w, int W) {
   typedef typename X::T CT;
   typedef typename X::V2 V2;
-  constexpr int kCell = X::kElem, kLane4 = 4 * X::kElem;          // bytes of a cell / of a lane's four cells
+  constexpr int kLane4 = 4 * X::kElem;                            // bytes of a lane's four cells
   lds_u8* L0 = (lds_u8*)smem;
   const int V = p.V, blank = p.blank, L = 2 * S + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
-  const int ring_off = hl.ring + DIR * kRingBlks * hl.blk_bytes;
+  const int ring_off = hl.ring + DIR * X::kRing * hl.blk_bytes;
   volatile int* myfilled = reinterpret_cast<int*>(smem + hl.filled) + DIR * kRingBlks;
   lds_u8* prog = L0 + hl.prog + DIR * 32;
   lds_u8* exw = L0 + hl.exw + DIR * (kHaloSlots * 4);
@@ -474,11 +486,22 @@ __device__ __forceinline__ void hf_chain_wave(const FastParams& p, int b, int T,
   };
 
   CT e0[kBlk], e1[kBlk], ybw[2 * kBlk];             // the block's probabilities of the two labels; (yb, wb) per step
-  const int lab0_off = lab[0] * (X::kRowElems * kCell), lab1_off = lab[1] * (X::kRowElems * kCell), yw_off = (V + 1) * (X::kRowElems * kCell);
+  constexpr int kRowBytes = X::kRowElems * X::kRingElem;
+  const int lab0_off = lab[0] * kRowBytes, lab1_off = lab[1] * kRowBytes, yw_off = (V + 1) * kRowBytes;
   auto load_half = [&](int n, auto half_tag) {     // steps 4H .. 4H+3 of block n
     constexpr int H = decltype(half_tag)::value;
-    const int yo = ring_off + (n % kRingBlks) * hl.blk_bytes;
-    if constexpr (X::kF32) {
+    const int yo = ring_off + (n % X::kRing) * hl.blk_bytes;
+    if constexpr (X::kBigV) {
+      // f32 ring, f64 cells: four steps of a label per read; the tilted blank probability is formed here (exact, as the
+      // producers of the f64 ring form it)
+      const h_f4 a0 = *(lds_f4*)(L0 + yo + lab0_off + 16 * H), a1 = *(lds_f4*)(L0 + yo + lab1_off + 16 * H);
+      const h_f4 y0 = *(lds_f4*)(L0 + yo + yw_off + 32 * H), y1 = *(lds_f4*)(L0 + yo + yw_off + 32 * H + 16);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { e0[4 * H + k] = (CT)a0[k]; e1[4 * H + k] = (CT)a1[k]; }
+      ybw[8 * H + 0] = (CT)y0[0]; ybw[8 * H + 2] = (CT)y0[2]; ybw[8 * H + 4] = (CT)y1[0]; ybw[8 * H + 6] = (CT)y1[2];
+#pragma unroll
+      for (int k = 0; k < 4; k++) ybw[8 * H + 2 * k + 1] = rr2 * ybw[8 * H + 2 * k];
+    } else if constexpr (X::kF32) {
       const h_f4 a0 = *(lds_f4*)(L0 + yo + lab0_off + 16 * H), a1 = *(lds_f4*)(L0 + yo + lab1_off + 16 * H);
       const h_f4 y0 = *(lds_f4*)(L0 + yo + yw_off + 32 * H), y1 = *(lds_f4*)(L0 + yo + yw_off + 32 * H + 16);
 #pragma unroll
@@ -750,8 +773,8 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
   if (tid < 2 * kHaloSlots) reinterpret_cast<int*>(smem + hl.exw)[tid] = (tid & (kHaloSlots - 1)) < kHfLag ? ((tid & (kHaloSlots - 1)) << 12) | 2048 : -1;
   if (tid < 8) reinterpret_cast<double*>(smem + hl.zacc)[tid] = 0.0;
   if (tid < 2) reinterpret_cast<int*>(smem + hl.ckdone)[tid] = 0;
-  for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
-    reinterpret_cast<typename X::T*>(smem + hl.ring + (i / kBlk) * hl.blk_bytes)[V * X::kRowElems + (i % kBlk)] = 0;
+  for (int i = tid; i < 2 * X::kRing * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
+    reinterpret_cast<typename X::R*>(smem + hl.ring + (i / kBlk) * hl.blk_bytes)[V * X::kRowElems + (i % kBlk)] = 0;
   __syncthreads();
 
   constexpr int kChains = 2 * X::kMaxW, kFrame = kChains, kProd = kChains + 2, kCkpt = kProd + 2 * X::kProducers;
@@ -774,9 +797,14 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
     const int first = (wave - kProd) >> 1;               // the producers of a direction take every kProducers-th block
     lds_u8* prog = L0 + hl.prog + d * 32;
     const double rr2 = (double)X::tilt2(fast_tilt(S, T));        // (the chain waves' own expression)
-    unsigned char* ring = smem + hl.ring + d * kRingBlks * hl.blk_bytes;
+    unsigned char* ring = smem + hl.ring + d * X::kRing * hl.blk_bytes;
     volatile int* fl = reinterpret_cast<int*>(smem + hl.filled) + d * kRingBlks;
     constexpr int MODE = X::kF32 ? 2 : 1;
+    if constexpr (X::kBigV) {
+      if (V <= 128) prep_wave_big<16, X::kRing>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, lane, prog, rr2);
+      else if (V <= 176) prep_wave_big<22, X::kRing>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, lane, prog, rr2);
+      else prep_wave_big<28, X::kRing>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, lane, prog, rr2);
+    } else
     if (V <= 16) prep_wave<2, MODE>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
     else if (V <= 32) prep_wave<4, MODE>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
     else if (V <= 48) prep_wave<6, MODE>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
@@ -793,7 +821,8 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
 #endif
 // the segment kernel's parameters with the gradient's element width as a compile-time fact (an instance per width: three
 // copies of the gradient passes behind a run-time test cost the f32 kernel 80 bytes of scratch and 5 us)
-template <bool O16> struct SegParams : FastParams { static constexpr bool kOut16 = O16; };
+// (BIG: alphabets of 97..224 columns -- the probability tile is staged in two rounds, a gradient lane takes up to four labels)
+template <bool O16, bool BIG = false> struct SegParams : FastParams { static constexpr bool kOut16 = O16, kBigV = BIG; };
 constexpr int kHalf = 8;           // rows of alpha*beta buffered in LDS before they are summed and written out
 // Between the segment wave's LDS phases (scatter -> scan -> per-label reads -> next half's scatter).  The LDS executes one
 // wave's operations in order, so a read issued after a write of the same wave sees it without a wait; only the compiler has
@@ -835,16 +864,18 @@ struct F2Lds {
     ys = Ps + kHalf * PROW;
     starts = reinterpret_cast<int*>(ys + kYs * (V + 1));
   }
-  __host__ __device__ static size_t bytes(int V) { return sizeof(float) * (4 + kHalf * PROW + kYs * (V + 1)) + sizeof(int) * 130; }
+  __host__ __device__ static size_t bytes(int V) { return sizeof(float) * (4 + kHalf * PROW + kYs * (V + 1)) + sizeof(int) * (V > 127 ? 258 : 130); }
 };
 
 // The gradient rows are written one lane per (row, label): with V <= 32 columns the 64 lanes cover two rows per pass (four
 // with V <= 16), beyond 64 columns a lane takes two labels.  What a lane needs about its label is the same for all 16
 // rows of the segment and is looked up once.
-struct GradLanes {
-  int hi[2], lo[2];     // float index into Ps of the label's last sorted slot / of the slot before its first (+ the lane's row)
-  int y[2];             // float index of the label's row in the transposed probability tile (+ the lane's row)
-  float isblank[2];     // 1 for the blank column (it takes the pre-summed blank cells), else 0
+template <int NSET>
+struct GradLanesT {
+  static constexpr int kSets = NSET;
+  int hi[NSET], lo[NSET];     // float index into Ps of the label's last sorted slot / of the slot before its first (+ the lane's row)
+  int y[NSET];          // float index of the label's row in the transposed probability tile (+ the lane's row)
+  float isblank[NSET];  // 1 for the blank column (it takes the pre-summed blank cells), else 0
   int rpp;              // rows per pass: 1, 2 or 4 (wave-uniform)
   int rsel;             // this lane's row inside a pass
   int goff;             // rsel * V + v: the lane's offset inside a pass's rows of the gradient; -1: the lane writes nothing
@@ -856,7 +887,7 @@ struct GradLanes {
     const int v0 = rpp == 1 ? lane : lane & (vp - 1);
     goff = v0 < V ? rsel * V + v0 : -1;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < NSET; s++) {
       const int v = min(v0 + 64 * s, V - 1);
       hi[s] = lds.starts[v + 1] - 1 + rsel * F2Lds<PPL>::PROW; lo[s] = lds.starts[v] - 1 + rsel * F2Lds<PPL>::PROW;
       y[s] = v * kYs + rsel; isblank[s] = v == blank ? 1.f : 0.f;
@@ -865,9 +896,11 @@ struct GradLanes {
 };
 
 // rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows.  FULL: all 8 rows are live.
-template <int PPL, bool FULL, typename P>
+typedef GradLanesT<2> GradLanes;        // up to 128 columns (kMaxSmallV); four sets: kMaxBigV
+
+template <int PPL, bool FULL, typename P, typename GL>
 __device__ __forceinline__ void finish_rows(const P& p, int b, int t0, int n, int h, const F2Lds<PPL>& lds,
-                                            const GradLanes& gl, const float (&pb)[kHalf], int lane, float& smin, float& smax,
+                                            const GL& gl, const float (&pb)[kHalf], int lane, float& smin, float& smax,
                                             int u_lo, int u_hi, float zfrac) {
   constexpr int PROW = F2Lds<PPL>::PROW;
   const int V = p.V;
@@ -964,9 +997,9 @@ __device__ __forceinline__ void finish_rows(const P& p, int b, int t0, int n, in
     if (gl.rpp == 2) pass(std::integral_constant<int, 2>{});
     else if (gl.rpp == 4) pass(std::integral_constant<int, 4>{});
     else {
-      const int nsets = V > 64 ? 2 : 1;
+      const int nsets = (V + 63) >> 6;
 #pragma unroll
-      for (int s = 0; s < 2; s++) {
+      for (int s = 0; s < GL::kSets; s++) {
         if (s < nsets) {
           const int v = lane + 64 * s;
           const float* pre_hi = lds.Ps + gl.hi[s];
@@ -1039,11 +1072,11 @@ struct SegIn {
 };
 
 // FULL: an interior segment (16 live steps, neither t = 0 nor t = T-1 inside): no guards in the loops.
-template <int PPL, bool FULL, typename P>
+template <int PPL, bool FULL, typename P, typename GL>
 __device__ __forceinline__ void segment_body(const P& p, int b, int seg, int T, int S, int n,
                                              const LaneCells<PPL>& lc, const int (&rank)[PPL],
                                              const SegIn<PPL>& in,
-                                             const F2Lds<PPL>& lds, const GradLanes& gl, int lane, float& smin, float& smax) {
+                                             const F2Lds<PPL>& lds, const GL& gl, int lane, float& smin, float& smax) {
   constexpr int NC = 2 * PPL;
   constexpr int kSlope = 3 * NC;    // exponent drop allowed per lane (see the alpha load below)
   constexpr int PROW = F2Lds<PPL>::PROW;
@@ -1252,10 +1285,10 @@ __device__ __forceinline__ void segment_body(const P& p, int b, int seg, int T, 
 // from pairs 1, 3), and for the other group one DPP move and one plain move assemble it.  The emission factors stay
 // scalar multiplies (a lane's labels sit in different rows of the probability tile).  Same arithmetic as segment_body,
 // cell for cell; 14 + 21 vector instructions per row instead of 22 + 30.
-template <bool FULL, typename P>
+template <bool FULL, typename P, typename GL>
 __device__ __forceinline__ void segment_body_pk(const P& p, int b, int seg, int T, int S, int n,
                                                 const LaneCells<4>& lc, const int (&rank)[4], const SegIn<4>& in,
-                                                const F2Lds<4>& lds, const GradLanes& gl, int lane, float& smin, float& smax) {
+                                                const F2Lds<4>& lds, const GL& gl, int lane, float& smin, float& smax) {
   constexpr int PPL = 4, NC = 8;
   constexpr int kSlope = 3 * NC;
   constexpr int PROW = F2Lds<PPL>::PROW;
@@ -1434,10 +1467,18 @@ __device__ __forceinline__ void segment_body_pk(const P& p, int b, int seg, int 
   }
 }
 
+#ifndef E2E_F2_LDSPAD
+#define E2E_F2_LDSPAD 0
+#endif
+#ifndef E2E_F2_WPB                  // independent segment waves per workgroup (tools/diag)
+#define E2E_F2_WPB 1
+#endif
 template <int PPL, typename P>
 __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
-  const int b = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.y, seg = blockIdx.x * E2E_F2_WPB + (E2E_F2_WPB > 1 ? (int)(threadIdx.x >> 6) : 0), lane = threadIdx.x & 63;
+  if (E2E_F2_WPB > 1 && seg >= p.NS) return;
   const int V = p.V, Tmax = p.T, t0 = seg * kSeg;
+  if (E2E_F2_WPB > 1) smem += (threadIdx.x >> 6) * ((F2Lds<PPL>::bytes(V) + E2E_F2_LDSPAD + 15) & ~(size_t)15);
   const F2Lds<PPL> lds(smem, V);
   typedef float f4 __attribute__((ext_vector_type(4)));
   F2_STAMP(-1)
@@ -1453,11 +1494,14 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
 #pragma unroll
     for (int r = 0; r < PPL; r++) w[r] = ci[r];
   }
-  const int* ls = p.lstart + (size_t)b * 130;
-  const int s0 = ls[lane], s1 = ls[64 + lane], s2 = ls[128 + (lane & 1)];
+  constexpr bool BIG = P::kBigV;
+  const int* ls = p.lstart + (size_t)b * p.LS;
+  const int s0 = ls[lane], s1 = ls[64 + lane], s2 = ls[128 + (BIG ? lane : (lane & 1))];
+  int s3 = 0, s4 = 0;
+  if (BIG) { s3 = ls[192 + lane]; s4 = ls[256 + (lane & 1)]; }
   // (b) the segment's 16 probability rows: 16*V consecutive floats of ytab, as 16-byte loads from the aligned
-  //     address below (<= 6 per lane for V <= 96)
-  constexpr int kTileLoads = (kSeg * kMaxSmallV + 3 + 255) / 256;
+  //     address below (<= 6 per lane for V <= 96; BIG: eight now, the rest after these have been staged)
+  constexpr int kTileLoads = BIG ? 8 : (kSeg * kMaxSmallV + 3 + 255) / 256;
   const size_t g0 = ((size_t)b * Tmax + t0) * V;
   const size_t a0 = g0 & ~(size_t)3;
   const int skew = (int)(g0 - a0);
@@ -1490,7 +1534,8 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   LaneCells<PPL> lc;
   int rank[PPL];
   lc.unpack(w, S, T, rank);
-  lds.starts[lane] = s0; lds.starts[64 + lane] = s1; if (lane < 2) lds.starts[128 + lane] = s2;
+  if (BIG) { lds.starts[lane] = s0; lds.starts[64 + lane] = s1; lds.starts[128 + lane] = s2; lds.starts[192 + lane] = s3; if (lane < 2) lds.starts[256 + lane] = s4; }
+  else { lds.starts[lane] = s0; lds.starts[64 + lane] = s1; if (lane < 2) lds.starts[128 + lane] = s2; }
   if (lane < kYs) lds.ys[V * kYs + lane] = 0.f;                           // the zero row V
   if (n < kSeg)
     for (int i = lane; i < kYs * V; i += 64) lds.ys[i] = 0.f;            // dead steps of a short last segment
@@ -1498,23 +1543,37 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
     // scatter the rows into the transposed tile
     const int count = n * V;
     const unsigned magic = (1u << 20) / (unsigned)V + 1u;                // idx / V for idx < 2^20 / V
+    auto scatter = [&](const f4 (&tl)[kTileLoads], int jbase) {
 #pragma unroll
-    for (int j = 0; j < kTileLoads; j++) {
-      if (4 * 64 * j < kSeg * V + skew) {
+      for (int j = 0; j < kTileLoads; j++) {
+        if (4 * 64 * (jbase + j) < kSeg * V + skew) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const int idx = 4 * (64 * j + lane) + c - skew;
-          if (idx >= 0 && idx < count) {
-            const int tt = (int)(((unsigned)idx * magic) >> 20);
-            lds.ys[(idx - tt * V) * kYs + tt] = tile[j][c];
+          for (int c = 0; c < 4; c++) {
+            const int idx = 4 * (64 * (jbase + j) + lane) + c - skew;
+            if (idx >= 0 && idx < count) {
+              const int tt = (int)(((unsigned)idx * magic) >> 20);
+              lds.ys[(idx - tt * V) * kYs + tt] = tl[j][c];
+            }
           }
         }
+      }
+    };
+    scatter(tile, 0);
+    if (BIG) {
+      // the rest of the tile, a round of eight loads at a time (16 * 224 floats: two rounds in all)
+      for (int jbase = kTileLoads; 4 * 64 * jbase < kSeg * V + skew; jbase += kTileLoads) {
+        const f4* src = reinterpret_cast<const f4*>(p.ytab + a0);
+        f4 more[kTileLoads];
+#pragma unroll
+        for (int j = 0; j < kTileLoads; j++)
+          if (4 * 64 * (jbase + j) < kSeg * V + skew) more[j] = src[64 * (jbase + j) + lane];
+        scatter(more, jbase);
       }
     }
   }
   if (lane < kHalf) lds.Ps[lane * F2Lds<PPL>::PROW - 1] = 0.f;           // the rows' zero guards
   F2_LDS_ORDER   // staged rows visible to this (single) wave
-  GradLanes gl;
+  GradLanesT<BIG ? 4 : 2> gl;
   gl.init(lds, V, p.blank, lane);
   F2_STAMP(0)
   float smin = __builtin_huge_valf(), smax = 0.f;
@@ -1561,23 +1620,26 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
 #define E2E_F2_MINW 2
 #endif
 #define E2E_F2_MINW4 (E2E_F2_HALF ? 3 : E2E_F2_MINW)     // four pairs per lane: three waves per SIMD with half the alpha rows kept
-#ifndef E2E_F2_LDSPAD
-#define E2E_F2_LDSPAD 0
-#endif
 // (eight pairs per lane: 16 alpha rows of 16 cells are 256 registers by themselves -- one wave per SIMD, no spills)
-template <int PPL, bool O16>
-__global__ E2E_KERNEL_ALIGN __launch_bounds__(64, PPL == 8 ? 1 : PPL == 4 ? E2E_F2_MINW4 : E2E_F2_MINW) void ctc_fast_segment_kernel(FastParams p) {
+template <int PPL, bool O16, bool BIG = false>
+__global__ E2E_KERNEL_ALIGN __launch_bounds__(64 * E2E_F2_WPB, PPL == 8 ? 1 : PPL == 4 ? E2E_F2_MINW4 : E2E_F2_MINW) void ctc_fast_segment_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  SegParams<O16> q;
+  SegParams<O16, BIG> q;
   static_cast<FastParams&>(q) = p;
   segment_wave<PPL>(q, smem);
 }
 
 // the segment kernel behind a chain kernel: the instance of the gradient's element width
-template <int PPL>
+template <int PPL, bool BIG = false>
 int launch_segments(const FastParams& p, size_t lds, hipStream_t stream) {
-  if (dtype_is_16bit(p.xdt)) hipLaunchKernelGGL((ctc_fast_segment_kernel<PPL, true>), dim3(p.NS, p.B), dim3(64), lds, stream, p);
-  else hipLaunchKernelGGL((ctc_fast_segment_kernel<PPL, false>), dim3(p.NS, p.B), dim3(64), lds, stream, p);
+  const dim3 grid((p.NS + E2E_F2_WPB - 1) / E2E_F2_WPB, p.B), block(64 * E2E_F2_WPB);
+  if (E2E_F2_WPB > 1) lds = ((lds + 15) & ~(size_t)15) * E2E_F2_WPB;
+  if constexpr (BIG) {
+    if (dtype_is_16bit(p.xdt)) hipLaunchKernelGGL((ctc_fast_segment_kernel<PPL, true, true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((ctc_fast_segment_kernel<PPL, false, true>), grid, block, lds, stream, p);
+  } else
+  if (dtype_is_16bit(p.xdt)) hipLaunchKernelGGL((ctc_fast_segment_kernel<PPL, true>), grid, block, lds, stream, p);
+  else hipLaunchKernelGGL((ctc_fast_segment_kernel<PPL, false>), grid, block, lds, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_segment_kernel launch");
   return E2E_OK;
 }
@@ -1605,6 +1667,16 @@ constexpr bool kLeanDefault = true;    // (targets of 128..223 labels: 132.4 aga
 
 template <int PPL>
 int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
+  if (p.V > kMaxSmallV) {
+    // 97..224 columns: the halo chains over the f32 ring, the segment kernel's wide-row form (fast_supported: PPL == 4 here)
+    if constexpr (PPL == 4) {
+      const HfLds hl = HfLds::of<ChainF64W>(p.V);
+      E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<4, ChainF64W>), hl.total), "hipFuncSetAttribute");
+      hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<4, ChainF64W>), dim3(p.B), dim3(ChainF64W::kWaves * 64), hl.total, stream, p);
+      E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
+      return launch_segments<4, true>(p, F2Lds<4>::bytes(p.V) + E2E_F2_LDSPAD, stream);
+    } else { set_error("fast CTC path: %d columns need four pairs per lane", p.V); return E2E_ERR_UNSUPPORTED; }
+  }
   const size_t lds1 = F1Lds::bytes(p.V);
   E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL>), (int)lds1), "hipFuncSetAttribute");
   const size_t lds2 = F2Lds<PPL>::bytes(p.V) + E2E_F2_LDSPAD;
@@ -1654,15 +1726,22 @@ int ppl_for(int Smax) {
   return 0;
 }
 
+// ... of a call: alphabets beyond kMaxSmallV run on ChainF64W and the segment kernel's four-pairs form only
+int ppl_of(int V, int Smax) {
+  if (V > kMaxSmallV) return (V <= kMaxBigV && Smax + 1 <= ChainF64W::kMaxW * kHfOwn) ? 4 : 0;
+  return ppl_for(Smax);
+}
+
 struct FastLayout {
   size_t ytab, ckA, ckQ, ckE, cumA, cumB, trkA, trkB, logz, zt2, flags, segmask, cinfo, lstart, ctl, total;
-  int NS, NB, CELLS, MW;
+  int NS, NB, CELLS, MW, LS;
 };
 
 FastLayout fast_layout(int B, int T, int V, int Smax) {
   FastLayout l;
-  const int ppl = ppl_for(Smax);
+  const int ppl = ppl_of(V, Smax);
   l.CELLS = 128 * (ppl > 0 ? ppl : 1);
+  l.LS = max(130, 64 * ((V + 64) >> 6) + 2);
   l.NS = (T + kSeg - 1) / kSeg;
   l.NB = (T + kBlk - 1) / kBlk + 4;       // (cumA / cumB are read up to two blocks past an utterance's last)
   size_t o = 0;
@@ -1680,7 +1759,7 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
   l.MW = (l.NS + 31) / 32;
   l.segmask = o; o += align_up((size_t)B * l.MW * sizeof(unsigned), 256);
   l.cinfo = o; o += align_up((size_t)B * (l.CELLS / 2) * sizeof(unsigned), 256);
-  l.lstart = o; o += align_up((size_t)B * 130 * sizeof(int), 256);
+  l.lstart = o; o += align_up((size_t)B * l.LS * sizeof(int), 256);
   l.ctl = o; o += 256;
   l.total = o;
   return l;
@@ -1691,7 +1770,7 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
 bool fast_supported(int T, int V, int Smax, int dtype) {
   // (T: the halo chains tag their frame words with the block index in 19 bits)
   // (16-bit logits: read and written in their dtype around the same f32 lattice)
-  return (dtype == E2E_F32 || dtype_is_16bit(dtype)) && V >= 2 && V <= kMaxSmallV && ppl_for(Smax) != 0 && T < (1 << 22);
+  return (dtype == E2E_F32 || dtype_is_16bit(dtype)) && V >= 2 && ppl_of(V, Smax) != 0 && T < (1 << 22);
 }
 
 size_t fast_workspace_bytes(int B, int T, int V, int Smax) {
@@ -1720,14 +1799,14 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   p.zt2 = reinterpret_cast<double*>(ws + l.zt2);
   p.logz = reinterpret_cast<double*>(ws + l.logz); p.flags = reinterpret_cast<int*>(ws + l.flags);
   p.segmask = reinterpret_cast<unsigned*>(ws + l.segmask); p.MW = l.MW;
-  p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart);
+  p.cinfo = reinterpret_cast<unsigned*>(ws + l.cinfo); p.lstart = reinterpret_cast<int*>(ws + l.lstart); p.LS = l.LS;
   p.ctl = reinterpret_cast<int*>(ws + l.ctl);
   p.gscale = (float)a.grad_scale;
   p.ztol = kZTol;
   p.chains = a.chains;
   p.NS = l.NS; p.NB = l.NB; p.CELLS = l.CELLS;
   int rc;
-  switch (ppl_for(a.Smax)) {
+  switch (ppl_of(a.V, a.Smax)) {
     case 1: rc = launch_fast_ppl<1>(p, a.stream); break;
     case 2: rc = launch_fast_ppl<2>(p, a.stream); break;
     case 4: rc = launch_fast_ppl<4>(p, a.stream); break;
@@ -1740,7 +1819,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   // mode 1: redo flagged utterances exactly; mode 2: no fallback requested -> poison them
   FastRetry rt;
   rt.ytab = p.ytab; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.cumA = p.cumA; rt.cumB = p.cumB;
-  rt.NS = p.NS; rt.NB = p.NB; rt.CELLS = p.CELLS; rt.PPL = ppl_for(a.Smax); rt.logz = p.logz; rt.ctl = p.ctl;
+  rt.NS = p.NS; rt.NB = p.NB; rt.CELLS = p.CELLS; rt.PPL = ppl_of(a.V, a.Smax); rt.logz = p.logz; rt.ctl = p.ctl;
   rt.segmask = p.segmask; rt.MW = p.MW;
   return launch_exact_flagged(e, p.flags, fallback_to_exact ? 1 : 2, &rt);
 }

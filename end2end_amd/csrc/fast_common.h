@@ -26,6 +26,8 @@ constexpr int kRingBlks = 8;    // ring depth (blocks)
 constexpr int kRow32 = 12;      // floats per label row of an f32 ring block (ctc_fast_chain_hf_kernel): 8 steps + pad, 48 B
 constexpr int kRow = 10;        // doubles per label row of a ring block: 8 steps + pad (80 B spreads the 16-byte gathers over the banks)
 constexpr int kMaxSmallV = 96;  // alphabet columns the lattice kernels take (prep: <= 12 columns per lane)
+constexpr int kMaxBigV = 224;   // ... and with the wide-row forms of the halo chains and of the segment kernel (ChainF64W: f32 ring of
+                                // depth 4, 28 columns per producer lane, four label sets per gradient lane); targets of <= 223 labels
 
 struct FastParams {
   const void* x; int xdt;          // logits / log-probabilities and their dtype (E2E_F32 / E2E_F16 / E2E_BF16); the gradient has the same
@@ -49,8 +51,9 @@ struct FastParams {
   int* flags;      // [B]       != 0: redo with the exact kernel
   unsigned* segmask; // [B][MW]  bit s of an utterance's words: segment s failed its range / self-check (flag bits 8 / 16): the
   int MW;          //           f64 redo of the flagged-utterance launch takes those segments only; cleared by the chain kernel
-  unsigned* cinfo; // [B][CELLS/2]  per label pair: label | sorted slot << 8 (10 bits) | alpha skip << 20 | beta skip << 21
-  int* lstart;     // [B][130]  first label-sorted slot of every label (V+1 entries used)
+  unsigned* cinfo; // [B][CELLS/2]  per label pair: label (10 bits) | sorted slot << 10 (10 bits) | alpha skip << 20 | beta skip << 21
+  int* lstart;     // [B][LS]   first label-sorted slot of every label (V+1 entries used); LS = 64 * ceil((V+1)/64) + 2
+  int LS;
   int* ctl;        // [4]  0: fallback workgroups that have finished (F1 clears it; the last one reduces the losses);
                    //      1: flagged utterances the f64 redo of the segments could not settle (diagnostics)
   float gscale;    // every gradient element is multiplied by this as it is written (e2e_ctc_loss_opts.grad_scale)
@@ -312,15 +315,15 @@ struct LaneCells {
   }
   // the packed form F1 leaves in the workspace for F2 (one word per label pair; `slot` = label-sorted position)
   __device__ static unsigned pack(int lab, int slot, float skp, float skn) {
-    return (unsigned)lab | ((unsigned)slot << 8) | (skp != 0.f ? 1u << 20 : 0u) | (skn != 0.f ? 1u << 21 : 0u);
+    return (unsigned)lab | ((unsigned)slot << 10) | (skp != 0.f ? 1u << 20 : 0u) | (skn != 0.f ? 1u << 21 : 0u);
   }
   __device__ void unpack(const unsigned* w, int S, int T, int (&slot)[PPL]) {
     set_tilt(S, T);
     has_blank_label = false;
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
-      lab[q] = (int)(w[q] & 0xffu);
-      slot[q] = (int)((w[q] >> 8) & 0x3ffu);
+      lab[q] = (int)(w[q] & 0x3ffu);
+      slot[q] = (int)((w[q] >> 10) & 0x3ffu);
       skp[q] = (w[q] >> 20) & 1u ? r * r : 0.f;
       skn[q] = (w[q] >> 21) & 1u ? r * r : 0.f;
     }
@@ -357,7 +360,7 @@ struct F1Lds {
                      //  (114) allows -- measured +7 % at B = 1024 with the second workgroup's roles rotated onto SIMDs 1/3)
   int* filled;       // [2][kRingBlks]   probability block n of a direction is complete (== n+1)
   int* took;         // [2]              the direction's chain has read the probabilities of blocks < took
-  int* sortcnt;      // [130] counting-sort scratch of the cell-info wave
+  int* sortcnt;      // [130] counting-sort scratch of the cell-info wave (V <= 96 here: two chunks of 64 labels + 2)
   int blk_elems;
   static constexpr int kSyncInts = 2 * kRingBlks + 2;
   __device__ F1Lds(unsigned char* smem, int V) {
@@ -536,6 +539,110 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 #endif
 }
 
+// Hand-off waits are bounded: a protocol error flags the utterance (bit 128 -> the exact kernel redoes it) instead of
+// hanging the GPU.  (~2^20 polls of >= 64 cycles: far beyond any legitimate wait.)
+#define HALO_WAIT(cond)                                                                          \
+  do {                                                                                           \
+    if (!(cond)) {                                                                               \
+      int _spins = 0;                                                                            \
+      do { __builtin_amdgcn_s_sleep(1); if (++_spins > (1 << 20)) { atomicOr(&p.flags[b], 128); break; } } while (!(cond)); \
+    }                                                                                            \
+    asm volatile("" ::: "memory");                                                               \
+  } while (0)
+
+// prep_wave's MODE 2 (f32 ring with a row of (blank probability, tilted blank probability) pairs) for alphabets of up to 8 * NV
+// = 224 columns: the chains of ChainF64W.  What differs: a ring of RING blocks (the rows are 2.3 times as long), TWO register
+// sets in flight instead of three (56 instead of 84 registers at NV = 28) and column offsets that are computed, not held.
+// A separate function so that the kernels of the small alphabets keep their code as it was measured.
+template <int NV, int RING>
+__device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T, int dir, int first, int stride,
+                                              unsigned char* myring_bytes, int blk_bytes, volatile int* myfilled, int lane,
+                                              lds_u8* prog, double rr2) {
+  const int V = p.V;
+  const int nblk = (T + kBlk - 1) / kBlk;
+  const int64_t xo = (int64_t)b * p.sB;
+  float* ytab = p.ytab + (size_t)b * p.T * V;
+  const int tt = lane >> 3, l8 = lane & 7;
+  const float ninf = -__builtin_huge_valf();
+  const int64_t c0 = (int64_t)l8 * p.sV, cstep = 8 * p.sV;
+  auto load_block = [&](auto f32_tag, int n, float (&out)[NV]) {
+    constexpr bool F32IN = decltype(f32_tag)::value;
+    const int t = block_time(dir, n, tt, T);
+    const bool row_live = n < nblk && t < T;
+    const int64_t xr = xo + (int64_t)(row_live ? t : 0) * p.sT + c0;       // (unconditional loads from clamped addresses, as above)
+    const bool bf = p.xdt == E2E_BF16;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const int64_t o = xr + (l8 + 8 * k < V ? k * cstep : 0);
+      if (F32IN) out[k] = reinterpret_cast<const float*>(p.x)[o];
+      else {
+        const unsigned short h = reinterpret_cast<const unsigned short*>(p.x)[o];
+        out[k] = bf ? __uint_as_float((unsigned)h << 16) : (float)__builtin_bit_cast(f16_t, h);
+      }
+    }
+  };
+  int consumed = 0;
+  float lpmin = 0.f;
+  auto process = [&](int n, const float (&xraw)[NV]) {
+    if (n >= nblk) return;
+    const int t = block_time(dir, n, tt, T);
+    const bool row_live = t < T;
+    float y[NV];
+    if (p.logprobs) {
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        const float xv = (row_live && l8 + 8 * k < V) ? xraw[k] : ninf;
+        y[k] = exp_le0(xv);
+        lpmin = fminf(lpmin, xv > ninf ? xv : 0.f);
+      }
+    } else {
+      float m = ninf;
+#pragma unroll
+      for (int k = 0; k < NV; k++) m = fmaxf(m, (row_live && l8 + 8 * k < V) ? xraw[k] : ninf);
+      m = row8_max(m);
+      float ssum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        const float xv = (row_live && l8 + 8 * k < V) ? xraw[k] : ninf;
+        y[k] = exp_le0(xv - m); ssum += y[k];
+        lpmin = fminf(lpmin, xv > ninf ? xv - m : 0.f);
+      }
+      ssum = row8_sum(ssum);
+      float inv = __builtin_amdgcn_rcpf(ssum);
+      inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);
+#pragma unroll
+      for (int k = 0; k < NV; k++) y[k] *= inv;
+    }
+    if (n >= RING && consumed < n - RING + 1)       // (bounded: a protocol error flags the utterance instead of hanging)
+      HALO_WAIT((consumed = __builtin_amdgcn_readfirstlane(lds_min8(prog))) >= n - RING + 1);
+    float* blk32 = reinterpret_cast<float*>(myring_bytes + (size_t)(n % RING) * blk_bytes);
+    float* yrow = ytab + (size_t)(row_live ? t : 0) * V;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const int v = l8 + 8 * k;
+      if (v < V) {
+        blk32[v * kRow32 + tt] = row_live ? y[k] : 0.f;                   // transposed: [label][step]
+        if (v == p.blank) {
+          float2 yw; yw.x = row_live ? y[k] : 0.f; yw.y = row_live ? (float)rr2 * y[k] : 0.f;
+          *reinterpret_cast<float2*>(blk32 + (V + 1) * kRow32 + 2 * tt) = yw;
+        }
+        if (dir == 0 && row_live) yrow[v] = y[k];
+      }
+    }
+    publish(&myfilled[first], n + stride);
+  };
+  auto run = [&](auto f32_tag) {
+    float xa[NV], xb[NV];
+    load_block(f32_tag, first, xa);
+    for (int n = first; n < nblk; n += 2 * stride) {
+      load_block(f32_tag, n + stride, xb); process(n, xa);
+      load_block(f32_tag, n + 2 * stride, xa); process(n + stride, xb);
+    }
+  };
+  if (p.xdt == E2E_F32) run(std::true_type{}); else run(std::false_type{});
+  if (dir == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], 64); }       // (see prep_wave)
+}
+
 // Per-utterance lattice description for F2, computed once here instead of once per 16-step segment there (63x at
 // T = 1000): label, skip flags and the label-sorted slot of every label pair, plus the first slot of every label.
 // Counting sort of the label cells by label: cell i -> start[label] + (its order inside the label); cells past
@@ -543,7 +650,9 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 template <int PPL>
 __device__ __forceinline__ void cellinfo_wave(const FastParams& p, int b, int T, int S, int* cnt, int lane) {
   const int V = p.V;
-  cnt[lane] = 0; cnt[64 + lane] = 0; if (lane < 2) cnt[128 + lane] = 0;
+  const int nch = (V + 64) >> 6;             // chunks of 64 labels that hold 0..V (two for V <= 127; cnt: [64 * nch + 2], <= 258)
+  for (int c = 0; c < nch; c++) cnt[64 * c + lane] = 0;
+  if (lane < 2) cnt[64 * nch + lane] = 0;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   LaneCells<PPL> lc;
   lc.load(p.targets + (int64_t)b * p.tgt_stride, S, T, V, p.blank, lane);
@@ -554,17 +663,18 @@ __device__ __forceinline__ void cellinfo_wave(const FastParams& p, int b, int T,
     rank[r] = (i < S && lc.lab[r] < V) ? atomicAdd(&cnt[lc.lab[r]], 1) : 0;    // ds_add_rtn_u32
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  int* ls = p.lstart + (size_t)b * 130;
+  int* ls = p.lstart + (size_t)b * p.LS;
   {
-    // exclusive prefix over the label counts, two chunks of 64 labels
-    const int c0 = cnt[lane], c1 = cnt[64 + lane];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int i0 = wave_scan(c0);
-    const int t0s = __builtin_amdgcn_readlane(i0, 63);
-    const int i1 = wave_scan(c1) + t0s;
-    cnt[lane] = i0 - c0; ls[lane] = i0 - c0;
-    cnt[64 + lane] = i1 - c1; ls[64 + lane] = i1 - c1;
-    if (lane == 63) { cnt[128] = i1; ls[128] = i1; ls[129] = i1; }
+    // exclusive prefix over the label counts, chunk by chunk
+    int carry = 0;
+    for (int c = 0; c < nch; c++) {
+      const int cc = cnt[64 * c + lane];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int inc = wave_scan(cc) + carry;
+      cnt[64 * c + lane] = inc - cc; ls[64 * c + lane] = inc - cc;
+      carry = __builtin_amdgcn_readlane(inc, 63);
+    }
+    if (lane == 63) { cnt[64 * nch] = carry; ls[64 * nch] = carry; ls[64 * nch + 1] = carry; }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   unsigned* ci = p.cinfo + (size_t)b * (p.CELLS / 2) + PPL * lane;
@@ -599,17 +709,6 @@ __device__ __forceinline__ void cellinfo_wave(const FastParams& p, int b, int T,
 constexpr int kHaloSlots = 8;                 // ring depth (blocks) of the published exponents and edge lanes
 constexpr int kHaloLag = 2;                   // blocks between measuring the row's exponent and removing it
 constexpr int kHaloIdle = 0x3fffffff;         // prog[] of a wave that holds no cell of the utterance
-
-// Hand-off waits are bounded: a protocol error flags the utterance (bit 128 -> the exact kernel redoes it) instead of
-// hanging the GPU.  (~2^20 polls of >= 64 cycles: far beyond any legitimate wait.)
-#define HALO_WAIT(cond)                                                                          \
-  do {                                                                                           \
-    if (!(cond)) {                                                                               \
-      int _spins = 0;                                                                            \
-      do { __builtin_amdgcn_s_sleep(1); if (++_spins > (1 << 20)) { atomicOr(&p.flags[b], 128); break; } } while (!(cond)); \
-    }                                                                                            \
-    asm volatile("" ::: "memory");                                                               \
-  } while (0)
 
 // The frame wave of a direction decides the exponent every chain wave removes at the end of block n: the absolute
 // exponent of the row's largest cell at the end of block n - kHaloLag, less what has been removed up to block n-1, so

@@ -1,4 +1,4 @@
-# usage (on the GPU box, from the repo root): bash tools/diag/measure_round3.sh TAG [full]
+# usage (on the GPU box, from the repo root): bash tools/diag/measure_round4.sh TAG [full]
 # bench line + rocprofv3 kernel stats + SQ counters (+ FETCH/WRITE passes with PMC=1) of the default bench command
 TAG=${1:-x}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
