@@ -378,10 +378,18 @@ struct ChainF64L : ChainF64 {
 //             all): the probability ring is f32 -- what the producers compute anyway -- and four blocks deep, 87 KB at 224
 //             columns (f64 and eight deep: 290 KB); a chain wave converts what it reads (four conversions per step) and forms
 //             the tilted blank probability itself.  Same cells, same recurrence, same results as ChainF64.
+#ifndef E2E_W_PRODUCERS
+#define E2E_W_PRODUCERS 4
+#endif
 struct ChainF64W : ChainF64 {
   typedef float R;
   static constexpr bool kBigV = true;
   static constexpr int kRing = 4, kRingElem = 4, kRowElems = kRow32;
+  // the producers are what bounds these chains (28 columns per lane and block: ~700 instructions): four per direction, 16 waves,
+  // 128 registers -- the plain block loop, as ChainF64L
+  static constexpr int kProducers = E2E_W_PRODUCERS;
+  static constexpr int kWaves = 2 * kMaxW + 2 + 2 * kProducers + 2;
+  static constexpr bool kPairedLoop = E2E_W_PRODUCERS <= 2;
 };
 
 struct HfLds {
@@ -811,6 +819,44 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
     else if (V <= 64) prep_wave<8, MODE>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
     else prep_wave<12, MODE>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, nullptr, lane, prog, rr2);
   }
+}
+
+// The probabilities of every live frame for ChainF64W (see prep_wave_big): one wave per frame, up to four columns per lane;
+// fused log-softmax for raw logits (ctc_loss.cpp reads log-probabilities: CTCLoss applies log_softmax first).
+__global__ __launch_bounds__(256) void ctc_fast_prob_kernel(FastParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)p.B * p.T) return;
+  const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T), V = p.V;
+  const int64_t Tq = p.x_len[b];
+  if (Tq < 1 || Tq > p.T || t >= Tq) return;
+  const int64_t xr = (int64_t)b * p.sB + (int64_t)t * p.sT;
+  const float ninf = -__builtin_huge_valf();
+  constexpr int NK = (kMaxBigV + 63) / 64;
+  float x[NK];
+#pragma unroll
+  for (int k = 0; k < NK; k++) { const int v = lane + 64 * k; x[k] = v < V ? load_elem(p.x, xr + (int64_t)v * p.sV, p.xdt) : ninf; }
+  float y[NK];
+  if (p.logprobs) {
+#pragma unroll
+    for (int k = 0; k < NK; k++) y[k] = (x[k] > ninf && x[k] < -69.f) ? kTinyProb : exp_le0(x[k]);
+  } else {
+    float m = x[0];
+#pragma unroll
+    for (int k = 1; k < NK; k++) m = fmaxf(m, x[k]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float ssum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; k++) { y[k] = exp_le0(x[k] - m); ssum += y[k]; }
+    ssum = wave_sum(ssum);
+    float inv = __builtin_amdgcn_rcpf(ssum);
+    inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);        // one Newton step: ~0.5 ulp
+#pragma unroll
+    for (int k = 0; k < NK; k++) y[k] = (x[k] > ninf && x[k] - m < -69.f) ? kTinyProb : y[k] * inv;
+  }
+  float* yrow = p.ytab + (size_t)row * V;
+#pragma unroll
+  for (int k = 0; k < NK; k++) { const int v = lane + 64 * k; if (v < V) yrow[v] = y[k]; }
 }
 
 // ============================================================================================
@@ -1670,6 +1716,8 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   if (p.V > kMaxSmallV) {
     // 97..224 columns: the halo chains over the f32 ring, the segment kernel's wide-row form (fast_supported: PPL == 4 here)
     if constexpr (PPL == 4) {
+      hipLaunchKernelGGL(ctc_fast_prob_kernel, dim3((unsigned)(((int64_t)p.B * p.T + 3) / 4)), dim3(256), 0, stream, p);
+      E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_prob_kernel launch");
       const HfLds hl = HfLds::of<ChainF64W>(p.V);
       E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<4, ChainF64W>), hl.total), "hipFuncSetAttribute");
       hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<4, ChainF64W>), dim3(p.B), dim3(ChainF64W::kWaves * 64), hl.total, stream, p);

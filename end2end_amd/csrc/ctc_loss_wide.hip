@@ -63,9 +63,11 @@ __global__ __launch_bounds__(256) void wide_compact_kernel(WideParams p) {
   for (int k = tid; k < p.VC; k += 256) p.clabel[(size_t)b * p.VC + k] = (k == p.VC - 1) ? p.blank : -1;
   __syncthreads();
   for (int i = tid; i < S; i += 256) {
+    // (no early exit: the reads of lab[k] are then independent and pipeline -- with a break every iteration waited for its
+    //  LDS read, 23 us for 200 labels)
     const int li = lab[i];
     int r = i;
-    for (int k = 0; k < i; k++) if (lab[k] == li) { r = k; break; }
+    for (int k = i - 1; k >= 0; k--) r = lab[k] == li ? k : r;
     rep[i] = r;
   }
   __syncthreads();
@@ -441,9 +443,15 @@ __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
   const float* xc = p.xc + (size_t)row * p.VC;
   const int* cl = p.clabel + (size_t)b * p.VC;
   const float sh = p.shift[row];
+  // A column whose posterior is nothing in f32 -- the lattice's prob - posterior came back as the probability itself, bit for
+  // bit: the label cannot be emitted at this frame, or so unlikely that the subtraction does not change the number -- already
+  // holds its value (wide_rows_dense_kernel wrote the probability) and is left alone: a 4-byte store into a line that has
+  // left the caches is a read-modify-write of the line in DRAM, and those stores are what this kernel's time consists of.
   for (int k = lane; k < p.VC; k += 64) {
     const int l = cl[k];
-    if (l >= 0) gr[l] = (E)((exp_acc(xc[k] + sh) - (exp_acc(xc[k]) - gc[k])) * p.gscale);
+    const float xk = xc[k], gk = gc[k];
+    const float yk = exp_acc(xk);
+    if (l >= 0 && gk != yk) gr[l] = (E)((exp_acc(xk + sh) - (yk - gk)) * p.gscale);
   }
 }
 

@@ -550,97 +550,67 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
     asm volatile("" ::: "memory");                                                               \
   } while (0)
 
-// prep_wave's MODE 2 (f32 ring with a row of (blank probability, tilted blank probability) pairs) for alphabets of up to 8 * NV
-// = 224 columns: the chains of ChainF64W.  What differs: a ring of RING blocks (the rows are 2.3 times as long), TWO register
-// sets in flight instead of three (56 instead of 84 registers at NV = 28) and column offsets that are computed, not held.
-// A separate function so that the kernels of the small alphabets keep their code as it was measured.
+// The halo chains' producers for alphabets of 97..224 columns (ChainF64W): prep_wave's MODE 2 layout -- an f32 ring of label rows
+// and one row of (blank probability, tilted blank probability) pairs --, a ring of RING blocks (the rows are 2.3 times as long),
+// and NO arithmetic: with 28 columns per lane a block cost a producer ~700 instructions, the exponentials were computed twice
+// (alpha side, beta side) and the producers, not the chains, set the kernel's speed (510 cycles per step against 150).  The
+// probabilities are therefore computed ONCE, by the whole chip, in a launch of their own (ctc_fast_prob_kernel, which fills
+// ytab); a producer only moves a block's rows from ytab into the ring, transposed.
+constexpr float kTinyProb = 1e-35f;       // ytab marker: a FINITE log-probability below -69 (e^-69 = 1.08e-30 = 2^-100)
 template <int NV, int RING>
 __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T, int dir, int first, int stride,
                                               unsigned char* myring_bytes, int blk_bytes, volatile int* myfilled, int lane,
                                               lds_u8* prog, double rr2) {
   const int V = p.V;
   const int nblk = (T + kBlk - 1) / kBlk;
-  const int64_t xo = (int64_t)b * p.sB;
-  float* ytab = p.ytab + (size_t)b * p.T * V;
+  const float* ytab = p.ytab + (size_t)b * p.T * V;
   const int tt = lane >> 3, l8 = lane & 7;
-  const float ninf = -__builtin_huge_valf();
-  const int64_t c0 = (int64_t)l8 * p.sV, cstep = 8 * p.sV;
-  auto load_block = [&](auto f32_tag, int n, float (&out)[NV]) {
-    constexpr bool F32IN = decltype(f32_tag)::value;
+  // two register sets in flight: the rows of this wave's next block are requested before the current one is stored
+  // (unconditional loads from clamped addresses; what a dead row or column reads is replaced when it is used)
+  auto load_block = [&](int n, float (&out)[NV]) {
     const int t = block_time(dir, n, tt, T);
     const bool row_live = n < nblk && t < T;
-    const int64_t xr = xo + (int64_t)(row_live ? t : 0) * p.sT + c0;       // (unconditional loads from clamped addresses, as above)
-    const bool bf = p.xdt == E2E_BF16;
+    const float* yr = ytab + (size_t)(row_live ? t : 0) * V + l8;
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-      const int64_t o = xr + (l8 + 8 * k < V ? k * cstep : 0);
-      if (F32IN) out[k] = reinterpret_cast<const float*>(p.x)[o];
-      else {
-        const unsigned short h = reinterpret_cast<const unsigned short*>(p.x)[o];
-        out[k] = bf ? __uint_as_float((unsigned)h << 16) : (float)__builtin_bit_cast(f16_t, h);
-      }
-    }
+    for (int k = 0; k < NV; k++) out[k] = yr[l8 + 8 * k < V ? 8 * k : 0];
   };
   int consumed = 0;
-  float lpmin = 0.f;
-  auto process = [&](int n, const float (&xraw)[NV]) {
+  bool tiny = false;
+  auto process = [&](int n, const float (&yraw)[NV]) {
     if (n >= nblk) return;
     const int t = block_time(dir, n, tt, T);
     const bool row_live = t < T;
-    float y[NV];
-    if (p.logprobs) {
-#pragma unroll
-      for (int k = 0; k < NV; k++) {
-        const float xv = (row_live && l8 + 8 * k < V) ? xraw[k] : ninf;
-        y[k] = exp_le0(xv);
-        lpmin = fminf(lpmin, xv > ninf ? xv : 0.f);
-      }
-    } else {
-      float m = ninf;
-#pragma unroll
-      for (int k = 0; k < NV; k++) m = fmaxf(m, (row_live && l8 + 8 * k < V) ? xraw[k] : ninf);
-      m = row8_max(m);
-      float ssum = 0.f;
-#pragma unroll
-      for (int k = 0; k < NV; k++) {
-        const float xv = (row_live && l8 + 8 * k < V) ? xraw[k] : ninf;
-        y[k] = exp_le0(xv - m); ssum += y[k];
-        lpmin = fminf(lpmin, xv > ninf ? xv - m : 0.f);
-      }
-      ssum = row8_sum(ssum);
-      float inv = __builtin_amdgcn_rcpf(ssum);
-      inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);
-#pragma unroll
-      for (int k = 0; k < NV; k++) y[k] *= inv;
-    }
     if (n >= RING && consumed < n - RING + 1)       // (bounded: a protocol error flags the utterance instead of hanging)
       HALO_WAIT((consumed = __builtin_amdgcn_readfirstlane(lds_min8(prog))) >= n - RING + 1);
     float* blk32 = reinterpret_cast<float*>(myring_bytes + (size_t)(n % RING) * blk_bytes);
-    float* yrow = ytab + (size_t)(row_live ? t : 0) * V;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       const int v = l8 + 8 * k;
       if (v < V) {
-        blk32[v * kRow32 + tt] = row_live ? y[k] : 0.f;                   // transposed: [label][step]
-        if (v == p.blank) {
-          float2 yw; yw.x = row_live ? y[k] : 0.f; yw.y = row_live ? (float)rr2 * y[k] : 0.f;
-          *reinterpret_cast<float2*>(blk32 + (V + 1) * kRow32 + 2 * tt) = yw;
-        }
-        if (dir == 0 && row_live) yrow[v] = y[k];
+        const float y = row_live ? yraw[k] : 0.f;
+        tiny |= y > 0.f && y < 1e-30f;
+        blk32[v * kRow32 + tt] = y;                                        // transposed: [label][step]
       }
+    }
+    // the blank's pairs: read back from the row this wave has just written (the LDS runs a wave's operations in order)
+    if (l8 == 0) {
+      const float yb = blk32[p.blank * kRow32 + tt];
+      float2 yw; yw.x = yb; yw.y = (float)rr2 * yb;
+      *reinterpret_cast<float2*>(blk32 + (V + 1) * kRow32 + 2 * tt) = yw;
     }
     publish(&myfilled[first], n + stride);
   };
-  auto run = [&](auto f32_tag) {
+  {
     float xa[NV], xb[NV];
-    load_block(f32_tag, first, xa);
+    load_block(first, xa);
     for (int n = first; n < nblk; n += 2 * stride) {
-      load_block(f32_tag, n + stride, xb); process(n, xa);
-      load_block(f32_tag, n + 2 * stride, xa); process(n + stride, xb);
+      load_block(n + stride, xb); process(n, xa);
+      load_block(n + 2 * stride, xa); process(n + stride, xb);
     }
-  };
-  if (p.xdt == E2E_F32) run(std::true_type{}); else run(std::false_type{});
-  if (dir == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], 64); }       // (see prep_wave)
+  }
+  // Probabilities are f32: below ~2^-126 they are flushed (see prep_wave: reason bit 64, the exact kernel recomputes the
+  // utterance); the launch that filled ytab left kTinyProb wherever a finite log-probability lay below -69
+  if (dir == 0 && __any(tiny)) { if (lane == 0) atomicOr(&p.flags[b], 64); }
 }
 
 // Per-utterance lattice description for F2, computed once here instead of once per 16-step segment there (63x at

@@ -569,6 +569,76 @@ def test_long_transcripts_take_the_fast_path(shape):
         U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
 
 
+@pytest.mark.parametrize("logprobs", [False, True], ids=["logits", "logprobs"])
+@pytest.mark.parametrize("shape", [(2, 300, 97, 120), (3, 200, 128, 100), (2, 256, 129, 150), (3, 400, 224, 223), (2, 300, 200, 40),
+                                   (4, 64, 177, 30)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)
+def test_alphabets_of_97_to_224_columns_take_the_fast_path(shape, logprobs):
+    """alphabets beyond 96 columns -- above all the compacted word-piece targets of more than 95 pieces --
+    run on the fast lattice kernels (ChainF64W: halo chains over an f32 probability ring filled from a table that
+    ctc_fast_prob_kernel computes once; the segment kernel's wide-row form): ALGO_FAST leaves no NaN, results equal the
+    oracle at the default tolerances; ragged lengths, a repeated label.  (src/losses/ctc_loss.cpp:25-36: no bound on V.)"""
+    B, T, V, S = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, V, generator=g)
+    if logprobs:
+        x = torch.log_softmax(x, -1)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tg[0, 3] = tg[0, 2]
+    xl = torch.tensor([T] + [T - 9 * (b + 1) for b in range(B - 1)])
+    tl = torch.tensor([S] + [max(1, S - 17 * (b + 1)) for b in range(B - 1)])
+    lf, gf = U.c_abi_loss(x, tg, xl, tl, 0, logprobs, _lib.ALGO_FAST)
+    assert np.isfinite(lf).all(), "the fast path flagged %d of %d utterances" % (int(np.isnan(lf).sum()), B)
+    lp = (x.double() if logprobs else torch.log_softmax(x.double(), -1)).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    if not logprobs:
+        for b in range(B):
+            g_o[b, xl[b]:] = 0
+    U.assert_same(lf, l_o, F32_RTOL, F32_ATOL * 10, "losses")
+    U.assert_same(gf, g_o, F32_RTOL, F32_ATOL, "grads")
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 8000, 200), (2, 150, 32000, 120), (3, 300, 4096, 223)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)
+def test_word_piece_targets_of_more_than_95_pieces_take_the_fast_lattice(shape):
+    """The wide path's compaction leaves up to Smax + 1 columns; beyond 96 of them the lattice used to be the exact kernel's
+    (0.73 ms at B=64, T=256, V=8000, S<=200).  Under ALGO_FAST -- no fallback -- nothing may come back NaN-poisoned."""
+    B, T, V, S = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tg[0, 5] = tg[0, 4]
+    xl = torch.tensor([T] + [T - 13] * (B - 1)); tl = torch.tensor([S] + [S - 30] * (B - 1))
+    lf, gf = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    assert np.isfinite(lf).all(), "the fast path flagged %d of %d utterances" % (int(np.isnan(lf).sum()), B)
+    lp = torch.log_softmax(x.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0
+    U.assert_same(lf, l_o, F32_RTOL, F32_ATOL * 10, "losses")
+    U.assert_same(gf, g_o, F32_RTOL, 5e-7, "grads")
+
+
+def test_tiny_probabilities_at_a_wide_alphabet_are_handed_to_the_exact_kernel():
+    """ChainF64W's probability table marks a FINITE log-probability below -69 (f32 would flush what the lattice makes of it);
+    the producers flag the utterance (reason bit 64) and the exact kernel recomputes it: AUTO equals the oracle, FAST poisons
+    that utterance only.  A log-probability of -inf -- an impossible symbol -- is exact and flags nothing."""
+    g = torch.Generator().manual_seed(21)
+    B, T, V, S = 3, 60, 150, 20
+    lp = torch.log_softmax(torch.randn(B, T, V, generator=g, dtype=torch.float64), -1)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    lp[1, 10:20, 1:] -= 85.0                     # ten frames where every label is ~e-90
+    lp[2, :, 149] = -float("inf")               # a symbol that cannot occur ...
+    tg[2][tg[2] == 149] = 7                      # ... and does not
+    lp = lp.float()
+    xl, tl = [T] * B, [S] * B
+    l_o, g_o = O.ctc_loss(lp.double().numpy(), tg.numpy(), xl, tl, 0)
+    losses, grads = U.c_abi_loss(lp, tg, xl, tl, 0, True, _lib.ALGO_AUTO)
+    U.assert_same(losses, l_o, F32_RTOL, F32_ATOL, "losses")
+    U.assert_same(grads, g_o, F32_RTOL, F32_ATOL, "grads")
+    lf, gf = U.c_abi_loss(lp, tg, xl, tl, 0, True, _lib.ALGO_FAST)
+    assert np.isnan(lf[1]) and np.isfinite(lf[[0, 2]]).all()
+    U.assert_same(gf[[0, 2]], g_o[[0, 2]], F32_RTOL, F32_ATOL, "grads of the utterances the fast path kept")
+
+
 def test_flagged_launch_with_more_utterances_than_its_flag_cache():
     """3000 utterances (the flagged launch caches 2048 flag words in LDS and reads the rest from memory; 24 alpha slabs serve
     every utterance that needs the reference's arithmetic): blank-valued targets and impossible lengths sprinkled over the
