@@ -821,42 +821,53 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
   }
 }
 
-// The probabilities of every live frame for ChainF64W (see prep_wave_big): one wave per frame, up to four columns per lane;
-// fused log-softmax for raw logits (ctc_loss.cpp reads log-probabilities: CTCLoss applies log_softmax first).
+// The probabilities of every live frame for ChainF64W (see prep_wave_big): a wave takes kProbRows consecutive frames at once
+// (their loads are all in flight together: one frame per wave left the kernel latency-bound at 3.3 TB/s), up to four columns per
+// lane; fused log-softmax for raw logits (ctc_loss.cpp reads log-probabilities: CTCLoss applies log_softmax first).
+constexpr int kProbRows = 4;
 __global__ __launch_bounds__(256) void ctc_fast_prob_kernel(FastParams p) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (int64_t)p.B * p.T) return;
-  const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T), V = p.V;
-  const int64_t Tq = p.x_len[b];
-  if (Tq < 1 || Tq > p.T || t >= Tq) return;
-  const int64_t xr = (int64_t)b * p.sB + (int64_t)t * p.sT;
+  const int lane = threadIdx.x & 63, V = p.V;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kProbRows, nrows = (int64_t)p.B * p.T;
+  if (row0 >= nrows) return;
   const float ninf = -__builtin_huge_valf();
   constexpr int NK = (kMaxBigV + 63) / 64;
-  float x[NK];
+  float x[kProbRows][NK];
+  bool live[kProbRows];
 #pragma unroll
-  for (int k = 0; k < NK; k++) { const int v = lane + 64 * k; x[k] = v < V ? load_elem(p.x, xr + (int64_t)v * p.sV, p.xdt) : ninf; }
-  float y[NK];
-  if (p.logprobs) {
+  for (int r = 0; r < kProbRows; r++) {
+    const int64_t row = row0 + r < nrows ? row0 + r : nrows - 1;
+    const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+    const int64_t Tq = p.x_len[b];
+    live[r] = row0 + r < nrows && Tq >= 1 && Tq <= p.T && t < Tq;
+    const int64_t xr = (int64_t)b * p.sB + (int64_t)t * p.sT;
 #pragma unroll
-    for (int k = 0; k < NK; k++) y[k] = (x[k] > ninf && x[k] < -69.f) ? kTinyProb : exp_le0(x[k]);
-  } else {
-    float m = x[0];
-#pragma unroll
-    for (int k = 1; k < NK; k++) m = fmaxf(m, x[k]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    float ssum = 0.f;
-#pragma unroll
-    for (int k = 0; k < NK; k++) { y[k] = exp_le0(x[k] - m); ssum += y[k]; }
-    ssum = wave_sum(ssum);
-    float inv = __builtin_amdgcn_rcpf(ssum);
-    inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);        // one Newton step: ~0.5 ulp
-#pragma unroll
-    for (int k = 0; k < NK; k++) y[k] = (x[k] > ninf && x[k] - m < -69.f) ? kTinyProb : y[k] * inv;
+    for (int k = 0; k < NK; k++) { const int v = lane + 64 * k; x[r][k] = v < V ? load_elem(p.x, xr + (int64_t)v * p.sV, p.xdt) : ninf; }
   }
-  float* yrow = p.ytab + (size_t)row * V;
 #pragma unroll
-  for (int k = 0; k < NK; k++) { const int v = lane + 64 * k; if (v < V) yrow[v] = y[k]; }
+  for (int r = 0; r < kProbRows; r++) {
+    if (!live[r]) continue;                                  // (wave-uniform)
+    float y[NK];
+    if (p.logprobs) {
+#pragma unroll
+      for (int k = 0; k < NK; k++) y[k] = (x[r][k] > ninf && x[r][k] < -69.f) ? kTinyProb : exp_le0(x[r][k]);
+    } else {
+      float m = x[r][0];
+#pragma unroll
+      for (int k = 1; k < NK; k++) m = fmaxf(m, x[r][k]);
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float ssum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NK; k++) { y[k] = exp_le0(x[r][k] - m); ssum += y[k]; }
+      ssum = wave_sum(ssum);
+      float inv = __builtin_amdgcn_rcpf(ssum);
+      inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);        // one Newton step: ~0.5 ulp
+#pragma unroll
+      for (int k = 0; k < NK; k++) y[k] = (x[r][k] > ninf && x[r][k] - m < -69.f) ? kTinyProb : y[k] * inv;
+    }
+    float* yrow = p.ytab + (size_t)(row0 + r) * V;
+#pragma unroll
+    for (int k = 0; k < NK; k++) { const int v = lane + 64 * k; if (v < V) yrow[v] = y[k]; }
+  }
 }
 
 // ============================================================================================
@@ -1716,7 +1727,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   if (p.V > kMaxSmallV) {
     // 97..224 columns: the halo chains over the f32 ring, the segment kernel's wide-row form (fast_supported: PPL == 4 here)
     if constexpr (PPL == 4) {
-      hipLaunchKernelGGL(ctc_fast_prob_kernel, dim3((unsigned)(((int64_t)p.B * p.T + 3) / 4)), dim3(256), 0, stream, p);
+      hipLaunchKernelGGL(ctc_fast_prob_kernel, dim3((unsigned)(((int64_t)p.B * p.T + 4 * kProbRows - 1) / (4 * kProbRows))), dim3(256), 0, stream, p);
       E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_prob_kernel launch");
       const HfLds hl = HfLds::of<ChainF64W>(p.V);
       E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<4, ChainF64W>), hl.total), "hipFuncSetAttribute");
