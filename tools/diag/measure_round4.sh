@@ -20,3 +20,12 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print({k:d[k] for k in ('value','ms_per_step','module_ms_per_step')}, d['roofline']['kernel_ms'], d['roofline']['frac'], d['roofline']['peak_measured'])
 "
+if [ "$2" = full ]; then
+# the other kernel families, the wide-alphabet share in both dtypes, the word-piece shapes
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_others_$TAG -o others -- python3 tools/diag/profile_others.py > gpurun_out/prof_others_$TAG.log 2>&1 < /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c5_f32_$TAG -o c5 -- python3 tools/diag/profile_c5.py > gpurun_out/prof_c5_f32_$TAG.log 2>&1 < /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c5_bf16_$TAG -o c5 -- python3 tools/diag/profile_c5.py bf16 > gpurun_out/prof_c5_bf16_$TAG.log 2>&1 < /dev/null
+bash tools/diag/profile_shape.sh wp8k_$TAG 64 256 8000 200 > /dev/null
+bash tools/diag/profile_shape.sh wp32k_$TAG 16 150 32000 120 > /dev/null
+bash tools/diag/profile_shape.sh mid_$TAG 256 1000 200 200 > /dev/null
+fi
