@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
   const float qnan = __builtin_nanf("");
   // label columns (prob - posterior, with posterior = exp(xc) - gc in the shifted compact space): fetched and computed
   // up front, written after the dense row
-  constexpr int kMaxFix = 2;            // VC <= 128 columns
+  constexpr int kMaxFix = 2;            // the first 128 compact columns (the rest: after the row, below)
   float fix[kMaxFix]; int fixcol[kMaxFix];
 #pragma unroll
   for (int u = 0; u < kMaxFix; u++) { fix[u] = 0.f; fixcol[u] = -1; }
@@ -266,6 +266,19 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
     __builtin_amdgcn_s_waitcnt(0);
 #pragma unroll
     for (int u = 0; u < kMaxFix; u++) if (fixcol[u] >= 0) gr[fixcol[u]] = fix[u];
+    // compact columns beyond the 128 fetched up front (targets of more than 127 distinct labels)
+    const float* gc = p.gc + (size_t)row * p.VC;
+    const int* cl = p.clabel + (size_t)b * p.VC;
+    const float sh = live ? p.shift[row] : 0.f;
+    for (int k = lane + 64 * kMaxFix; k < p.VC; k += 64) {
+      const int l = cl[k];
+      if (l >= 0 && live) {
+        const float xl = xr[(int64_t)l * p.sV] - lse;
+        gr[l] = (exp_acc(xl) - (exp_acc(xl - sh) - gc[k])) * p.gscale;
+      } else if (l >= 0 && gc[k] == -__builtin_huge_valf()) {
+        gr[l] = -__builtin_huge_valf();
+      }
+    }
   }
 }
 

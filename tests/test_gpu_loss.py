@@ -597,7 +597,8 @@ def test_alphabets_of_97_to_224_columns_take_the_fast_path(shape, logprobs):
     U.assert_same(gf, g_o, F32_RTOL, F32_ATOL, "grads")
 
 
-@pytest.mark.parametrize("shape", [(2, 256, 8000, 200), (2, 150, 32000, 120), (3, 300, 4096, 223)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)
+@pytest.mark.parametrize("shape", [(2, 256, 8000, 200), (2, 150, 32000, 120), (3, 300, 4096, 223), (3, 298, 230, 223),
+                                   (2, 178, 3001, 167), (1, 260, 9001, 200)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)
 def test_word_piece_targets_of_more_than_95_pieces_take_the_fast_lattice(shape):
     """The wide path's compaction leaves up to Smax + 1 columns; beyond 96 of them the lattice used to be the exact kernel's
     (0.73 ms at B=64, T=256, V=8000, S<=200).  Under ALGO_FAST -- no fallback -- nothing may come back NaN-poisoned."""
