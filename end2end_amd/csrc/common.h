@@ -77,6 +77,7 @@ constexpr int kFastSeg = 16;       // steps between two checkpoints of the fast 
 // f32 segment kernel ran out of range keeps its f64 chains' results: checkpoints, probabilities, loss).
 struct FastRetry {
   int* ctl;                        // the fast path's control words (see FastParams::ctl)
+  int ytab_segments;               // ytab is [B][NS][V][16] (the small alphabets' form) instead of [B][T][V]
   const float* ytab; const float* ckA; const float* ckQ; const short* ckE; const int* cumA; const int* cumB;
   const double* logz;              // [B][2] the chains' log Z (alpha side, beta side)
   const unsigned* segmask;         // [B][MW] bit s: segment s failed its range / self-check in the segment kernel (only those are redone)

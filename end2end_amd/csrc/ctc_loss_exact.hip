@@ -140,10 +140,13 @@ __device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned
     skn[r] = (i + 1 < S && li != blank && ln != li) ? 1.f : 0.f;
   }
   {
-    const float* src = rt.ytab + ((size_t)b * Tmax + t0) * V;
-    for (int i = lane; i < n * V; i += 64) ys[i] = src[i];
+    // (the segment's probabilities as F1 left them: [label][16 steps] for the small alphabets, [step][label] beyond)
+    const float* src = rt.ytab_segments ? rt.ytab + ((size_t)b * rt.NS + seg) * V * kSeg : rt.ytab + ((size_t)b * Tmax + t0) * V;
+    const int cnt = rt.ytab_segments ? kSeg * V : n * V;
+    for (int i = lane; i < cnt; i += 64) ys[i] = src[i];
   }
-  auto y = [&](int tt, int v) -> double { return v >= 0 ? (double)ys[tt * V + v] : 0.0; };
+  const int ys_t = rt.ytab_segments ? 1 : V, ys_v = rt.ytab_segments ? kSeg : 1;
+  auto y = [&](int tt, int v) -> double { return v >= 0 ? (double)ys[tt * ys_t + v * ys_v] : 0.0; };
   // the exponents the chains had removed around this segment (see FastParams in ctc_loss_fast.hip): blocks i .. i+2 of 8
   // steps, i = t0 / 8 -- read once (a load per row on the rows' critical path cost more than the arithmetic)
   int cA[3], cB[3];

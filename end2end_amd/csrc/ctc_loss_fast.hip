@@ -1556,18 +1556,24 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   const int s0 = ls[lane], s1 = ls[64 + lane], s2 = ls[128 + (BIG ? lane : (lane & 1))];
   int s3 = 0, s4 = 0;
   if (BIG) { s3 = ls[192 + lane]; s4 = ls[256 + (lane & 1)]; }
-  // (b) the segment's 16 probability rows: 16*V consecutive floats of ytab, as 16-byte loads from the aligned
-  //     address below (<= 6 per lane for V <= 96; BIG: eight now, the rest after these have been staged)
-  constexpr int kTileLoads = BIG ? 8 : (kSeg * kMaxSmallV + 3 + 255) / 256;
+  // (b) the segment's probabilities.  Small alphabets: F1 left them as the tile is laid out here -- [label][16 steps] -- so a
+  //     lane's 16-byte load IS four steps of a label (<= 6 loads per lane for V <= 96).  BIG: 16*V consecutive floats of the
+  //     row-major table from the aligned address below, eight loads now, the rest after these have been staged
+  constexpr int kTileLoads = BIG ? 8 : (4 * kMaxSmallV + 63) / 64;
   const size_t g0 = ((size_t)b * Tmax + t0) * V;
   const size_t a0 = g0 & ~(size_t)3;
   const int skew = (int)(g0 - a0);
   f4 tile[kTileLoads];
-  {
+  if (BIG) {
     const f4* src = reinterpret_cast<const f4*>(p.ytab + a0);
 #pragma unroll
     for (int j = 0; j < kTileLoads; j++)
       if (4 * 64 * j < kSeg * V + skew) tile[j] = src[64 * j + lane];       // (uniform test)
+  } else {
+    const f4* src = reinterpret_cast<const f4*>(p.ytab + ((size_t)b * p.NS + seg) * V * kSeg);
+#pragma unroll
+    for (int j = 0; j < kTileLoads; j++)
+      if (64 * j < 4 * V) tile[j] = src[min(64 * j + lane, 4 * V - 1)];     // (uniform test; the last load's surplus lanes re-read the end)
   }
   // (c) alpha checkpoint and the rescale exponents
   SegIn<PPL> in;
@@ -1594,9 +1600,24 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   if (BIG) { lds.starts[lane] = s0; lds.starts[64 + lane] = s1; lds.starts[128 + lane] = s2; lds.starts[192 + lane] = s3; if (lane < 2) lds.starts[256 + lane] = s4; }
   else { lds.starts[lane] = s0; lds.starts[64 + lane] = s1; if (lane < 2) lds.starts[128 + lane] = s2; }
   if (lane < kYs) lds.ys[V * kYs + lane] = 0.f;                           // the zero row V
-  if (n < kSeg)
+  if (BIG && n < kSeg)
     for (int i = lane; i < kYs * V; i += 64) lds.ys[i] = 0.f;            // dead steps of a short last segment
-  if (!(E2E_F2_ABL & 32)) {
+  if (!BIG) {
+    // one 16-byte LDS write per load: label (lane >> 2) + 16 j, steps 4 (lane & 3) .. + 3
+    float* dst = lds.ys + (lane >> 2) * kYs + 4 * (lane & 3);
+    const int q4 = 4 * (lane & 3);
+#pragma unroll
+    for (int j = 0; j < kTileLoads; j++) {
+      if (64 * j < 4 * V) {
+        f4 v = tile[j];
+        if (n < kSeg) {                                                    // (uniform) dead steps of a short last segment: zeros
+#pragma unroll
+          for (int c = 0; c < 4; c++) v[c] = q4 + c < n ? v[c] : 0.f;
+        }
+        if (64 * j + lane < 4 * V) *reinterpret_cast<f4*>(dst + 16 * j * kYs) = v;
+      }
+    }
+  } else if (!(E2E_F2_ABL & 32)) {
     // scatter the rows into the transposed tile
     const int count = n * V;
     const unsigned magic = (1u << 20) / (unsigned)V + 1u;                // idx / V for idx < 2^20 / V
@@ -1616,16 +1637,14 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
       }
     };
     scatter(tile, 0);
-    if (BIG) {
-      // the rest of the tile, a round of eight loads at a time (16 * 224 floats: two rounds in all)
-      for (int jbase = kTileLoads; 4 * 64 * jbase < kSeg * V + skew; jbase += kTileLoads) {
-        const f4* src = reinterpret_cast<const f4*>(p.ytab + a0);
-        f4 more[kTileLoads];
+    // the rest of the tile, a round of eight loads at a time (16 * 224 floats: two rounds in all)
+    for (int jbase = kTileLoads; 4 * 64 * jbase < kSeg * V + skew; jbase += kTileLoads) {
+      const f4* src = reinterpret_cast<const f4*>(p.ytab + a0);
+      f4 more[kTileLoads];
 #pragma unroll
-        for (int j = 0; j < kTileLoads; j++)
-          if (4 * 64 * (jbase + j) < kSeg * V + skew) more[j] = src[64 * (jbase + j) + lane];
-        scatter(more, jbase);
-      }
+      for (int j = 0; j < kTileLoads; j++)
+        if (4 * 64 * (jbase + j) < kSeg * V + skew) more[j] = src[64 * (jbase + j) + lane];
+      scatter(more, jbase);
     }
   }
   if (lane < kHalf) lds.Ps[lane * F2Lds<PPL>::PROW - 1] = 0.f;           // the rows' zero guards
@@ -1804,7 +1823,7 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
   l.NS = (T + kSeg - 1) / kSeg;
   l.NB = (T + kBlk - 1) / kBlk + 4;       // (cumA / cumB are read up to two blocks past an utterance's last)
   size_t o = 0;
-  l.ytab = o; o += align_up((size_t)B * T * V * sizeof(float), 256);
+  l.ytab = o; o += align_up((size_t)B * l.NS * kSeg * V * sizeof(float), 256);
   l.ckA = o; o += align_up((size_t)B * l.NS * l.CELLS * sizeof(float), 256);
   l.ckQ = o; o += align_up((size_t)B * l.NS * l.CELLS * sizeof(float), 256);
   l.ckE = o; o += align_up((size_t)B * l.NS * 2 * 64 * sizeof(short), 256);
@@ -1877,7 +1896,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   e.ws = ws + l.total; e.ws_bytes = a.ws_bytes - l.total;
   // mode 1: redo flagged utterances exactly; mode 2: no fallback requested -> poison them
   FastRetry rt;
-  rt.ytab = p.ytab; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.cumA = p.cumA; rt.cumB = p.cumB;
+  rt.ytab = p.ytab; rt.ytab_segments = a.V <= kMaxSmallV ? 1 : 0; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.cumA = p.cumA; rt.cumB = p.cumB;
   rt.NS = p.NS; rt.NB = p.NB; rt.CELLS = p.CELLS; rt.PPL = ppl_of(a.V, a.Smax); rt.logz = p.logz; rt.ctl = p.ctl;
   rt.segmask = p.segmask; rt.MW = p.MW;
   return launch_exact_flagged(e, p.flags, fallback_to_exact ? 1 : 2, &rt);

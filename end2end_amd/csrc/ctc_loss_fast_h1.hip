@@ -402,7 +402,7 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
   const bool contig = p.sV == 1;
   const int64_t xl = (int64_t)b * p.sB + (int64_t)l8 * p.sV;        // this lane's first column (element offset)
   const int64_t cstep = 8 * p.sV;
-  float* yl = p.ytab + (size_t)b * p.T * V + l8;
+  float* yl = p.ytab + ((size_t)b * p.NS * V + l8) * kSeg;          // [segment][label][16 steps]
   const int t_first = DIR == 0 ? tt : 8 * M + 7 - tt;                // the lane's row in block 0; block n: t_first +- 8 n
   lds_u8* prog = L0 + hl.prog + DIR * 32;
   const int a_fill = hl.filled + (DIR * kRingBlks + first) * 4;
@@ -497,10 +497,10 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
       if (blank_lane) { h_d2 yw; yw.x = (double)ybl; yw.y = rr2 * (double)ybl; *(volatile lds_d2*)(L0 + (a_yw + sb)) = yw; }
     }
     if (DIR == 0 && row_live) {
-      float* yrow = yl + (size_t)t * V;
+      float* yrow = yl + (size_t)(t >> 4) * V * kSeg + (t & (kSeg - 1));
 #pragma unroll
       for (int k = 0; k < NV; k++) {
-        if (k < kFull || live[k]) yrow[8 * k] = y[k];
+        if (k < kFull || live[k]) yrow[8 * k * kSeg] = y[k];
       }
     }
     // every lane stores the same word ("my blocks up to n are there"): no divergence, one LDS write

@@ -36,7 +36,9 @@ struct FastParams {
   const int64_t* x_len; const int64_t* t_len;
   int B, T, V, Smax, blank;
   float* losses; void* grads;     // (losses: f32 also for 16-bit I/O)
-  float* ytab;     // [B][T][V]  probabilities y_t[v]
+  float* ytab;     // probabilities y_t[v].  Alphabets of <= kMaxSmallV columns: [B][NS][V][16] -- per 16-step segment, label-major,
+                   // the form the segment kernel's LDS tile has (one 16-byte copy per label and four steps: staging the
+                   // row-major form cost it a seventh of its instructions); beyond (ChainF64W): [B][T][V]
   float* ckA;      // [B][NS][CELLS]  row k: alpha row at t = 16k-1 (k >= 1)
   float* ckQ;      // [B][NS][CELLS]  row k: beta-with-emission row at t = 16k (k >= 1)
   short* ckE;      // [B][NS][2][64]  per-lane exponent of checkpoint row k (0: alpha, 1: beta); -30000 = all zero
@@ -407,7 +409,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
   const int V = p.V;
   const int nblk = (T + kBlk - 1) / kBlk;
   const int64_t xo = (int64_t)b * p.sB;
-  float* ytab = p.ytab + (size_t)b * p.T * V;
+  float* ytab = p.ytab + (size_t)b * p.NS * kSeg * V;       // [segment][label][16 steps]
   const int tt = lane >> 3, l8 = lane & 7;
   const float ninf = -__builtin_huge_valf();
   bool col_live[NV];
@@ -492,7 +494,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 #pragma unroll
       for (int k = 0; k < NV; k++) y[k] *= inv;
     }
-    float* yrow = ytab + (size_t)(row_live ? t : 0) * V;
+    float* yrow = ytab + ((size_t)((row_live ? t : 0) >> 4) * V + l8) * kSeg + (t & (kSeg - 1));
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       if (col_live[k]) {
@@ -511,7 +513,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
         } else {
           blk[(l8 + 8 * k) * kRow + tt] = row_live ? (double)y[k] : 0.0;   // transposed: [label][step]
         }
-        if (dir == 0 && row_live) yrow[l8 + 8 * k] = y[k];
+        if (dir == 0 && row_live) yrow[8 * k * kSeg] = y[k];
       }
     }
     // every lane stores the same word: no divergence, one LDS write.  (MODE 1, 2: one word per producer, "my blocks up to n
