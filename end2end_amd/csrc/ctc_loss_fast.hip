@@ -392,6 +392,15 @@ struct ChainF64W : ChainF64 {
   static constexpr bool kPairedLoop = E2E_W_PRODUCERS <= 2;
 };
 
+//   ChainF64LW: ChainF64L over the f32 ring -- alphabets of up to 448 columns with targets of up to 447 labels (word-piece
+//             targets of 224..447 pieces).  The ring is two blocks deep (21.6 KB per block at 448 columns: 154 KB of LDS in
+//             all), so a chain wave waits for its producers at every block; served, not tuned, like ChainF64L.
+struct ChainF64LW : ChainF64L {
+  typedef float R;
+  static constexpr bool kBigV = true;
+  static constexpr int kRing = 2, kRingElem = 4, kRowElems = kRow32;
+};
+
 struct HfLds {
   // byte offsets from the start of the workgroup's LDS
   int ring;        // [2][kRingBlks] blocks of blk_bytes: (V+1) label rows of kRowElems cells (row V: zeros) + 16 cells (yb, wb) x 8 steps
@@ -411,7 +420,7 @@ struct HfLds {
     blk_bytes = ((V + 1) * row_elems + 16) * ring_elem;
     filled = ring + 2 * depth * blk_bytes;
     sortcnt = filled + 2 * kRingBlks * 4;
-    bnd = (sortcnt + (V > 127 ? 258 : 130) * 4 + 15) & ~15;
+    bnd = (sortcnt + (V > 127 ? lstart_ints(V) : 130) * 4 + 15) & ~15;
     zacc = bnd + 2 * maxw * kHaloSlots * kHfHalo * 4 * elem;
     prog = zacc + 64;
     exw = prog + 2 * 8 * 4;
@@ -809,7 +818,10 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
     volatile int* fl = reinterpret_cast<int*>(smem + hl.filled) + d * kRingBlks;
     constexpr int MODE = X::kF32 ? 2 : 1;
     if constexpr (X::kBigV) {
-      if (V <= 128) prep_wave_big<16, X::kRing>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, lane, prog, rr2);
+      if constexpr (X::kMaxW > 2) {                          // ChainF64LW
+        if (V <= 288) prep_wave_big<36, X::kRing, 1>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, lane, prog, rr2);
+        else prep_wave_big<56, X::kRing, 1>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, lane, prog, rr2);
+      } else if (V <= 128) prep_wave_big<16, X::kRing>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, lane, prog, rr2);
       else if (V <= 176) prep_wave_big<22, X::kRing>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, lane, prog, rr2);
       else prep_wave_big<28, X::kRing>(p, b, T, d, first, X::kProducers, ring, hl.blk_bytes, fl, lane, prog, rr2);
     } else
@@ -825,12 +837,12 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
 // (their loads are all in flight together: one frame per wave left the kernel latency-bound at 3.3 TB/s), up to four columns per
 // lane; fused log-softmax for raw logits (ctc_loss.cpp reads log-probabilities: CTCLoss applies log_softmax first).
 constexpr int kProbRows = 4;
+template <int NK>                  // columns per lane: 4 (<= kMaxBigV) or 7 (<= kMaxHugeV)
 __global__ __launch_bounds__(256) void ctc_fast_prob_kernel(FastParams p) {
   const int lane = threadIdx.x & 63, V = p.V;
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kProbRows, nrows = (int64_t)p.B * p.T;
   if (row0 >= nrows) return;
   const float ninf = -__builtin_huge_valf();
-  constexpr int NK = (kMaxBigV + 63) / 64;
   float x[kProbRows][NK];
   bool live[kProbRows];
 #pragma unroll
@@ -921,7 +933,7 @@ struct F2Lds {
     ys = Ps + kHalf * PROW;
     starts = reinterpret_cast<int*>(ys + kYs * (V + 1));
   }
-  __host__ __device__ static size_t bytes(int V) { return sizeof(float) * (4 + kHalf * PROW + kYs * (V + 1)) + sizeof(int) * (V > 127 ? 258 : 130); }
+  __host__ __device__ static size_t bytes(int V) { return sizeof(float) * (4 + kHalf * PROW + kYs * (V + 1)) + sizeof(int) * (V > 127 ? lstart_ints(V) : 130); }
 };
 
 // The gradient rows are written one lane per (row, label): with V <= 32 columns the 64 lanes cover two rows per pass (four
@@ -953,7 +965,7 @@ struct GradLanesT {
 };
 
 // rows [h*8, h*8+8) of the segment: per-label sums, normaliser, gradient rows.  FULL: all 8 rows are live.
-typedef GradLanesT<2> GradLanes;        // up to 128 columns (kMaxSmallV); four sets: kMaxBigV
+typedef GradLanesT<2> GradLanes;        // up to 128 columns (kMaxSmallV); four sets: kMaxBigV, seven: kMaxHugeV
 
 template <int PPL, bool FULL, typename P, typename GL>
 __device__ __forceinline__ void finish_rows(const P& p, int b, int t0, int n, int h, const F2Lds<PPL>& lds,
@@ -1127,6 +1139,18 @@ struct SegIn {
     }
   }
 };
+
+// A label cell's slot in a row of the label-sorted products, kept as the LDS byte address of the slot in row 0: the compiler
+// recomputed `base + (slot << 2)` for every store (64 per segment) rather than keep a second register per slot.
+__device__ __forceinline__ int ps_slot_address(float* Ps, int slot) {           // LDS byte address of Ps[slot]
+  typedef __attribute__((address_space(3))) float lds_f32;
+  return (int)(unsigned)(size_t)((lds_f32*)Ps + slot);
+}
+__device__ __forceinline__ void ps_put(int slot_address, int row_floats, float v) {
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  typedef __attribute__((address_space(3))) float lds_f32;
+  *(lds_f32*)((lds_byte*)(size_t)(unsigned)slot_address + 4 * row_floats) = v;    // (the row is the instruction's immediate)
+}
 
 // FULL: an interior segment (16 live steps, neither t = 0 nor t = T-1 inside): no guards in the loops.
 template <int PPL, bool FULL, typename P, typename GL>
@@ -1306,7 +1330,7 @@ __device__ __forceinline__ void segment_body(const P& p, int b, int seg, int T, 
 #pragma unroll
         for (int r = 0; r < PPL; r++) {
           pblank += A[tt][2 * r] * bs[2 * r];
-          Ps[k * PROW + rank[r]] = A[tt][2 * r + 1] * bs[2 * r + 1];
+          ps_put(rank[r], k * PROW, A[tt][2 * r + 1] * bs[2 * r + 1]);
         }
         pb[k] = pblank;
         // q_t = beta_t * y_t
@@ -1506,8 +1530,8 @@ __device__ __forceinline__ void segment_body_pk(const P& p, int b, int seg, int 
         const h_f2 pbl = ABA[tt & kA] * bsBA + ABB[tt & kA] * bsBB;
         pb[k] = pbl.x + pbl.y;
         const h_f2 PA = ALA[tt & kA] * bsLA, PB = ALB[tt & kA] * bsLB;
-        Ps[k * PROW + rank[0]] = PA.x; Ps[k * PROW + rank[1]] = PB.x;
-        Ps[k * PROW + rank[2]] = PA.y; Ps[k * PROW + rank[3]] = PB.y;
+        ps_put(rank[0], k * PROW, PA.x); ps_put(rank[1], k * PROW, PB.x);
+        ps_put(rank[2], k * PROW, PA.y); ps_put(rank[3], k * PROW, PB.y);
         // q_t = beta_t * y_t
         const h_f2 YB = {yb, yb};
         qBA = bsBA * YB; qBB = bsBB * YB;
@@ -1553,9 +1577,8 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   }
   constexpr bool BIG = P::kBigV;
   const int* ls = p.lstart + (size_t)b * p.LS;
-  const int s0 = ls[lane], s1 = ls[64 + lane], s2 = ls[128 + (BIG ? lane : (lane & 1))];
-  int s3 = 0, s4 = 0;
-  if (BIG) { s3 = ls[192 + lane]; s4 = ls[256 + (lane & 1)]; }
+  int s0 = 0, s1 = 0, s2 = 0;
+  if (!BIG) { s0 = ls[lane]; s1 = ls[64 + lane]; s2 = ls[128 + (lane & 1)]; }      // (BIG: up to 514 entries, copied below)
   // (b) the segment's probabilities.  Small alphabets: F1 left them as the tile is laid out here -- [label][16 steps] -- so a
   //     lane's 16-byte load IS four steps of a label (<= 6 loads per lane for V <= 96).  BIG: 16*V consecutive floats of the
   //     row-major table from the aligned address below, eight loads now, the rest after these have been staged
@@ -1597,7 +1620,9 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   LaneCells<PPL> lc;
   int rank[PPL];
   lc.unpack(w, S, T, rank);
-  if (BIG) { lds.starts[lane] = s0; lds.starts[64 + lane] = s1; lds.starts[128 + lane] = s2; lds.starts[192 + lane] = s3; if (lane < 2) lds.starts[256 + lane] = s4; }
+#pragma unroll
+  for (int r = 0; r < PPL; r++) rank[r] = ps_slot_address(lds.Ps, rank[r]);      // kept as LDS byte addresses: see ps_put
+  if (BIG) { for (int i = lane; i < lstart_ints(V); i += 64) lds.starts[i] = ls[i]; }
   else { lds.starts[lane] = s0; lds.starts[64 + lane] = s1; if (lane < 2) lds.starts[128 + lane] = s2; }
   if (lane < kYs) lds.ys[V * kYs + lane] = 0.f;                           // the zero row V
   if (BIG && n < kSeg)
@@ -1620,7 +1645,8 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   } else if (!(E2E_F2_ABL & 32)) {
     // scatter the rows into the transposed tile
     const int count = n * V;
-    const unsigned magic = (1u << 20) / (unsigned)V + 1u;                // idx / V for idx < 2^20 / V
+    const unsigned magic = (1u << 24) / (unsigned)V + 1u;                // idx / V, exact for idx < 2^24 / V (>= 37 449 > 16 * 448);
+                                                                           // idx * magic < 7 172 * 172 962 < 2^32 for V >= 97
     auto scatter = [&](const f4 (&tl)[kTileLoads], int jbase) {
 #pragma unroll
       for (int j = 0; j < kTileLoads; j++) {
@@ -1629,7 +1655,7 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
           for (int c = 0; c < 4; c++) {
             const int idx = 4 * (64 * (jbase + j) + lane) + c - skew;
             if (idx >= 0 && idx < count) {
-              const int tt = (int)(((unsigned)idx * magic) >> 20);
+              const int tt = (int)(((unsigned)idx * magic) >> 24);
               lds.ys[(idx - tt * V) * kYs + tt] = tl[j][c];
             }
           }
@@ -1649,7 +1675,7 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   }
   if (lane < kHalf) lds.Ps[lane * F2Lds<PPL>::PROW - 1] = 0.f;           // the rows' zero guards
   F2_LDS_ORDER   // staged rows visible to this (single) wave
-  GradLanesT<BIG ? 4 : 2> gl;
+  GradLanesT<BIG ? (PPL == 8 ? (kMaxHugeV + 63) / 64 : (kMaxBigV + 63) / 64) : 2> gl;
   gl.init(lds, V, p.blank, lane);
   F2_STAMP(0)
   float smin = __builtin_huge_valf(), smax = 0.f;
@@ -1732,6 +1758,15 @@ int launch_segments(const FastParams& p, size_t lds, hipStream_t stream) {
 // one-segment waves already overlap each other's load latency and store tails; a register prefetch spills (tried twice).)
 // targets of 256..447 labels: the halo chains on four waves per direction, the segment kernel with eight pairs per lane
 int launch_fast_long(const FastParams& p, hipStream_t stream) {
+  if (p.V > kMaxSmallV) {          // the wide-row form (see ChainF64LW)
+    hipLaunchKernelGGL(ctc_fast_prob_kernel<(kMaxHugeV + 63) / 64>, dim3((unsigned)(((int64_t)p.B * p.T + 4 * kProbRows - 1) / (4 * kProbRows))), dim3(256), 0, stream, p);
+    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_prob_kernel launch");
+    const HfLds hl = HfLds::of<ChainF64LW>(p.V);
+    E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<8, ChainF64LW>), hl.total), "hipFuncSetAttribute");
+    hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<8, ChainF64LW>), dim3(p.B), dim3(ChainF64LW::kWaves * 64), hl.total, stream, p);
+    E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
+    return launch_segments<8, true>(p, F2Lds<8>::bytes(p.V), stream);
+  }
   const HfLds hl = HfLds::of<ChainF64L>(p.V);
   E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<8, ChainF64L>), hl.total), "hipFuncSetAttribute");
   hipLaunchKernelGGL((ctc_fast_chain_hf_kernel<8, ChainF64L>), dim3(p.B), dim3(ChainF64L::kWaves * 64), hl.total, stream, p);
@@ -1746,7 +1781,7 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   if (p.V > kMaxSmallV) {
     // 97..224 columns: the halo chains over the f32 ring, the segment kernel's wide-row form (fast_supported: PPL == 4 here)
     if constexpr (PPL == 4) {
-      hipLaunchKernelGGL(ctc_fast_prob_kernel, dim3((unsigned)(((int64_t)p.B * p.T + 4 * kProbRows - 1) / (4 * kProbRows))), dim3(256), 0, stream, p);
+      hipLaunchKernelGGL(ctc_fast_prob_kernel<(kMaxBigV + 63) / 64>, dim3((unsigned)(((int64_t)p.B * p.T + 4 * kProbRows - 1) / (4 * kProbRows))), dim3(256), 0, stream, p);
       E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_prob_kernel launch");
       const HfLds hl = HfLds::of<ChainF64W>(p.V);
       E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hf_kernel<4, ChainF64W>), hl.total), "hipFuncSetAttribute");
@@ -1806,7 +1841,10 @@ int ppl_for(int Smax) {
 
 // ... of a call: alphabets beyond kMaxSmallV run on ChainF64W and the segment kernel's four-pairs form only
 int ppl_of(int V, int Smax) {
-  if (V > kMaxSmallV) return (V <= kMaxBigV && Smax + 1 <= ChainF64W::kMaxW * kHfOwn) ? 4 : 0;
+  if (V > kMaxSmallV) {
+    if (V <= kMaxBigV && Smax + 1 <= ChainF64W::kMaxW * kHfOwn) return 4;
+    return (V <= kMaxHugeV && Smax + 1 <= ChainF64LW::kMaxW * kHfOwn) ? 8 : 0;      // (more columns or more labels: eight pairs per lane)
+  }
   return ppl_for(Smax);
 }
 
@@ -1819,7 +1857,7 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
   FastLayout l;
   const int ppl = ppl_of(V, Smax);
   l.CELLS = 128 * (ppl > 0 ? ppl : 1);
-  l.LS = max(130, 64 * ((V + 64) >> 6) + 2);
+  l.LS = max(130, lstart_ints(V));
   l.NS = (T + kSeg - 1) / kSeg;
   l.NB = (T + kBlk - 1) / kBlk + 4;       // (cumA / cumB are read up to two blocks past an utterance's last)
   size_t o = 0;

@@ -28,6 +28,9 @@ constexpr int kRow = 10;        // doubles per label row of a ring block: 8 step
 constexpr int kMaxSmallV = 96;  // alphabet columns the lattice kernels take (prep: <= 12 columns per lane)
 constexpr int kMaxBigV = 224;   // ... and with the wide-row forms of the halo chains and of the segment kernel (ChainF64W: f32 ring of
                                 // depth 4, 28 columns per producer lane, four label sets per gradient lane); targets of <= 223 labels
+constexpr int kMaxHugeV = 448;  // ... and of the long-transcript kernels (ChainF64LW: ring of depth 2, 56 columns per producer lane,
+                                // seven label sets per gradient lane, eight pairs per segment-kernel lane); targets of <= 447 labels
+__host__ __device__ inline int lstart_ints(int V) { return 64 * ((V + 64) >> 6) + 2; }   // label-start entries per utterance (>= 130)
 
 struct FastParams {
   const void* x; int xdt;          // logits / log-probabilities and their dtype (E2E_F32 / E2E_F16 / E2E_BF16); the gradient has the same
@@ -559,7 +562,7 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 // probabilities are therefore computed ONCE, by the whole chip, in a launch of their own (ctc_fast_prob_kernel, which fills
 // ytab); a producer only moves a block's rows from ytab into the ring, transposed.
 constexpr float kTinyProb = 1e-35f;       // ytab marker: a FINITE log-probability below -69 (e^-69 = 1.08e-30 = 2^-100)
-template <int NV, int RING>
+template <int NV, int RING, int SETS = 2>
 __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T, int dir, int first, int stride,
                                               unsigned char* myring_bytes, int blk_bytes, volatile int* myfilled, int lane,
                                               lds_u8* prog, double rr2) {
@@ -602,13 +605,17 @@ __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T,
     }
     publish(&myfilled[first], n + stride);
   };
-  {
+  if constexpr (SETS == 2) {
     float xa[NV], xb[NV];
     load_block(first, xa);
     for (int n = first; n < nblk; n += 2 * stride) {
       load_block(n + stride, xb); process(n, xa);
       load_block(n + 2 * stride, xa); process(n + stride, xb);
     }
+  } else {
+    // one set (56 columns per lane: two do not fit 128 registers): the rows are requested, then the wave waits for its ring
+    // slot -- with a ring of two blocks that wait is what hides the loads
+    for (int n = first; n < nblk; n += stride) { float xa[NV]; load_block(n, xa); process(n, xa); }
   }
   // Probabilities are f32: below ~2^-126 they are flushed (see prep_wave: reason bit 64, the exact kernel recomputes the
   // utterance); the launch that filled ytab left kTinyProb wherever a finite log-probability lay below -69
@@ -622,7 +629,7 @@ __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T,
 template <int PPL>
 __device__ __forceinline__ void cellinfo_wave(const FastParams& p, int b, int T, int S, int* cnt, int lane) {
   const int V = p.V;
-  const int nch = (V + 64) >> 6;             // chunks of 64 labels that hold 0..V (two for V <= 127; cnt: [64 * nch + 2], <= 258)
+  const int nch = (V + 64) >> 6;             // chunks of 64 labels that hold 0..V (two for V <= 127; cnt: [64 * nch + 2] = lstart_ints(V))
   for (int c = 0; c < nch; c++) cnt[64 * c + lane] = 0;
   if (lane < 2) cnt[64 * nch + lane] = 0;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -618,6 +618,30 @@ def test_word_piece_targets_of_more_than_95_pieces_take_the_fast_lattice(shape):
     U.assert_same(gf, g_o, F32_RTOL, 5e-7, "grads")
 
 
+@pytest.mark.parametrize("shape", [(2, 500, 225, 224), (2, 700, 300, 300), (2, 900, 448, 447), (2, 300, 97, 250), (2, 700, 8000, 300),
+                                   (1, 600, 9001, 447)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)
+def test_up_to_448_columns_and_447_labels_take_the_fast_path(shape):
+    """More than 96 columns together with targets of 224..447 labels, or 225..448 columns with any target: the long-transcript
+    kernels' wide-row form (ChainF64LW: f32 ring two blocks deep, 56 columns per producer lane; the segment kernel with eight
+    pairs per lane and up to seven labels per gradient lane) -- directly and behind the wide path's compaction.  ALGO_FAST
+    leaves no NaN; the oracle's results at the default tolerances."""
+    B, T, V, S = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tg[0, 3] = tg[0, 2]
+    xl = torch.tensor([T] + [T - 21 * (b + 1) for b in range(B - 1)])
+    tl = torch.tensor([S] + [max(1, S - 50 * (b + 1)) for b in range(B - 1)])
+    lf, gf = U.c_abi_loss(x, tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    assert np.isfinite(lf).all(), "the fast path flagged %d of %d utterances" % (int(np.isnan(lf).sum()), B)
+    lp = torch.log_softmax(x.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0
+    U.assert_same(lf, l_o, F32_RTOL, F32_ATOL * 100, "losses")
+    U.assert_same(gf, g_o, F32_RTOL, F32_ATOL, "grads")
+
+
 def test_tiny_probabilities_at_a_wide_alphabet_are_handed_to_the_exact_kernel():
     """ChainF64W's probability table marks a FINITE log-probability below -69 (f32 would flush what the lattice makes of it);
     the producers flag the utterance (reason bit 64) and the exact kernel recomputes it: AUTO equals the oracle, FAST poisons

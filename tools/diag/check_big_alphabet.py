@@ -32,11 +32,16 @@ def check(B, T, V, S, logprobs=False, dtype=torch.float32, seed=3, ragged=True):
 for shape in [(2, 300, 97, 120), (3, 200, 128, 100), (2, 256, 129, 150), (3, 400, 224, 223), (2, 300, 200, 40), (4, 64, 177, 30)]:
     check(*shape)
     check(*shape, logprobs=True)
+for shape in [(2, 500, 225, 224), (2, 700, 300, 300), (3, 900, 448, 447), (2, 600, 448, 100), (2, 300, 97, 250), (2, 640, 150, 400)]:
+    check(*shape)
+    check(*shape, logprobs=True)
+check(2, 700, 8000, 300, ragged=False)
+check(1, 600, 32000, 447, ragged=False)
 check(2, 256, 8000, 200, ragged=False)
 check(2, 150, 32000, 120, ragged=False)
 
 d = torch.device("cuda", 0)
-for (B, T, V, S) in [(64, 256, 8000, 200), (16, 150, 32000, 120), (256, 1000, 200, 200)]:
+for (B, T, V, S) in [(64, 256, 8000, 200), (16, 150, 32000, 120), (256, 1000, 200, 200), (32, 700, 8000, 400)]:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, T, V, generator=g).to(d); tg = torch.randint(1, V, (B, S), generator=g).to(d)
     tl = torch.randint(S // 2, S + 1, (B,), generator=g).to(d); xl = torch.full((B,), T).to(d)

@@ -14,7 +14,7 @@ mode = sys.argv[3] if len(sys.argv) > 3 else ''
 dense = mode == 'dense'        # target lengths close to the input lengths
 edges = mode == 'edges'        # short inputs, target lengths around the lane-packing boundaries
 wide = mode == 'wide'          # alphabets beyond the lattice kernels' columns (compaction path)
-mid = mode in ('mid', 'middense')   # alphabets of 97..224 columns: the lattice kernels' wide-row form, no compaction
+mid = mode in ('mid', 'middense')   # alphabets of 97..448 columns: the lattice kernels' wide-row forms, no compaction
 verbose = os.environ.get('FUZZ_VERBOSE') == '1'
 check_auto = os.environ.get('FUZZ_AUTO', '1') == '1'
 auto_bad = 0
@@ -26,11 +26,10 @@ tally = collections.Counter(); feas = collections.Counter(); flagwords = collect
 for case in range(n_cases):
     B = int(rng.integers(1, 9)); T = int(rng.integers(1, 700)); V = int(rng.integers(2, 97))
     if wide: V = int(rng.choice([230, 500, 1000, 3001])); T = int(rng.integers(1, 300))
-    if mid: V = int(rng.integers(97, 225)); T = int(rng.integers(1, 500))
+    if mid: V = int(rng.integers(97, 449)); T = int(rng.integers(1, 700))
     if edges and rng.integers(0, 2): T = int(rng.integers(1, 48))
-    Smax = int(rng.integers(0, min(255, T) + 1))
-    if wide or mid: Smax = min(Smax, 223)    # (what the wide-row form of the lattice kernels holds)
-    if mode == 'middense' and T > 4: Smax = int(min(223, max(1, T * rng.uniform(0.45, 0.98))))
+    Smax = int(rng.integers(0, min(447 if (mid or wide) else 255, T) + 1))
+    if mode == 'middense' and T > 4: Smax = int(min(447, max(1, T * rng.uniform(0.45, 0.98))))
     if edges and T >= 70: Smax = int(min(T, rng.choice([62, 63, 64, 65, 126, 127, 128, 129, 254, 255])))
     if dense and T > 4: Smax = int(min(255, max(1, T * rng.uniform(0.45, 0.98))))
     sharp = float(rng.choice([0.1, 1.0, 3.0] if dense else [0.1, 1.0, 3.0, 8.0, 20.0]))
