@@ -384,6 +384,7 @@ def shape_cliff_numbers(dev):
                                ("long_targets_T1000_S300", (256, 1000, 29, 300)),
                                ("wordpiece_V8000_S200", (64, 256, 8000, 200)),
                                ("wordpiece_V32000_S120", (16, 150, 32000, 120)),
+                               ("wordpiece_V8000_S400", (32, 700, 8000, 400)),
                                ("mid_alphabet_V200_S200", (256, 1000, 200, 200))):
         _, db = make_batch(7000, B, T, V, S, dev)
         hp = HotPath(db)
@@ -393,7 +394,7 @@ def shape_cliff_numbers(dev):
         out[name] = {"workload": "B=%d T=%d V=%d S in [%d,%d] f32" % (B, T, V, S // 2, S), "ms": ms,
                      "frames_per_s": B * T / (ms * 1e-3),
                      "path": "fast path (eight pairs per lane)" if V <= 96 else
-                             "fast path, wide-row form (97..224 columns: probability table + halo chains over an f32 ring)" if V <= 224 else
+                             "fast path, wide-row form (97..448 columns: probability table + halo chains over an f32 ring)" if V <= 448 else
                              "wide path: streaming rows + the fast lattice's wide-row form on the compact columns (more than 95 distinct labels)"}
         del hp, db
         torch.cuda.empty_cache()
