@@ -642,6 +642,29 @@ def test_up_to_448_columns_and_447_labels_take_the_fast_path(shape):
     U.assert_same(gf, g_o, F32_RTOL, F32_ATOL, "grads")
 
 
+def test_wide_row_form_takes_strided_input_and_any_blank():
+    """ChainF64W's probability table is filled through the logits' strides and the blank may sit anywhere: a time-major view
+    (the reference's own layout before its transpose, modules/ctc_loss.py:33-36) with the blank in the last column and in
+    the middle, against the oracle."""
+    g = torch.Generator().manual_seed(23)
+    B, T, V, S = 3, 180, 170, 120
+    xt = torch.randn(T, B, V, generator=g)                  # time-major storage
+    x = xt.permute(1, 0, 2)                                  # (B, T, V) view, strides (V, B*V, 1)
+    assert not x.is_contiguous()
+    for blank in (V - 1, 77):
+        labs = [v for v in range(V) if v != blank]
+        tg = torch.tensor(np.random.default_rng(blank).choice(labs, size=(B, S)), dtype=torch.long)
+        xl = torch.tensor([T, T - 11, T - 40]); tl = torch.tensor([S, S - 13, 50])
+        lf, gf = U.c_abi_loss(x, tg, xl, tl, blank, False, _lib.ALGO_FAST)
+        assert np.isfinite(lf).all()
+        lp = torch.log_softmax(x.double(), -1).numpy()
+        l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), blank)
+        for b in range(B):
+            g_o[b, xl[b]:] = 0
+        U.assert_same(lf, l_o, F32_RTOL, F32_ATOL * 10, "losses (blank %d)" % blank)
+        U.assert_same(gf, g_o, F32_RTOL, F32_ATOL, "grads (blank %d)" % blank)
+
+
 def test_tiny_probabilities_at_a_wide_alphabet_are_handed_to_the_exact_kernel():
     """ChainF64W's probability table marks a FINITE log-probability below -69 (f32 would flush what the lattice makes of it);
     the producers flag the utterance (reason bit 64) and the exact kernel recomputes it: AUTO equals the oracle, FAST poisons
