@@ -1000,8 +1000,20 @@ __device__ __forceinline__ void finish_rows(const P& p, int b, int t0, int n, in
 #pragma unroll
     for (int k = 0; k < kHalf; k++) {
       const float excl = inc[k] - c[k][PPL - 1];
+      if constexpr (PPL % 2 == 0) {
+        // (two slots per packed add: the lane's slots sit in aligned register pairs as the 16-byte read left them)
+        typedef float pk2 __attribute__((ext_vector_type(2)));
+        const pk2 e2 = {excl, excl};
 #pragma unroll
-      for (int r = 0; r < PPL; r++) lds.Ps[k * PROW + PPL * lane + r] = c[k][r] + excl;
+        for (int r = 0; r < PPL; r += 2) {
+          pk2 v = {c[k][r], c[k][r + 1]};
+          v += e2;
+          lds.Ps[k * PROW + PPL * lane + r] = v.x; lds.Ps[k * PROW + PPL * lane + r + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < PPL; r++) lds.Ps[k * PROW + PPL * lane + r] = c[k][r] + excl;
+      }
       st8[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc[k]), 63)) + btot8[k];
     }
   }
