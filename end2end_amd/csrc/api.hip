@@ -108,20 +108,28 @@ int launch_scale(void* grads, int dtype, const void* scale, int B, int64_t row_e
   return E2E_OK;
 }
 
-// Streaming copy used by bench.py to measure the box's achievable HBM rate (roofline.peak_measured): one 16-byte
-// non-temporal load and store per lane and iteration, 8 in flight, the grid sized to the chip.
+// Streaming copy used by bench.py to measure the box's achievable HBM rate (roofline.peak_measured).  Every wave copies
+// contiguous 32 KB pieces, eight 16-byte non-temporal loads per lane in flight, then their stores: 6.5 - 7.0 TB/s on the
+// pool's boxes (tools/diag/microbench/ubench_copy.hip).  The grid-stride form this kernel had until round 4 -- a wave's eight
+// loads a whole grid apart -- reaches 4.8 - 5.1 TB/s on the same boxes, and hipMemcpyAsync 4.7 - 4.9: `peak_measured` was
+// not a ceiling.
 typedef float copy_f4 __attribute__((ext_vector_type(4)));
+constexpr int kCopyPiece = 2048;                       // 16-byte elements per piece (32 KB)
 __global__ __launch_bounds__(256) void stream_copy_kernel(copy_f4* __restrict__ dst, const copy_f4* __restrict__ src, size_t n16) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 7 * stride < n16; i += 8 * stride) {
-    copy_f4 v[8];
+  const int lane = threadIdx.x & 63;
+  const size_t nwaves = (size_t)gridDim.x * 4, npieces = n16 / kCopyPiece;
+  for (size_t pc = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pc < npieces; pc += nwaves) {
+    const copy_f4* s = src + pc * kCopyPiece; copy_f4* d = dst + pc * kCopyPiece;
+    for (int i = lane; i < kCopyPiece; i += 8 * 64) {
+      copy_f4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(&src[i + u * stride]);
+      for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(&s[i + 64 * u]);
 #pragma unroll
-    for (int u = 0; u < 8; u++) __builtin_nontemporal_store(v[u], &dst[i + u * stride]);
+      for (int u = 0; u < 8; u++) __builtin_nontemporal_store(v[u], &d[i + 64 * u]);
+    }
   }
-  for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+  // (what does not fill a piece)
+  for (size_t i = npieces * kCopyPiece + (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 }  // namespace e2e
@@ -131,7 +139,7 @@ using namespace e2e;
 // diagnostics, not part of include/e2e_ctc.h: dst[0..bytes) = src[0..bytes), bytes a multiple of 16
 extern "C" int e2e_debug_stream_copy(void* dst, const void* src, size_t bytes, void* stream) {
   if (!dst || !src || bytes % 16) { set_error("e2e_debug_stream_copy: bad argument"); return E2E_ERR_ARG; }
-  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream,
                      (copy_f4*)dst, (const copy_f4*)src, bytes / 16);
   E2E_HIP_CHECK(hipGetLastError(), "stream_copy_kernel launch");
   return E2E_OK;
