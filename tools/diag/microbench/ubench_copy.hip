@@ -101,6 +101,49 @@ __global__ __launch_bounds__(64 * WPB) void rows_two_pass(f4* __restrict__ dst, 
     }
   }
 }
+// one row per WORKGROUP: each of its WPR waves keeps 32 / WPR chunks of the row in registers; the maximum and the sum cross
+// the waves through LDS (two barriers per row); RPB rows per block one after the other
+template <int WPR, int COMP>
+__global__ __launch_bounds__(64 * WPR) void rows_split(f4* __restrict__ dst, const f4* __restrict__ src, size_t n16, int row16) {
+  constexpr int U = 32 / WPR;
+  __shared__ float red[2][8];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t base = (size_t)blockIdx.x * row16;
+  if (base + row16 > n16) return;
+  const f4* x = src + base; f4* g = dst + base;
+  f4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(&x[min(64 * (U * w + u) + lane, row16 - 1)]);
+  float m = -1e30f;
+#pragma unroll
+  for (int u = 0; u < U; u++) m = fmaxf(m, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) red[0][w] = m;
+  __syncthreads();
+  float M = red[0][0];
+#pragma unroll
+  for (int k = 1; k < WPR; k++) M = fmaxf(M, red[0][k]);
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      float t = v[u][e] - M;
+#pragma unroll
+      for (int c = 0; c < COMP; c++) t = __builtin_fmaf(t, 1.0001f, 0.5f);
+      v[u][e] = t; sum += t;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if (lane == 0) red[1][w] = sum;
+  __syncthreads();
+  float S = 0.f;
+#pragma unroll
+  for (int k = 0; k < WPR; k++) S += red[1][k];
+  const float inv = 1.f / S;
+#pragma unroll
+  for (int u = 0; u < U; u++) __builtin_nontemporal_store(v[u] * inv, &g[min(64 * (U * w + u) + lane, row16 - 1)]);
+}
 template <typename F> float timeit(F f, int reps = 10) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   f(); hipDeviceSynchronize();
@@ -131,5 +174,9 @@ int main() {
     float ms = timeit([&] { hipLaunchKernelGGL((rows_two_pass<U, NT1, NT2, WPB>), dim3(grid), dim3(64 * WPB), 0, 0, dst, src, n16, row16); }); \
     printf("two passes over the row, %d chunks in flight, nt loads %d/%d, %d waves per block: %.2f TB/s (algorithmic)\n", U, NT1, NT2, WPB, 2.0 * (n16 / row16 * row16 * 16.0) / ms / 1e9); }
   TWOP(8, 0, 0, 4) TWOP(8, 0, 1, 4) TWOP(8, 1, 1, 4) TWOP(4, 0, 1, 4) TWOP(8, 0, 1, 8) TWOP(8, 0, 1, 2) TWOP(16, 0, 1, 4)
+#define SPLIT(WPR, COMP) { const int row16 = 2000; const unsigned grid = (unsigned)(n16 / row16); \
+    float ms = timeit([&] { hipLaunchKernelGGL((rows_split<WPR, COMP>), dim3(grid), dim3(64 * WPR), 0, 0, dst, src, n16, row16); }); \
+    printf("row split over %d waves of a workgroup, %2d VALU per element: %.2f TB/s\n", WPR, COMP, 2.0 * (n16 / row16 * row16 * 16.0) / ms / 1e9); }
+  SPLIT(4, 0) SPLIT(4, 10) SPLIT(2, 10) SPLIT(8, 10) SPLIT(4, 20)
   return 0;
 }
