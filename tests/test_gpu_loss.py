@@ -713,3 +713,16 @@ def test_flagged_launch_with_more_utterances_than_its_flag_cache():
     ok = np.flatnonzero(feasible)
     la2, _, red2 = U.c_abi_loss(xt[ok], tg[ok], xl[ok], tl[ok], 0, False, _lib.ALGO_AUTO, opts=(1.0, _lib.REDUCE_SUM))
     assert abs(red2 - l_o[ok].sum()) <= 2e-6 * abs(l_o[ok].sum())
+
+
+def test_bandwidth_probe_copies_exactly():
+    """`e2e_debug_stream_copy` (include/e2e_ctc_debug.h; what bench.py's `roofline.peak_measured` times): whole 32 KB pieces per
+    wave plus a remainder -- the destination must equal the source for sizes on both sides of a piece."""
+    L = _lib.load()
+    d = U.dev()
+    for n in (4 * 5, 1 << 13, (1 << 20) + 4 * 777):
+        src = torch.randn(n, device=d)
+        dst = torch.zeros_like(src)
+        _lib.check(L.e2e_debug_stream_copy(dst.data_ptr(), src.data_ptr(), n * 4, _lib.stream_ptr(d)))
+        torch.cuda.synchronize()
+        assert torch.equal(src, dst), n
