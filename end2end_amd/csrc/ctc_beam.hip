@@ -904,6 +904,12 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
   if (LM) for (int c = tid; c < V; c += kThreads) if (c != blank && c != p.space_id) lmc0[c] = lm_query<LMK == 2>(p, lt, M0.lm[0], -1, c);
   __syncthreads();
   int n = 1, cur = 0;
+  // the pair loop's thread layout depends on n alone, and n is W for all but an utterance's first steps: worked out when n
+  // changes (three integer divisions, ~100 instructions per thread of a phase that is bound by the instructions it issues)
+  int lay_n = -1, lay_P = 1, lay_mpp = kThreads, lay_ii0 = 0, lay_part = 0;
+  // e / V for e < 256 * V (candidate and row indices: W < 256) by multiplication
+  const unsigned v_magic = (1u << 24) / (unsigned)V + 1u;
+  auto div_v = [&](int e) -> int { return (int)(((unsigned)e * v_magic) >> 24); };
 #ifdef E2E_BEAM_PROFILE
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
   if (b == 0 && tid == 0) for (int i = 0; i < 16; i++) g_beam_prof[i] = 0;
@@ -936,15 +942,18 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     // laid out member-major -- P threads per member, each taking every P-th character -- so that what a pair needs of
     // its member (probabilities, last character, word count, LM state) is read once per thread, not once per pair.
     const int npairs = n * V;
-    const int P = n < kThreads ? kThreads / n : 1;            // threads per member
-    const int members_per_pass = kThreads / P;
-    const int part = tid % P;
+    if (n != lay_n) {                                           // (uniform)
+      lay_n = n; lay_P = n < kThreads ? kThreads / n : 1; lay_mpp = kThreads / lay_P; lay_ii0 = tid / lay_P; lay_part = tid - lay_ii0 * lay_P;
+    }
+    const int P = lay_P;                                        // threads per member
+    const int members_per_pass = lay_mpp;
+    const int part = lay_part;
     int my_new = 0;
     // blank shares, child shares, scores of the would-be prefixes (weak child lookup, :250-252)
     // (the high words of the largest key of all and of the smallest key of the old members bracket the selection
     // threshold; they are collected while the keys are produced)
     unsigned key_hi = 0u, key_lo = 0xffffffffu;
-    for (int ii = tid / P; ii < n; ii += members_per_pass) {
+    for (int ii = lay_ii0; ii < n; ii += members_per_pass) {
       const double full = A.full[ii], ppb = A.ppb[ii];
       const int last = A.last[ii];
       LmFields pr;                                              // (only the fields the scores need are ever loaded)
@@ -1311,7 +1320,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       }
       // (the rows of the members that stay: the waves behind those two copy them meanwhile)
       for (int e = tid - 256; e >= 0 && e < nsel * V; e += kThreads - 256) {
-        const int j2 = e / V;
+        const int j2 = div_v(e);
         const int f = Bm.from[j2];
         if (f >= 0) lmcB[e] = lmcA[f * V + (e - j2 * V)];
       }
@@ -1319,14 +1328,14 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
       BPROF(13);
       const int nnew = s_nnew;
       for (int t2 = tid; t2 < nnew * V; t2 += kThreads) {
-        const int r = t2 / V, c = t2 - r * V, j2 = newlist[r];
+        const int r = div_v(t2), c = t2 - r * V, j2 = newlist[r];
         if (c == blank || c == p.space_id) continue;
         lmcB[j2 * V + c] = lm_query<LMK == 2>(p, lt, Bm.lm[j2], Bm.last[j2], c);
       }
       lds_barrier();
       BPROF(14);
       for (int e = tid; e < nsel * V; e += kThreads) {
-        const int j2 = e / V;
+        const int j2 = div_v(e);
         const int o = ldr[j2];
         if (o != j2) lmcB[e] = lmcB[o * V + (e - j2 * V)];
       }
