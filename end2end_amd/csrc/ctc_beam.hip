@@ -907,6 +907,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
   // the pair loop's thread layout depends on n alone, and n is W for all but an utterance's first steps: worked out when n
   // changes (three integer divisions, ~100 instructions per thread of a phase that is bound by the instructions it issues)
   int lay_n = -1, lay_P = 1, lay_mpp = kThreads, lay_ii0 = 0, lay_part = 0;
+  unsigned lay_nmagic = 0u;          // ceil(2^32 / n): q / n for q < W * V by one multiplication (n > 1)
   // e / V for e < 256 * V (candidate and row indices: W < 256) by multiplication
   const unsigned v_magic = (1u << 24) / (unsigned)V + 1u;
   auto div_v = [&](int e) -> int { return (int)(((unsigned)e * v_magic) >> 24); };
@@ -944,6 +945,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
     const int npairs = n * V;
     if (n != lay_n) {                                           // (uniform)
       lay_n = n; lay_P = n < kThreads ? kThreads / n : 1; lay_mpp = kThreads / lay_P; lay_ii0 = tid / lay_P; lay_part = tid - lay_ii0 * lay_P;
+      lay_nmagic = n > 1 ? (unsigned)((0x100000000ULL + (unsigned)n - 1u) / (unsigned)n) : 0u;
     }
     const int P = lay_P;                                        // threads per member
     const int members_per_pass = lay_mpp;
@@ -1048,7 +1050,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         mapB.insert(A.node[i], j);
       } else {
         const int q = d - n;
-        const int c = q / n, i = q - c * n;
+        const int c = n > 1 ? (int)__umulhi((unsigned)q, lay_nmagic) : q, i = q - c * n;      // (q / n: exact for q * n < 2^32)
         const double val = srow[c] + (c == A.last[i] ? A.ppb[i] : A.full[i]);
         int k = atomicAdd(&s_next_node, 1);                                       // make_shared<Prefix>, :254
         if (k >= p.NCAP) { s_err = 1; k = 0; }
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
         copy_lm<LM>(Bm.lm[j], A.lm[d]);
       } else {
         const int q = d - n;
-        const int c = q / n, i = q - c * n;
+        const int c = n > 1 ? (int)__umulhi((unsigned)q, lay_nmagic) : q, i = q - c * n;
         LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
         if (LM) ans = lmcA[i * V + c];
         child_lm<LM>(p, lt, A.lm[i], A.last[i], c, ans, Bm.lm[j]);                 // (straight into LDS: a local LmFields lives in scratch)
