@@ -1493,8 +1493,13 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
   if (LM) for (int c = tid; c < V; c += kThreads) if (c != blank && c != p.space_id) lmc0[c] = lm_query<LMK == 2>(p, lt, M0.lm[0], -1, c);
   gsync();
   int n = 1, cur = 0;
+  // q / n for the candidate numbers of a step (q < n * V, q * n < 2^32) by one multiplication: ceil(2^32 / n), worked out when
+  // the beam's size changes (a division per candidate was a third of the pair loop's instructions at ~30 candidates per thread)
+  int magic_n = -1; unsigned magic = 0u;
+  auto div_n = [&](int q) -> int { return n > 1 ? (int)__umulhi((unsigned)q, magic) : q; };
 
   for (int t = 0; t < T; t++) {
+    if (n != magic_n) { magic_n = n; magic = n > 1 ? (unsigned)((0x100000000ULL + (unsigned)n - 1u) / (unsigned)n) : 0u; }
     Members A, Bm;
     A.carve(mem0 + (size_t)cur * mbytes, W);
     Bm.carve(mem0 + (size_t)(cur ^ 1) * mbytes, W);
@@ -1607,7 +1612,7 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
     int my_new = 0;
     unsigned key_hi = 0u, key_lo = 0xffffffffu;
     for (int e = tid; e < npairs; e += kThreads) {
-      const int si = e / n, ii = e - si * n;            // (slot si of the list outer, prefix inner: the reference's order)
+      const int si = div_n(e), ii = e - si * n;        // (slot si of the list outer, prefix inner: the reference's order)
       const int ci = CH(si);
       const double full = A.full[ii], ppb = A.ppb[ii];
       const int last = A.last[ii];
@@ -1675,7 +1680,7 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
         mapB.insert(A.node[i], j);
       } else {
         const int q = d - n;
-        const int si = q / n, i = q - si * n;
+        const int si = div_n(q), i = q - si * n;
         const int c = CH(si);
         const double val = LP(c) + (c == A.last[i] ? A.ppb[i] : A.full[i]);
         LmAnswer ans; ans.sc = 0.f; ans.wi = 0u;
