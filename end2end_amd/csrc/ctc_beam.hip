@@ -1495,11 +1495,15 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
   int n = 1, cur = 0;
   // q / n for the candidate numbers of a step (q < n * V, q * n < 2^32) by one multiplication: ceil(2^32 / n), worked out when
   // the beam's size changes (a division per candidate was a third of the pair loop's instructions at ~30 candidates per thread)
-  int magic_n = -1; unsigned magic = 0u;
-  auto div_n = [&](int q) -> int { return n > 1 ? (int)__umulhi((unsigned)q, magic) : q; };
+  // (exact while q * n < 2^32; a beam of 512 over an alphabet of 32 000 without the pre-selection is beyond that: plain division)
+  int magic_n = -1; unsigned magic = 0u; bool magic_ok = false;
+  auto div_n = [&](int q) -> int { return magic_ok ? (int)__umulhi((unsigned)q, magic) : q / n; };
 
   for (int t = 0; t < T; t++) {
-    if (n != magic_n) { magic_n = n; magic = n > 1 ? (unsigned)((0x100000000ULL + (unsigned)n - 1u) / (unsigned)n) : 0u; }
+    if (n != magic_n) {
+      magic_n = n; magic = n > 1 ? (unsigned)((0x100000000ULL + (unsigned)n - 1u) / (unsigned)n) : 0u;
+      magic_ok = n > 1 && (unsigned long long)n * (unsigned long long)V * (unsigned long long)n < (1ULL << 32);
+    }
     Members A, Bm;
     A.carve(mem0 + (size_t)cur * mbytes, W);
     Bm.carve(mem0 + (size_t)(cur ^ 1) * mbytes, W);
