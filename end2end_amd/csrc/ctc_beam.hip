@@ -908,9 +908,9 @@ __global__ __launch_bounds__(NT) void ctc_beam_kernel(BeamParams p) {
   // changes (three integer divisions, ~100 instructions per thread of a phase that is bound by the instructions it issues)
   int lay_n = -1, lay_P = 1, lay_mpp = kThreads, lay_ii0 = 0, lay_part = 0;
   unsigned lay_nmagic = 0u;          // ceil(2^32 / n): q / n for q < W * V by one multiplication (n > 1)
-  // e / V for e < 256 * V (candidate and row indices: W < 256) by multiplication
-  const unsigned v_magic = (1u << 24) / (unsigned)V + 1u;
-  auto div_v = [&](int e) -> int { return (int)(((unsigned)e * v_magic) >> 24); };
+  // e / V for row indices e < W * V <= kMaxCand by multiplication: ceil(2^32 / V), exact while e * V < 2^32
+  const unsigned v_magic = V > 1 ? (unsigned)((0x100000000ULL + (unsigned)V - 1u) / (unsigned)V) : 0u;
+  auto div_v = [&](int e) -> int { return V > 1 ? (int)__umulhi((unsigned)e, v_magic) : e; };
 #ifdef E2E_BEAM_PROFILE
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
   if (b == 0 && tid == 0) for (int i = 0; i < 16; i++) g_beam_prof[i] = 0;
