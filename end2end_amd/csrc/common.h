@@ -66,6 +66,13 @@ int launch_reduce_losses(const LossArgs& a);
 
 // Exponential tilt of the fast path's scaled lattice (rows hold alpha[j] r^j and beta[j] r^(L-1-j)); shared by the
 // kernels that produce and that consume its checkpoints.  See LaneCells in ctc_loss_fast.hip.
+// frame number -> (utterance, step) for the one-wave-per-frame kernels: a 32-bit division where the frame count allows it
+// (a 64-bit one is ~100 instructions, more than some of those kernels' own work per frame)
+__device__ __forceinline__ void split_frame(int64_t row, int T, int& b, int& t) {
+  if (row < 0x7fffffffLL) { const unsigned r = (unsigned)row, q = r / (unsigned)T; b = (int)q; t = (int)(r - q * (unsigned)T); }
+  else { b = (int)(row / T); t = (int)(row - (int64_t)b * T); }
+}
+
 __host__ __device__ inline float fast_tilt(int S, int T) {
   float rho = (float)S / (float)T;
   rho = fminf(fmaxf(rho, 1.f / 33.f), 0.8f);

@@ -839,19 +839,15 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // the whole flag vector in ONE round trip per workgroup (every workgroup looks at all of it, so that all of them agree
-  // on what is flagged); flag words and segment counts are kept in LDS for the walks below
+  // on what is flagged); the flag words are kept in LDS for the walks below
   __shared__ int any;
-  __shared__ unsigned short s_flag[kFlagCache], s_nseg[kFlagCache];
+  __shared__ unsigned short s_flag[kFlagCache];
   if (tid == 0) any = 0;
   __syncthreads();
   for (int b = tid; b < p.B; b += kThreads) {
     const int f = p.flags[b] & (kRedoFailed - 1);
     if (f != 0) any = 1;
-    if (b < kFlagCache) {
-      s_flag[b] = (unsigned short)f;
-      const int64_t Tq = f != 0 ? p.x_len[b] : 0;
-      s_nseg[b] = (unsigned short)((Tq >= 1 && Tq <= p.T) ? (Tq + kFastSeg - 1) / kFastSeg : 0);
-    }
+    if (b < kFlagCache) s_flag[b] = (unsigned short)f;
   }
   __syncthreads();
   const bool reduce = p.reduced && p.reduction != E2E_REDUCE_NONE;
@@ -872,11 +868,6 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
     return;
   }
   auto flag_of = [&](int b) -> int { return b < kFlagCache ? (int)s_flag[b] : (p.flags[b] & (kRedoFailed - 1)); };
-  auto nseg_of = [&](int b) -> int {
-    if (b < kFlagCache) return (int)s_nseg[b];
-    const int64_t Tq = p.x_len[b];
-    return (Tq >= 1 && Tq <= p.T) ? (int)((Tq + kFastSeg - 1) / kFastSeg) : 0;
-  };
   auto range_only = [&](int f) -> bool { return p.mode == 1 && p.has_retry && f != 0 && (f & ~(8 | 16)) == 0; };
 
   if (p.mode == 2) {

@@ -848,7 +848,7 @@ __global__ __launch_bounds__(256) void ctc_fast_prob_kernel(FastParams p) {
 #pragma unroll
   for (int r = 0; r < kProbRows; r++) {
     const int64_t row = row0 + r < nrows ? row0 + r : nrows - 1;
-    const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+    int b, t; split_frame(row, p.T, b, t);
     const int64_t Tq = p.x_len[b];
     live[r] = row0 + r < nrows && Tq >= 1 && Tq <= p.T && t < Tq;
     const int64_t xr = (int64_t)b * p.sB + (int64_t)t * p.sT;
@@ -1175,7 +1175,6 @@ __device__ __forceinline__ void segment_body(const P& p, int b, int seg, int T, 
   constexpr int PROW = F2Lds<PPL>::PROW;
   const int blank = p.blank, L = 2 * S + 1, t0 = seg * kSeg;
   const float* ys = lds.ys;
-  float* Ps = lds.Ps;
   const float rr = lc.r;
   const bool cond = (T > 1 || L == 1);
   // the four rescale exponents that fall inside this segment (alpha at t%8 == 7, beta at t%8 == 0)
@@ -1387,7 +1386,6 @@ __device__ __forceinline__ void segment_body_pk(const P& p, int b, int seg, int 
   constexpr int PROW = F2Lds<PPL>::PROW;
   const int blank = p.blank, L = 2 * S + 1, t0 = seg * kSeg;
   const float* ys = lds.ys;
-  float* Ps = lds.Ps;
   const float rr = lc.r;
   const bool cond = (T > 1 || L == 1);
   const int eA7 = in.eA7, eA15 = in.eA15, eB0 = in.eB0, eB8 = in.eB8;

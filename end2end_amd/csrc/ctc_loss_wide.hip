@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_rows_kernel(WideParams p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * kWaves + w;
   if (row >= (int64_t)p.B * p.T) return;
-  const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+  int b, t; split_frame(row, p.T, b, t);
   const int64_t Tq = p.x_len[b];
   if (t >= Tq) return;
   const float* xr = p.x + (int64_t)b * p.sB + (int64_t)t * p.sT;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * kWaves + w;
   if (row >= (int64_t)p.B * p.T) return;
-  const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+  int b, t; split_frame(row, p.T, b, t);
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const float* xr = p.x + (int64_t)b * p.sB + (int64_t)t * p.sT;
   float* gr = p.grads + (size_t)row * p.V;
@@ -299,7 +299,7 @@ __device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row = (int64_t)blockIdx.x * kWaves + w;
   if (row >= (int64_t)p.B * p.T) return;
-  const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+  int b, t; split_frame(row, p.T, b, t);
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const E* xr = reinterpret_cast<const E*>(p.x) + (int64_t)b * p.sB + (int64_t)t * p.sT;
   ev* g4 = reinterpret_cast<ev*>(reinterpret_cast<E*>(p.grads) + (size_t)row * p.V);
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * kWaves + w;
   if (row >= (int64_t)p.B * p.T) return;
-  const int b = (int)(row / p.T), t = (int)(row - (int64_t)b * p.T);
+  int b, t; split_frame(row, p.T, b, t);
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   if (Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax) return;         // (poisoned by wide_rows_dense_kernel already)
   E* gr = reinterpret_cast<E*>(p.grads) + (size_t)row * p.V;
