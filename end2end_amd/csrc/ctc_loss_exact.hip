@@ -108,13 +108,15 @@ constexpr int kRetryGroup = 4;      // rows recomputed and held at a time
 // per-wave LDS of the redo: the segment's probability rows [16][V] (floats), post[V] per-label sums of the row at hand,
 // and the three kept alpha rows [3][8 cells][64 lanes] (registers hold the four rows in work, beta and the row being
 // stepped: with the kept rows on top the kernel spilled 82 registers into its hot loops)
-__host__ __device__ inline size_t retry_wave_lds_bytes(int V) {
-  return ((sizeof(float) * kFastSeg * (size_t)V + sizeof(double) * ((size_t)V + 2) + 15) & ~(size_t)15) + sizeof(double) * 3 * 8 * 64;
+// (ppl: label pairs per lane of the segment kernel whose rows are redone -- the kept rows hold max(8, 2 ppl) cells per lane)
+__host__ __device__ inline int retry_keep_cells(int ppl) { return 2 * ppl > 8 ? 2 * ppl : 8; }
+__host__ __device__ inline size_t retry_wave_lds_bytes(int V, int ppl) {
+  return ((sizeof(float) * kFastSeg * (size_t)V + sizeof(double) * ((size_t)V + 2) + 15) & ~(size_t)15) + sizeof(double) * 3 * retry_keep_cells(ppl) * 64;
 }
 
 template <typename IO, int PPL>
 __device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned char* wsmem, int b, int seg, int lane) {
-  constexpr int NC = 2 * PPL, kSeg = kFastSeg, G = kRetryGroup;
+  constexpr int NC = 2 * PPL, kSeg = kFastSeg, G = kRetryGroup, kKeep = NC > 8 ? NC : 8;
   const FastRetry& rt = p.retry;
   const int V = p.V, blank = p.blank, Tmax = p.T;
   const int T = (int)p.x_len[b], S = (int)p.t_len[b], L = 2 * S + 1;
@@ -221,7 +223,7 @@ __device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned
 #pragma unroll
       for (int i = 0; i < G; i++) if ((g - 1) * G + i < n) alpha_step(a, (g - 1) * G + i);
 #pragma unroll
-      for (int k = 0; k < NC; k++) keep[((g - 1) * 8 + k) * 64 + lane] = a[k];
+      for (int k = 0; k < NC; k++) keep[((g - 1) * kKeep + k) * 64 + lane] = a[k];
     }
   }
   // ---- beta back through the segment, four rows at a time ----
@@ -245,7 +247,7 @@ __device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned
       if (g == 0) checkpoint(a);
       else {
 #pragma unroll
-        for (int k = 0; k < NC; k++) a[k] = keep[((g - 1) * 8 + k) * 64 + lane];
+        for (int k = 0; k < NC; k++) a[k] = keep[((g - 1) * kKeep + k) * 64 + lane];
       }
 #pragma unroll
       for (int i = 0; i < G; i++) {
@@ -834,7 +836,10 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_all_kernel(ExactParams p) 
   }
 }
 
-template <typename IO, bool SCALED>
+// P8: the instance whose f64 redo of single segments is the one for eight label pairs per segment-kernel lane (targets of
+// 256..447 labels, alphabets beyond 224 columns) -- an instance of its own because that redo needs ~250 registers and
+// costs the others their allocation (the headline's fallback regime: 0.205 -> 0.217 ms with all four widths in one kernel)
+template <typename IO, bool SCALED, bool P8 = false>
 __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -878,7 +883,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   } else {
     // ---- 1. segments of the utterances flagged for range only: item i of the running list goes to wave i mod NW ----
     const int NW = (int)gridDim.x * p.redo_waves, me = (int)blockIdx.x * p.redo_waves + wid;
-    unsigned char* wsmem = smem + (size_t)wid * retry_wave_lds_bytes(p.V);
+    unsigned char* wsmem = smem + (size_t)wid * retry_wave_lds_bytes(p.V, p.retry.PPL);
     int base = 0;
     for (int c0 = 0; c0 < p.B && wid < p.redo_waves; c0 += 64) {
       const int bb = c0 + lane;
@@ -915,7 +920,8 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
             }
             if (seg < 0) continue;
             bool ok;
-            if (p.retry.PPL == 1) ok = retry_segment_f64<IO, 1>(p, wsmem, ub, seg, lane);
+            if constexpr (P8) ok = retry_segment_f64<IO, 8>(p, wsmem, ub, seg, lane);
+            else if (p.retry.PPL == 1) ok = retry_segment_f64<IO, 1>(p, wsmem, ub, seg, lane);
             else if (p.retry.PPL == 2) ok = retry_segment_f64<IO, 2>(p, wsmem, ub, seg, lane);
             else ok = retry_segment_f64<IO, 4>(p, wsmem, ub, seg, lane);
             if (!ok && lane == 0) atomicOr(&p.flags[ub], kRedoFailed);
@@ -973,11 +979,11 @@ size_t exact_lds_bytes(int V, int Smax) {
   return sizeof(double) * (2 * Lmax + 2 * S1 + 40) + sizeof(int) * (Lmax + 2 * S1 + ((size_t)V + 31) / 32);
 }
 // waves per workgroup that fit the redo's LDS beside the kernel's static 8.5 KB (wide alphabets: fewer than 8)
-int retry_waves(int V) {
-  const size_t n = (160 * 1024 - 10 * 1024) / retry_wave_lds_bytes(V);
+int retry_waves(int V, int ppl) {
+  const size_t n = (160 * 1024 - 10 * 1024) / retry_wave_lds_bytes(V, ppl);
   return n < 1 ? 0 : n > (size_t)(kThreads / 64) ? kThreads / 64 : (int)n;
 }
-size_t retry_lds_bytes(int V) { return retry_waves(V) * retry_wave_lds_bytes(V); }
+size_t retry_lds_bytes(int V, int ppl) { return retry_waves(V, ppl) * retry_wave_lds_bytes(V, ppl); }
 
 }  // namespace
 
@@ -1008,7 +1014,7 @@ int launch_exact(const LossArgs& a) { return launch_exact_flagged(a, nullptr, 0,
 
 int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetry* retry) {
   size_t lds = exact_lds_bytes(a.V, a.Smax);
-  if (mode == 1 && retry && retry_lds_bytes(a.V) > lds) lds = retry_lds_bytes(a.V);
+  if (mode == 1 && retry && retry_lds_bytes(a.V, retry->PPL) > lds) lds = retry_lds_bytes(a.V, retry->PPL);
   if (lds > 160 * 1024) {
     set_error("exact CTC kernel: V=%d, Smax=%d need %zu B of LDS (> 160 KiB)", a.V, a.Smax, lds);
     return E2E_ERR_UNSUPPORTED;
@@ -1029,8 +1035,9 @@ int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetr
   if (mode != 0 && !p.ctl) { set_error("internal: flagged exact launch without control words"); return E2E_ERR_ARG; }
   // (eight pairs per lane -- targets beyond 255 labels -- have no f64 redo of the segments: the full recomputation takes them)
   const bool f32_lattice = a.dtype == E2E_F32 || dtype_is_16bit(a.dtype);      // (16-bit I/O: the fast path's f32 lattice behind it)
-  p.has_retry = (mode == 1 && retry && f32_lattice && retry_waves(a.V) > 0 && retry->PPL <= 4) ? 1 : 0;
-  p.redo_waves = retry_waves(a.V);
+  p.has_retry = (mode == 1 && retry && f32_lattice && retry_waves(a.V, retry->PPL) > 0 &&
+                 (retry->PPL <= 4 || (retry->PPL == 8 && a.scaled_exact))) ? 1 : 0;      // (eight pairs per lane: the scaled instances only)
+  p.redo_waves = retry ? retry_waves(a.V, retry->PPL) : 0;
   if (p.has_retry) p.retry = *retry; else memset(&p.retry, 0, sizeof(p.retry));
   p.ws_alpha = reinterpret_cast<double*>(a.ws);
   p.ws_lse = reinterpret_cast<double*>(reinterpret_cast<char*>(a.ws) +
@@ -1050,13 +1057,15 @@ int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetr
   if (dtype_is_16bit(a.dtype)) {
     // 16-bit I/O exists behind the fast / wide paths only (flagged utterances of an AUTO or FAST call)
     if (mode == 0) { set_error("the exact kernel takes f32 / f64 logits (16-bit logits: algo AUTO)"); return E2E_ERR_UNSUPPORTED; }
-    if (a.dtype == E2E_F16) rc = scaled ? go(&ctc_exact_kernel<f16_t, true>) : go(&ctc_exact_kernel<f16_t, false>);
-    else rc = scaled ? go(&ctc_exact_kernel<bf16_t, true>) : go(&ctc_exact_kernel<bf16_t, false>);
+    const bool p8 = p.has_retry && p.retry.PPL == 8;
+    if (a.dtype == E2E_F16) rc = p8 ? go(&ctc_exact_kernel<f16_t, true, true>) : scaled ? go(&ctc_exact_kernel<f16_t, true>) : go(&ctc_exact_kernel<f16_t, false>);
+    else rc = p8 ? go(&ctc_exact_kernel<bf16_t, true, true>) : scaled ? go(&ctc_exact_kernel<bf16_t, true>) : go(&ctc_exact_kernel<bf16_t, false>);
   } else if (mode == 0) {
     if (a.dtype != E2E_F32) rc = go(&ctc_exact_all_kernel<double, false>);
     else if (scaled) rc = go(&ctc_exact_all_kernel<float, true>);
     else rc = go(&ctc_exact_all_kernel<float, false>);
   } else if (a.dtype != E2E_F32) rc = go(&ctc_exact_kernel<double, false>);
+  else if (p.has_retry && p.retry.PPL == 8) rc = go(&ctc_exact_kernel<float, true, true>);
   else if (scaled) rc = go(&ctc_exact_kernel<float, true>);
   else rc = go(&ctc_exact_kernel<float, false>);
   if (rc != E2E_OK) return rc;

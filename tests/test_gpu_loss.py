@@ -315,6 +315,34 @@ def test_range_flags_are_redone_in_f64_not_by_the_exact_kernel():
     U.assert_same(ga, ge, F32_RTOL, F32_ATOL, "grads")
 
 
+@pytest.mark.parametrize("shape", [(16, 900, 29, 300), (8, 600, 448, 100)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)
+def test_range_flags_with_eight_pairs_per_lane_are_redone_in_f64_too(shape):
+    """The same regime where the segment kernel holds eight label pairs per lane -- targets of 256..447 labels, alphabets
+    beyond 224 columns: until round 4 those utterances were recomputed in full by the exact kernel (8.5 ms instead of 0.27 for
+    a headline-sized batch with 88 of them); the flagged launch now has an instance whose f64 redo of single segments takes
+    16 cells per lane.  Most utterances must be settled by that redo (few are left for the full recomputation), and the
+    result must be the exact kernel's."""
+    B, T, V, S = shape
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal((B, T, V)) * 3.0).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, S)); tl = rng.integers(max(1, (2 * S) // 3), S + 1, size=B); xl = np.full(B, T); xl[1:] -= rng.integers(0, 60, size=B - 1)
+    args = (torch.from_numpy(x), torch.from_numpy(tg), torch.from_numpy(xl), torch.from_numpy(tl), 0, False)
+    lf, _ = U.c_abi_loss(*args, _lib.ALGO_FAST)
+    keep = {}
+    la, ga = U.c_abi_loss(*args, _lib.ALGO_AUTO, keep=keep)
+    le, ge = U.c_abi_loss(*args, _lib.ALGO_EXACT)
+    nflag = int(np.isnan(lf).sum())
+    assert nflag >= 2, "this input no longer drives the f32 segment kernel out of range: pick a harder one"
+    import ctypes
+    cnt = ctypes.c_int(-1)
+    L = _lib.load()
+    L.e2e_debug_fast_redo_failures.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    assert L.e2e_debug_fast_redo_failures(keep["workspace"].data_ptr(), B, T, V, S, ctypes.byref(cnt)) == 0
+    assert 0 <= cnt.value <= nflag // 2, "%d of %d flagged utterances were left to the full recomputation" % (cnt.value, nflag)
+    U.assert_same(la, le, F32_RTOL, 2e-5, "losses")
+    U.assert_same(ga, ge, F32_RTOL, F32_ATOL, "grads")
+
+
 def test_fast_path_takes_peaky_consistent_emissions():
     """What a trained model emits: logits that favour a valid alignment of the utterance's own targets by 2 .. 20 over unit
     noise.  The fast path must handle these itself (no flag, no exact fallback) and accurately."""
