@@ -812,6 +812,7 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
 
 constexpr int kFlagCache = 2048;    // utterances whose flag words and segment counts a workgroup keeps in LDS
 constexpr int kRedoFailed = 512;    // flag bit set by the segment redo
+constexpr int kRedoSettled = 1024;  // ... and by the slab owner that then recomputed the utterance in full (2b.)
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
@@ -946,6 +947,46 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
         h++;
       }
     }
+    // ---- 2b. what the segment redo could not settle (rows that do not reproduce the chains' log Z: f32 checkpoints that
+    //      lost what mattered -- 1 utterance in 7 with eight pairs per lane and sharp unrelated emissions), shared between
+    //      the workgroups that own an alpha slab.  They wait -- bounded -- until EVERY workgroup has reported the end of
+    //      its redos (nobody waits for them: no cycle); left to the last workgroup alone (3.), 33 such utterances of
+    //      2000 frames took 0.46 s. ----
+    if (P8 && p.mode == 1 && p.has_retry) {          // (the eight-pairs instance only: with narrower rows the redo hardly ever fails)
+      __shared__ int s_all;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      if (tid == 0) {
+        atomicAdd(&p.ctl[2], 1);
+        s_all = 0;
+        if ((int)blockIdx.x < p.nslabs) {
+          int spins = 0;
+          while (__hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x && ++spins < (1 << 18))
+            __builtin_amdgcn_s_sleep(8);
+          s_all = __hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x ? 1 : 0;
+        }
+      }
+      __syncthreads();
+      if (s_all) {                               // (uniform; slab owners only)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        int hf = 0;
+        for (int c0 = 0; c0 < p.B; c0 += 64) {
+          const int bb = c0 + lane;
+          const int f = bb < p.B ? __hip_atomic_load(&p.flags[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+          unsigned long long failed = __ballot((f & kRedoFailed) != 0);
+          while (failed) {
+            const int l = __builtin_ctzll(failed); failed &= failed - 1;
+            if (hf % p.nslabs == (int)blockIdx.x) {
+              ctc_exact_one<IO, SCALED>(p, smem, c0 + l, blockIdx.x);
+              __syncthreads();
+              // (the failed bit stays -- the other slab owners number the same set --, a second bit tells 3. to skip it)
+              if (tid == 0) { atomicAdd(&p.ctl[1], 1); atomicOr(&p.flags[c0 + l], kRedoSettled); }
+            }
+            hf++;
+          }
+        }
+      }
+    }
   }
   // ---- 3. the last workgroup to get here: what the segment redo could not settle, then the reduction ----
   // (release / acquire at agent scope: what other workgroups stored must have left their XCD's L2)
@@ -960,7 +1001,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
     for (int c0 = 0; c0 < p.B; c0 += 64) {
       const int bb = c0 + lane;
       const int f = bb < p.B ? __hip_atomic_load(&p.flags[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      unsigned long long failed = __ballot((f & kRedoFailed) != 0);
+      unsigned long long failed = __ballot((f & kRedoFailed) != 0 && (f & kRedoSettled) == 0);
       while (failed) {
         const int l = __builtin_ctzll(failed); failed &= failed - 1;
         if (tid == 0) atomicAdd(&p.ctl[1], 1);          // (diagnostics: redone in full although only the segments' range gave out)

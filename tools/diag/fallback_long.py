@@ -6,6 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, root)
 import torch
 from end2end_amd import _lib
+if os.environ.get("E2E_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["E2E_LIB"])
 L = _lib.load(); d = torch.device("cuda", 0)
 shapes = [tuple(int(a) for a in sys.argv[1:5])] if len(sys.argv) >= 5 else [(256, 1000, 29, 200), (256, 1000, 29, 300), (64, 600, 448, 100)]
 for (B, T, V, S) in shapes:
@@ -26,5 +27,7 @@ for (B, T, V, S) in shapes:
     fw = (ctypes.c_int * B)(); lz = (ctypes.c_double * (2 * B))()
     L.e2e_debug_fast_state.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
     ok = L.e2e_debug_fast_state(ws.data_ptr(), B, T, V, S, fw, lz) == 0
+    import collections
+    if ok: print("   flag words (1 lengths, 2 blank label, 4 infeasible / inf, 8 range, 16 non-finite, 32 log Z mismatch, 64 tiny emissions, 128 hand-off, 512 redo failed):", dict(collections.Counter(int(f) for f in fw)))
     print("B=%d T=%d V=%d S<=%d: %.3f ms per call, %s utterances handed over, losses finite %s" % (
         B, T, V, S, e0.elapsed_time(e1) / 5, sum(1 for f in fw if f & 0x1ff) if ok else "?", bool(torch.isfinite(losses).all())), flush=True)
