@@ -1,6 +1,6 @@
 """The fallback regime (logits x3 against unrelated targets) at shapes with eight pairs per segment-kernel lane -- long
 transcripts, alphabets beyond 224 columns --, where range-flagged utterances have no f64 redo of single segments:
-time per call and how many utterances the fast path handed over.  python tools/diag/fallback_long.py [B T V S]"""
+time per call and how many utterances the fast path handed over.  python tools/diag/fallback_long.py [B T V S [scale]]"""
 import sys, os, ctypes
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
@@ -8,10 +8,11 @@ import torch
 from end2end_amd import _lib
 if os.environ.get("E2E_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["E2E_LIB"])
 L = _lib.load(); d = torch.device("cuda", 0)
+scale = float(sys.argv[5]) if len(sys.argv) > 5 else 3.0
 shapes = [tuple(int(a) for a in sys.argv[1:5])] if len(sys.argv) >= 5 else [(256, 1000, 29, 200), (256, 1000, 29, 300), (64, 600, 448, 100)]
 for (B, T, V, S) in shapes:
     gen = torch.Generator().manual_seed(3)
-    x = (torch.randn(B, T, V, generator=gen) * 3).to(d); tg = torch.randint(1, V, (B, S), generator=gen).to(d)
+    x = (torch.randn(B, T, V, generator=gen) * scale).to(d); tg = torch.randint(1, V, (B, S), generator=gen).to(d)
     tl = torch.randint(S // 2, S + 1, (B,), generator=gen).to(d); xl = torch.full((B,), T).to(d)
     losses = torch.empty(B, device=d); grads = torch.empty(B, T, V, device=d)
     n = L.e2e_ctc_loss_workspace_bytes(B, T, V, S, 0, 0); ws = torch.zeros(n, dtype=torch.uint8, device=d)
