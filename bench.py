@@ -375,6 +375,89 @@ def fallback_regime_numbers(dev):
             "note": "flagged utterances are redone by the f64 segment redo / the exact kernel inside the same call"}
 
 
+def aligned_batch(seed, B, T, V, S, boost, blank=0):
+    """Emissions CONSISTENT with the targets (what a trained acoustic model produces; the generator of
+    tools/diag/peaky_flag_rate.py): unit-variance noise plus `boost` on one random monotone alignment of each utterance's own
+    targets -- every label gets one frame, blanks fill the rest (a label that would sit directly behind its equal
+    neighbour without a blank is dropped from the path; the targets keep it)."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, T, V)).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, S))
+    tl = rng.integers(max(S // 2, 1), S + 1, size=B)
+    for b in range(B):
+        n = int(tl[b])
+        slots = np.sort(rng.choice(T, size=n, replace=False))
+        path = np.full(T, blank)
+        path[slots] = tg[b, :n]
+        clash = np.nonzero((tg[b, 1:n] == tg[b, :n - 1]) & (slots[1:] == slots[:-1] + 1))[0] + 1
+        path[slots[clash]] = blank
+        x[b, np.arange(T), path] += boost
+    return (torch.from_numpy(x), torch.from_numpy(tg), torch.full((B,), T, dtype=torch.long), torch.from_numpy(tl))
+
+
+def emission_regime_numbers(dev, reps=5):
+    """The headline shape on emissions other than unit-variance noise: what the step costs where users
+    run it.  `trained_regime`: peaky emissions consistent with the targets (boost 6 / 10 / 14 on an alignment);
+    `label_noise`: the same with 8 of the 256 utterances given another utterance's targets (mislabelled data);
+    `sharp_unrelated`: logits x 8 against unrelated random targets (the worst case for a scaled lattice).  One C-ABI call
+    each, HIP events, inputs resident; `flagged_utterances` = utterances the f32 lattice handed to the f64 code inside
+    the same call, `unsettled` = those of them the segment redo could not settle (recomputed in full)."""
+    import ctypes
+    import torch
+    from end2end_amd import _lib
+    L = _lib.load()
+    w = WORKLOAD
+    B, T, V, S = w["B"], w["T"], w["V"], w["S"]
+    L.e2e_debug_fast_state.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
+    L.e2e_debug_fast_redo_failures.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+
+    def leg(host, what):
+        db = tuple(t.to(dev) for t in host)
+        hp = HotPath(db)
+        for _ in range(2):
+            hp.call(hp.means[0, :1])
+        ms = time_events(torch, lambda: hp.call(hp.means[0, :1]), reps)
+        fl = (ctypes.c_int * B)()
+        lz = (ctypes.c_double * (2 * B))()
+        L.e2e_debug_fast_state(hp.ws.data_ptr(), B, T, V, S, fl, lz)
+        un = ctypes.c_int(0)
+        L.e2e_debug_fast_redo_failures(hp.ws.data_ptr(), B, T, V, S, ctypes.byref(un))
+        finite = bool(torch.isfinite(hp.losses).all().item()) and bool(torch.isfinite(hp.grads).all().item())
+        reasons = {}
+        for v in fl:
+            for bit in (1, 2, 4, 8, 16, 32, 64):
+                if v & bit:
+                    reasons[str(bit)] = reasons.get(str(bit), 0) + 1
+        return {"workload": what, "ms": ms, "flagged_utterances": sum(1 for v in fl if v), "unsettled": int(un.value),
+                "flag_reasons": reasons,
+                "frames_per_s": B * T / (ms * 1e-3), "mean_loss": float(hp.losses.mean().item()), "finite": finite}
+
+    out = {"trained_regime": {}}
+    for boost in (6.0, 10.0, 14.0):
+        host = aligned_batch(int(boost), B, T, V, S, boost)
+        out["trained_regime"]["boost_%d" % boost] = leg(
+            host, "B=256 T=1000 V=29 S<=200, unit noise + %g on an alignment of the utterance's own targets" % boost)
+        if boost == 10.0:
+            x, tg, xl, tl = host
+            tg2, tl2 = tg.clone(), tl.clone()
+            for k in range(8):                                   # utterance 32k gets the targets of utterance 32k+1
+                tg2[32 * k], tl2[32 * k] = tg[32 * k + 1], tl[32 * k + 1]
+            out["label_noise"] = leg((x, tg2, xl, tl2), "the boost-10 batch with 8 of 256 utterances given another "
+                                                        "utterance's targets")
+    out["trained_regime"]["ms"] = max(v["ms"] for v in out["trained_regime"].values())
+    out["trained_regime"]["flagged_utterances"] = sum(v["flagged_utterances"] for k, v in out["trained_regime"].items()
+                                                      if k.startswith("boost_"))
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(B, T, V, generator=g) * 8.0
+    tg = torch.randint(1, V, (B, S), generator=g)
+    tl = torch.randint(S // 2, S + 1, (B,), generator=g)
+    out["sharp_unrelated"] = leg((x, tg, torch.full((B,), T, dtype=torch.long), tl),
+                                 "B=256 T=1000 V=29 S<=200, logits x8 against unrelated random targets")
+    return out
+
+
 def shape_cliff_numbers(dev):
     """Loss shapes beside the headline one: what a call costs where the fast paths end.  One C-ABI call each,
     HIP events, inputs resident."""
@@ -651,6 +734,7 @@ def main():
             out["decode"] = decode_numbers(dev, not args.no_cpu_baseline)
             out["fallback_regime"] = fallback_regime_numbers(dev)
             out["shape_cliffs"] = shape_cliff_numbers(dev)
+            out["emission_regimes"] = emission_regime_numbers(dev)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

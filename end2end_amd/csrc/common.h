@@ -89,6 +89,10 @@ struct FastRetry {
   const double* logz;              // [B][2] the chains' log Z (alpha side, beta side)
   const unsigned* segmask;         // [B][MW] bit s: segment s failed its range / self-check in the segment kernel (only those are redone)
   int NS, NB, CELLS, PPL, MW;
+  // the extended-range redo (ctc_ext.h): per-cell exponents of the checkpoint rows it writes over ckA / ckQ for the
+  // utterances it takes, and their partition sums
+  int* ckXA; int* ckXQ;            // [B][NS][CELLS]
+  double* extz;                    // [B][2]  Z = extz[0] * 2^extz[1]
 };
 
 size_t exact_workspace_bytes(int B, int T, int V, int Smax);            // every utterance (algo EXACT)

@@ -1,0 +1,394 @@
+// Extended-range redo of utterances the fast CTC path cannot settle (included by ctc_loss_exact.hip, inside its anonymous
+// namespace, after ExactParams): emissions that contradict the targets sharply -- mislabelled utterances in front of a
+// trained model, logits of scale 8 against unrelated targets.  There the lattice rows span thousands of bits: alpha's mass
+// and beta's sit on different cells, a row scaled by ONE power of two (the fast path's chains, the exact kernel's scaled
+// form) flushes cells whose posterior matters, and what was left was the log-domain walk -- ~10 ms per utterance on one
+// workgroup, 30-220 ms per call.
+//
+// Here every lattice cell carries its own exponent: value = m * 2^e, m an f64, e an int.  A step aligns the (up to three)
+// terms of a cell to the largest exponent among them -- nothing is ever flushed that f64 addition would not drop anyway --
+// and the mantissas are renormalised every fourth step (a probability is >= 2^-100 or exactly zero here: smaller ones
+// carry flag bit 64 and go to the exact kernel; so a mantissa drifts by < 2^-401 between renormalisations).  No tilt, no
+// common frame, no log: ~22 instructions per label pair and step instead of 4, but no exp() / log() per cell either.
+// Same recurrences as the reference (src/losses/ctc_loss.cpp:33-117) in the probability domain.
+//
+// Structure = the fast path's own, run again for the flagged utterances only, inside the flagged launch:
+//   * chains: ONE workgroup per utterance, waves (alpha w, beta w), w < 4, each owning 56 lanes x NP label pairs and
+//     carrying 8 halo lanes of its upstream neighbour's pairs (mass moves at most one pair per step, so the halo lasts
+//     8 NP steps; then the edge lanes are exchanged through LDS behind a workgroup barrier).  Probabilities come from the
+//     table the fast path's producers left (ytab).  Every 16 steps a wave stores its row as a checkpoint: f32 mantissas
+//     over the fast path's own checkpoint arrays, one int exponent per cell beside them.  ~0.07 (NP = 1) / 0.13 (NP = 2)
+//     us per frame instead of 1.6 (scaled form) or 10 (log domain).
+//   * segments: one workgroup per (utterance, 16-step segment), a wave per 32 label pairs (64 held: 16 of halo on either
+//     side, so the 16 steps need no exchange at all); alpha rows of the segment in registers, beta walks back, the
+//     posteriors alpha beta / Z are ordinary doubles in [0, 1] (THEIR underflow is exact) and are summed per label in LDS.
+//   Every workgroup of the launch takes segments; utterances are handed from the chains to the segments through flag bits.
+#pragma once
+
+constexpr int kXZero = -(1 << 30);            // exponent of a zero cell (below anything a row of 2^22 frames can reach)
+constexpr int kXHalo = 8, kXOwnLanes = 64 - kXHalo;
+constexpr int kExtDone = 2048;                // flag bit: the extended-range chains of the utterance are done (checkpoints, Z, loss)
+constexpr int kExtBad = 4096;                 // flag bit: ... and could not settle it (no alignment, a wait that timed out): exact kernel
+constexpr int kExtMaxList = 1024;             // utterances of one call the extended-range redo takes (the rest: exact kernel)
+
+__device__ __forceinline__ int x_fix(double m, int e) { return m != 0.0 ? e : kXZero; }
+__device__ __forceinline__ void x_norm(double& m, int& e) {          // mantissa back to [0.5, 1); zero stays (0, kXZero)
+  e += __builtin_amdgcn_frexp_exp(m);
+  m = __builtin_amdgcn_frexp_mant(m);
+}
+// lane n <- lane n-1 / n+1 of an exponent; the lane without a source gets a zero cell's exponent
+__device__ __forceinline__ int x_shift_up_e(int e) { return __builtin_amdgcn_update_dpp(kXZero, e, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int x_shift_down_e(int e) { return __builtin_amdgcn_update_dpp(kXZero, e, 0x130, 0xf, 0xf, false); }
+
+// One step of a label pair, both directions (alpha: slot (blank g, label g), P = label g-1 of the row before; beta with
+// emission: slot (blank g, label g-1), P = label g of the row after -- the mirror image, see ctc_loss_fast_h1.hip):
+//   B' = (B + P) yb,   L' = (L + B + skip P) yl              ctc_loss.cpp:47-60 / 84-99
+__device__ __forceinline__ void x_pair_step(double& Bm, int& Be, double& Lm, int& Le, double Pm, int Pe, double sk,
+                                            double yb, double yl) {
+  const int PeL = sk != 0.0 ? Pe : kXZero;
+  const int eB = max(Be, Pe), eL = max(Le, max(Be, PeL));
+  const double nB = (ldexp(Bm, Be - eB) + ldexp(Pm, Pe - eB)) * yb;
+  const double nL = fma(sk, ldexp(Pm, PeL - eL), ldexp(Lm, Le - eL) + ldexp(Bm, Be - eL)) * yl;
+  Bm = nB; Be = x_fix(nB, eB);
+  Lm = nL; Le = x_fix(nL, eL);
+}
+
+struct ExtLds {
+  // byte offsets into the workgroup's dynamic LDS
+  static constexpr int kRec = 32;                                   // an edge record: Bm, Lm (doubles), Be, Le (ints), padding
+  static constexpr int edge = 0;                                    // [2 dirs][4 waves][2 buffers][8 lanes][2 slots] records
+  static constexpr int zrec = edge + 2 * 4 * 2 * kXHalo * 2 * kRec; // [2 dirs][2] (m, e as double): the cells of Z
+  static constexpr int chain_total = zrec + 64;
+  // segments: post[16][V + 1] doubles
+  __host__ __device__ static size_t seg_bytes(int V) { return sizeof(double) * 16 * ((size_t)V + 1); }
+  __host__ __device__ static size_t bytes(int V) { return seg_bytes(V) > (size_t)chain_total ? seg_bytes(V) : (size_t)chain_total; }
+};
+
+// probabilities of one 16-step segment for a lane's labels: y[tt] of label `lab` (clamped by the caller) out of ytab
+__device__ __forceinline__ void x_load_rows(const FastRetry& rt, int b, int seg, int Tmax, int V, int lab, float (&out)[16]) {
+  if (rt.ytab_segments) {
+    const float4* src = reinterpret_cast<const float4*>(rt.ytab + (((size_t)b * rt.NS + seg) * V + lab) * kFastSeg);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const float4 v = src[q]; out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w; }
+  } else {
+    const float* src = rt.ytab + ((size_t)b * Tmax + (size_t)seg * kFastSeg) * V + lab;
+    const int nrow = Tmax - seg * kFastSeg;                      // rows of the table that exist from here
+#pragma unroll
+    for (int q = 0; q < 16; q++) out[q] = src[(size_t)(q < nrow ? q : 0) * V];
+  }
+}
+
+// ---- the chains ------------------------------------------------------------------------------------------------------
+// All 8 waves of the workgroup call this (wave = 2 w + DIR); waves that hold no cell only keep the barriers.
+template <int DIR, int NP, typename LT>
+__device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned char* smem, int b, int T, int S, int w, int lane) {
+  constexpr int kOwn = NP * kXOwnLanes, kPeriod = 8 * NP;           // pairs a wave owns; steps a halo lasts
+  const FastRetry& rt = p.retry;
+  const int V = p.V, blank = p.blank, L = 2 * S + 1, Tmax = p.T;
+  const int NSu = (T + kFastSeg - 1) / kFastSeg;
+  const int W = (S + kOwn) / kOwn;                                  // waves that hold a cell: pairs 0 .. S
+  const bool active = w < W;
+  const bool cond = (T > 1 || L == 1);                              // ctc_loss.cpp:39,76
+  const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
+  // slot r of the lane: pair g = g0 + r; alpha holds (blank g, label g), beta (blank g, label g - 1)
+  const int g0 = kOwn * w + NP * (DIR == 0 ? lane - kXHalo : lane);
+  const bool halo = DIR == 0 ? lane < kXHalo : lane >= kXOwnLanes;
+  const bool edge = DIR == 0 ? lane >= 64 - kXHalo : lane < kXHalo;
+  int lab[NP]; double sk[NP]; bool lvalid[NP];
+#pragma unroll
+  for (int r = 0; r < NP; r++) {
+    const int g = g0 + r, li = DIR == 0 ? g : g - 1;
+    lvalid[r] = li >= 0 && li < S;
+    const int lv = lvalid[r] ? (int)tg[li] : 0;
+    lab[r] = min(max(lv, 0), V - 1);
+    if (DIR == 0) {
+      const int lpv = li >= 1 && li < S ? (int)tg[li - 1] : -1;
+      sk[r] = (lvalid[r] && li >= 1 && lv != blank && lpv != lv) ? 1.0 : 0.0;                 // ctc_loss.cpp:53-57
+    } else {
+      const int lnv = li >= 0 && li + 1 < S ? (int)tg[li + 1] : -1;                          // P = label li + 1
+      sk[r] = (lvalid[r] && li + 1 < S && lv != blank && lnv != lv) ? 1.0 : 0.0;              // ctc_loss.cpp:91-96
+    }
+  }
+  double Bm[NP], Lm[NP]; int Be[NP], Le[NP];
+#pragma unroll
+  for (int r = 0; r < NP; r++) { Bm[r] = 0.0; Lm[r] = 0.0; Be[r] = kXZero; Le[r] = kXZero; }
+
+  unsigned char* rec_mine = smem + ExtLds::edge + (size_t)((DIR * 4 + w) * 2) * kXHalo * 2 * ExtLds::kRec;
+  const int upw = DIR == 0 ? w - 1 : w + 1;
+  const bool has_up = active && (DIR == 0 ? w > 0 : w + 1 < W);
+  unsigned char* rec_up = smem + ExtLds::edge + (size_t)((DIR * 4 + (has_up ? upw : 0)) * 2) * kXHalo * 2 * ExtLds::kRec;
+  int nex = 0;                                                      // exchanges so far (buffer = nex & 1)
+
+  float yb[16], yl[NP][16], nyb[16], nyl[NP][16];
+  const int s_first = DIR == 0 ? 0 : NSu - 1;
+  if (active) {
+    x_load_rows(rt, b, s_first, Tmax, V, blank, yb);
+#pragma unroll
+    for (int r = 0; r < NP; r++) x_load_rows(rt, b, s_first, Tmax, V, lab[r], yl[r]);
+  }
+  float* ckm = const_cast<float*>(DIR == 0 ? rt.ckA : rt.ckQ) + (size_t)b * rt.NS * rt.CELLS;
+  int* cke = (DIR == 0 ? rt.ckXA : rt.ckXQ) + (size_t)b * rt.NS * rt.CELLS;
+
+  for (int si = 0; si < NSu; si++) {
+    const int s = DIR == 0 ? si : NSu - 1 - si;
+    const int s_next = DIR == 0 ? s + 1 : s - 1;
+    if (active && si + 1 < NSu) {                                   // the next segment's rows: asked for a segment ahead
+      x_load_rows(rt, b, s_next, Tmax, V, blank, nyb);
+#pragma unroll
+      for (int r = 0; r < NP; r++) x_load_rows(rt, b, s_next, Tmax, V, lab[r], nyl[r]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int tt = DIR == 0 ? k : 15 - k;
+      const int t = s * kFastSeg + tt;
+      if (t >= T) continue;                                         // (uniform: the utterance's last segment may be short)
+      // halo refill: alpha before the steps t = kPeriod i > 0, beta before the steps t = kPeriod i - 1 < T - 1 -- the same
+      // number of exchanges in both directions, so that every wave of the workgroup meets every barrier
+      const bool exchange = DIR == 0 ? (tt % kPeriod == 0 && t > 0) : ((tt + 1) % kPeriod == 0 && t < T - 1);
+      if (exchange) {
+        if (active && edge) {
+#pragma unroll
+          for (int r = 0; r < NP; r++) {
+            unsigned char* q = rec_mine + (size_t)(((nex & 1) * kXHalo + (lane & (kXHalo - 1))) * 2 + r) * ExtLds::kRec;
+            *reinterpret_cast<double2*>(q) = double2{Bm[r], Lm[r]};
+            *reinterpret_cast<int2*>(q + 16) = int2{Be[r], Le[r]};
+          }
+        }
+        __syncthreads();
+        if (has_up && halo) {
+#pragma unroll
+          for (int r = 0; r < NP; r++) {
+            const unsigned char* q = rec_up + (size_t)(((nex & 1) * kXHalo + (lane & (kXHalo - 1))) * 2 + r) * ExtLds::kRec;
+            const double2 v = *reinterpret_cast<const double2*>(q);
+            const int2 e = *reinterpret_cast<const int2*>(q + 16);
+            Bm[r] = v.x; Lm[r] = v.y; Be[r] = e.x; Le[r] = e.y;
+          }
+        }
+        nex++;
+      }
+      if (!active) continue;
+      const double ybt = (double)yb[tt];
+      if (DIR == 0 ? t == 0 : t == T - 1) {
+        // the first row: ctc_loss.cpp:39-42 (alpha), :76-78 with the emission (beta)
+#pragma unroll
+        for (int r = 0; r < NP; r++) {
+          const int g = g0 + r;
+          const bool isB = DIR == 0 ? g == 0 : g == S, isL = DIR == 0 ? (g == 0 && S > 0) : (g == S && S > 0);
+          const double vb = (isB && cond) ? ybt : 0.0, vl = isL ? (double)yl[r][tt] : 0.0;
+          Bm[r] = vb; Be[r] = x_fix(vb, 0); Lm[r] = vl; Le[r] = x_fix(vl, 0);
+        }
+      } else if (DIR == 0) {
+        double Pm = lane_shift_up(Lm[NP - 1]); int Pe = x_shift_up_e(Le[NP - 1]);
+#pragma unroll
+        for (int r = 0; r < NP; r++) {
+          const double om = Lm[r]; const int oe = Le[r];
+          x_pair_step(Bm[r], Be[r], Lm[r], Le[r], Pm, Pe, sk[r], ybt, lvalid[r] ? (double)yl[r][tt] : 0.0);
+          Pm = om; Pe = oe;
+        }
+      } else {
+        double Pm = lane_shift_down(Lm[0]); int Pe = x_shift_down_e(Le[0]);
+#pragma unroll
+        for (int r = NP - 1; r >= 0; r--) {
+          const double om = Lm[r]; const int oe = Le[r];
+          x_pair_step(Bm[r], Be[r], Lm[r], Le[r], Pm, Pe, sk[r], ybt, lvalid[r] ? (double)yl[r][tt] : 0.0);
+          Pm = om; Pe = oe;
+        }
+      }
+      if ((k & 3) == 3 || (DIR == 0 ? t == T - 1 : t == 0)) {
+#pragma unroll
+        for (int r = 0; r < NP; r++) { x_norm(Bm[r], Be[r]); x_norm(Lm[r], Le[r]); }
+      }
+      // checkpoints: alpha row t = 16 k - 1 -> slot k, beta-with-emission row t = 16 k -> slot k (0 < 16 k < T), cells in
+      // lattice order (blank g = cell 2 g, label g = cell 2 g + 1); freshly normalised, the mantissa as f32
+      if (DIR == 0 ? (tt == 15 && t + 1 < T) : (tt == 0 && t > 0)) {
+        const int slot = DIR == 0 ? s + 1 : s;
+        if (!halo) {
+#pragma unroll
+          for (int r = 0; r < NP; r++) {
+            const int g = g0 + r;
+            if (g >= 0 && g <= S) {
+              const size_t cb = (size_t)slot * rt.CELLS + 2 * g;
+              ckm[cb] = (float)Bm[r]; cke[cb] = Be[r];
+              if (DIR == 0) { ckm[cb + 1] = (float)Lm[r]; cke[cb + 1] = Le[r]; }
+              else if (g >= 1) { ckm[cb - 1] = (float)Lm[r]; cke[cb - 1] = Le[r]; }
+            }
+          }
+        }
+      }
+    }
+    if (active && si + 1 < NSu) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        yb[q] = nyb[q];
+#pragma unroll
+        for (int r = 0; r < NP; r++) yl[r][q] = nyl[r][q];
+      }
+    }
+  }
+  // ---- Z from this side: alpha (ctc_loss.cpp:63-70): blank S + label S-1 of the last row; beta: sum_j alpha_0[j] beta_0[j]
+  //      = [cond] blank 0 + label 0 of the row t = 0 (with their emissions) ----
+  if (active && !halo) {
+    double* z = reinterpret_cast<double*>(smem + ExtLds::zrec) + DIR * 4;
+#pragma unroll
+    for (int r = 0; r < NP; r++) {
+      const int g = g0 + r;
+      if (DIR == 0) {
+        if (g == S) { z[0] = Bm[r]; z[1] = (double)Be[r]; }
+        if (g == S - 1) { z[2] = Lm[r]; z[3] = (double)Le[r]; }
+      } else {
+        if (g == 0) { z[0] = cond ? Bm[r] : 0.0; z[1] = (double)(cond ? Be[r] : kXZero); }
+        if (g == 1) { z[2] = Lm[r]; z[3] = (double)Le[r]; }
+      }
+    }
+  }
+}
+
+// One utterance's chains on this workgroup.  Ends with the utterance's flag word carrying kExtDone (and kExtBad if the
+// partition sum is not a positive number or the two sides disagree), after a release fence.
+template <typename IO>
+__device__ __forceinline__ void ext_chains(const ExactParams& p, unsigned char* smem, int b) {
+  typedef typename LossOf<IO>::type LT;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int T = (int)p.x_len[b], S = (int)p.t_len[b];
+  const int dir = wid & 1, w = wid >> 1;
+  if (tid < 8) {
+    double* z = reinterpret_cast<double*>(smem + ExtLds::zrec);
+    z[tid] = (tid & 1) ? (double)kXZero : 0.0;
+  }
+  __syncthreads();
+  if (S + 1 <= 4 * kXOwnLanes) {
+    if (dir == 0) ext_chain_wave<0, 1, LT>(p, smem, b, T, S, w, lane); else ext_chain_wave<1, 1, LT>(p, smem, b, T, S, w, lane);
+  } else {
+    if (dir == 0) ext_chain_wave<0, 2, LT>(p, smem, b, T, S, w, lane); else ext_chain_wave<1, 2, LT>(p, smem, b, T, S, w, lane);
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    const double* z = reinterpret_cast<const double*>(smem + ExtLds::zrec);
+    auto sum2 = [&](const double* c, double& m, int& e) {
+      const int e0 = (int)c[1], e1 = (int)c[3];
+      e = max(e0, e1);
+      m = ldexp(c[0], e0 - e) + ldexp(c[2], e1 - e);
+      if (m == 0.0) e = kXZero;
+      x_norm(m, e);
+    };
+    double ma, mb; int ea, eb;
+    sum2(z, ma, ea); sum2(z + 4, mb, eb);
+    const double la = log(ma) + (double)ea * 0.693147180559945309417, lb = log(mb) + (double)eb * 0.693147180559945309417;
+    const bool ok = ma > 0.0 && mb > 0.0 && fabs(la - lb) <= 1e-8 * fmax(1.0, fabs(la));
+    if (ok) {
+      p.retry.extz[2 * b] = ma; p.retry.extz[2 * b + 1] = (double)ea;
+      reinterpret_cast<LT*>(p.losses)[b] = (LT)(-la);
+    }
+    __threadfence();
+    atomicOr(&p.flags[b], ok ? kExtDone : (kExtDone | kExtBad));
+  }
+  __syncthreads();
+}
+
+// ---- the segments ----------------------------------------------------------------------------------------------------
+// One (utterance, 16-step segment) on this workgroup: wave c takes the label pairs 32 c .. 32 c + 31 (its lanes hold the
+// pairs 32 c - 16 .. 32 c + 47: what the 16 steps can reach from either side), c = wid, wid + 8, ...
+template <typename IO>
+__device__ __forceinline__ void ext_segment(const ExactParams& p, unsigned char* smem, int b, int seg) {
+  const FastRetry& rt = p.retry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int V = p.V, blank = p.blank, Tmax = p.T;
+  const int T = (int)p.x_len[b], S = (int)p.t_len[b], L = 2 * S + 1;
+  const int t0 = seg * kFastSeg, n = min(kFastSeg, T - t0);
+  const bool cond = (T > 1 || L == 1);
+  double* post = reinterpret_cast<double*>(smem);                   // [16][V + 1]
+  for (int i = tid; i < 16 * (V + 1); i += kThreads) post[i] = 0.0;
+  __syncthreads();
+  const double Zinv = 1.0 / rt.extz[2 * b];
+  const int Ze = (int)rt.extz[2 * b + 1];
+  const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
+  const int nchunk = (S + 32) / 32;                                 // pairs 0 .. S
+  for (int c = wid; c < nchunk; c += kThreads / 64) {
+    const int g = 32 * c - 16 + lane;
+    const bool own = lane >= 16 && lane < 48 && g <= S;
+    const bool lvalid = g >= 0 && g < S;
+    const int lv = lvalid ? (int)tg[g] : 0;
+    const int lab = min(max(lv, 0), V - 1);
+    const int lpv = g >= 1 && g < S ? (int)tg[g - 1] : -1, lnv = g >= 0 && g + 1 < S ? (int)tg[g + 1] : -1;
+    const double skp = (lvalid && g >= 1 && lv != blank && lpv != lv) ? 1.0 : 0.0;           // ctc_loss.cpp:53-57
+    const double skn = (lvalid && g + 1 < S && lv != blank && lnv != lv) ? 1.0 : 0.0;         // ctc_loss.cpp:91-96
+    float yb[16], yl[16];
+    x_load_rows(rt, b, seg, Tmax, V, blank, yb);
+    x_load_rows(rt, b, seg, Tmax, V, lab, yl);
+    // ---- alpha rows t0 .. t0 + n - 1 ----
+    double aBm[16], aLm[16]; int aBe[16], aLe[16];
+    double Bm = 0.0, Lm = 0.0; int Be = kXZero, Le = kXZero;
+    if (seg > 0 && g >= 0 && g <= S) {
+      const size_t cb = ((size_t)b * rt.NS + seg) * rt.CELLS + 2 * g;
+      Bm = (double)rt.ckA[cb]; Be = rt.ckXA[cb]; Lm = (double)rt.ckA[cb + 1]; Le = rt.ckXA[cb + 1];
+      Be = x_fix(Bm, Be); Le = x_fix(Lm, Le);
+    }
+#pragma unroll
+    for (int tt = 0; tt < 16; tt++) {
+      if (tt < n) {
+        const double ybt = (double)yb[tt], ylt = lvalid ? (double)yl[tt] : 0.0;
+        if (t0 + tt == 0) {
+          const double vb = (g == 0 && cond) ? ybt : 0.0, vl = (g == 0 && S > 0) ? ylt : 0.0;
+          Bm = vb; Be = x_fix(vb, 0); Lm = vl; Le = x_fix(vl, 0);
+        } else {
+          const double Pm = lane_shift_up(Lm); const int Pe = x_shift_up_e(Le);
+          x_pair_step(Bm, Be, Lm, Le, Pm, Pe, skp, ybt, ylt);
+        }
+        if ((tt & 3) == 3) { x_norm(Bm, Be); x_norm(Lm, Le); }
+      }
+      aBm[tt] = Bm; aBe[tt] = Be; aLm[tt] = Lm; aLe[tt] = Le;
+    }
+    // ---- beta back through the segment (q = beta with its emission; unshifted pairing: slot (blank g, label g)) ----
+    double qBm = 0.0, qLm = 0.0; int qBe = kXZero, qLe = kXZero;
+    if (t0 + n < T && g >= 0 && g <= S) {
+      const size_t cb = ((size_t)b * rt.NS + seg + 1) * rt.CELLS + 2 * g;
+      qBm = (double)rt.ckQ[cb]; qBe = rt.ckXQ[cb]; qLm = (double)rt.ckQ[cb + 1]; qLe = rt.ckXQ[cb + 1];
+      qBe = x_fix(qBm, qBe); qLe = x_fix(qLm, qLe);
+      if (g == S) { qLm = 0.0; qLe = kXZero; }                      // (label S does not exist; its checkpoint cell is never written)
+    }
+#pragma unroll
+    for (int tt = 15; tt >= 0; tt--) {
+      if (tt >= n) continue;
+      const int t = t0 + tt;
+      // beta of row t WITHOUT its emission (ctc_loss.cpp:72-100): what alpha_t is multiplied with
+      double bBm, bLm; int bBe, bLe;
+      if (t == T - 1) {
+        bBm = (g == S && cond) ? 1.0 : 0.0; bBe = x_fix(bBm, 0);
+        bLm = (g == S - 1 && g >= 0) ? 1.0 : 0.0; bLe = x_fix(bLm, 0);
+      } else {
+        const double nBm = lane_shift_down(qBm), nLm = lane_shift_down(qLm);
+        const int nBe = x_shift_down_e(qBe), nLe = x_shift_down_e(qLe);
+        bBe = max(qBe, qLe);
+        bBm = ldexp(qBm, qBe - bBe) + ldexp(qLm, qLe - bBe);
+        bBe = x_fix(bBm, bBe);
+        const int nLeS = skn != 0.0 ? nLe : kXZero;
+        bLe = max(qLe, max(nBe, nLeS));
+        bLm = fma(skn, ldexp(nLm, nLeS - bLe), ldexp(qLm, qLe - bLe) + ldexp(nBm, nBe - bLe));
+        bLe = x_fix(bLm, bLe);
+      }
+      // posteriors of the lane's two cells (ordinary doubles: a posterior below 2^-1074 IS zero)
+      const double pB = ldexp(aBm[tt] * bBm * Zinv, aBe[tt] + bBe - Ze);
+      const double pL = ldexp(aLm[tt] * bLm * Zinv, aLe[tt] + bLe - Ze);
+      double pb = own ? pB : 0.0;
+      pb = wave_sum_lane63(pb);
+      if (lane == 63 && pb != 0.0) atomicAdd(&post[tt * (V + 1) + blank], pb);
+      if (own && lvalid && pL != 0.0) atomicAdd(&post[tt * (V + 1) + lab], pL);
+      // q of row t
+      const double ybt = (double)yb[tt], ylt = lvalid ? (double)yl[tt] : 0.0;
+      qBm = bBm * ybt; qBe = x_fix(qBm, bBe);
+      qLm = bLm * ylt; qLe = x_fix(qLm, bLe);
+      if ((tt & 3) == 0) { x_norm(qBm, qBe); x_norm(qLm, qLe); }
+    }
+  }
+  __syncthreads();
+  // ---- the rows: y - posterior (ctc_loss.cpp:102-117) ----
+  IO* grads = reinterpret_cast<IO*>(p.grads) + (size_t)b * (size_t)Tmax * (size_t)V;
+  for (int i = tid; i < n * V; i += kThreads) {
+    const int tt = i / V, v = i - tt * V;
+    const float y = rt.ytab_segments ? rt.ytab[(((size_t)b * rt.NS + seg) * V + v) * kFastSeg + tt]
+                                     : rt.ytab[((size_t)b * Tmax + t0 + tt) * V + v];
+    grads[(size_t)(t0 + tt) * V + v] = (IO)(((double)y - post[tt * (V + 1) + v]) * p.gscale);
+  }
+  __syncthreads();
+}

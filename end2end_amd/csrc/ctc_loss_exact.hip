@@ -41,6 +41,7 @@ struct ExactParams {
   double gscale;      // every gradient element is multiplied by this as it is written
   void* reduced; int reduction;   // flagged modes: optional sum / mean of the losses, written by the last workgroup
   int has_retry; FastRetry retry;   // mode 1: the fast path's checkpoints, for the f64 redo of its second kernel
+  int has_ext;        // mode 1: utterances whose numbers -- not whose inputs -- defeated the fast path are redone in extended range (ctc_ext.h)
 };
 
 __device__ __forceinline__ double neg_inf() { return -__builtin_huge_val(); }
@@ -325,6 +326,8 @@ __device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned
   }
   return !__any(bad);
 }
+
+#include "ctc_ext.h"
 
 // One utterance b, with the alpha slab `slot` of the workspace.
 // (forced inline: out of line the parameter block is handed over through scratch memory and every pointer in it becomes
@@ -875,6 +878,8 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   }
   auto flag_of = [&](int b) -> int { return b < kFlagCache ? (int)s_flag[b] : (p.flags[b] & (kRedoFailed - 1)); };
   auto range_only = [&](int f) -> bool { return p.mode == 1 && p.has_retry && f != 0 && (f & ~(8 | 16)) == 0; };
+  // flagged for its numbers, not for its inputs (1: lengths, 2: blank inside the targets, 64: probabilities at the end of f32, 128: protocol)
+  auto ext_candidate = [&](int f) -> bool { return p.mode == 1 && p.has_ext && (f & (4 | 32)) != 0 && (f & (1 | 2 | 64 | 128)) == 0; };
 
   if (p.mode == 2) {
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
@@ -931,13 +936,96 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
       }
       base += tot;
     }
-    __syncthreads();                         // (the waves' LDS is taken over by the full recomputation)
-    // ---- 2. everything else that is flagged: the reference's arithmetic, utterance h on workgroup h mod nslabs ----
+    __syncthreads();                         // (the waves' LDS is taken over by what follows)
+    // ---- X. extended-range redo (ctc_ext.h) of what is flagged for its NUMBERS: alpha / beta log Z mismatch (32), a partition
+    //      sum out of range (4), and -- once every workgroup has reported the end of its redos -- what step 1 could not
+    //      settle (512).  Chains: utterance i of the list on workgroup i mod grid; then every workgroup takes segments. ----
+    __shared__ int s_dec, s_next, s_go;
+    __shared__ int s_xb[kExtMaxList];                   // the list: utterance numbers ...
+    __shared__ int s_xoff[kExtMaxList + 1];             // ... and the running count of their segments
+    if (p.has_ext) {
+      // (a) have all workgroups finished step 1?  Bounded wait (a grid that is not resident at once -- a partitioned or shared
+      //     GPU -- must not hang): all workgroups adopt ONE decision, 1 = everybody arrived, 2 = some wait ran out (then what
+      //     step 1 could not settle is left to step 3).  No wait at all when step 1 had nothing to do.
+      bool any_range = false;
+      for (int b = tid; b < p.B; b += kThreads) any_range |= range_only(flag_of(b));
+      const int have_range = __syncthreads_or(any_range ? 1 : 0);
+      if (have_range) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0) {
+          atomicAdd(&p.ctl[2], 1);
+          int spins = 0;
+          while (__hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x &&
+                 __hip_atomic_load(&p.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 15))
+            __builtin_amdgcn_s_sleep(8);
+          const int mine = __hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x ? 1 : 2;
+          const int was = atomicCAS(&p.ctl[3], 0, mine);
+          s_dec = was != 0 ? was : mine;
+          if (was == 0 && mine == 2) atomicAdd(&p.ctl[4], 1);       // (diagnostics: a wait ran out)
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      } else {
+        if (tid == 0) s_dec = 1;
+        __syncthreads();
+      }
+      const bool see_failed = s_dec == 1 && have_range;
+      // (b) the list, in utterance order, the same in every workgroup
+      if (wid == 0) {
+        int nx = 0, off = 0;
+        for (int c0 = 0; c0 < p.B && nx < kExtMaxList; c0 += 64) {
+          const int bb = c0 + lane;
+          int f = 0;
+          if (bb < p.B) {
+            f = flag_of(bb);
+            if (see_failed && range_only(f) &&
+                (__hip_atomic_load(&p.flags[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kRedoFailed)) f |= kRedoFailed;
+          }
+          const bool take = bb < p.B && (ext_candidate(f) || (f & kRedoFailed) != 0);
+          const int nseg = take ? ((int)p.x_len[bb] + kFastSeg - 1) / kFastSeg : 0;
+          const unsigned long long m = __ballot(take);
+          const int before = __builtin_popcountll(m & ((1ull << lane) - 1));
+          const int incl = wave_incl_scan(nseg, lane);
+          if (take && nx + before < kExtMaxList) { s_xb[nx + before] = bb; s_xoff[nx + before] = off + incl - nseg; }
+          const int cnt = __builtin_popcountll(m);
+          // (a list that overflows is cut at a chunk boundary: the rest is left to step 3)
+          if (nx + cnt > kExtMaxList) break;
+          nx += cnt; off += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (lane == 0) { s_next = nx; s_xoff[nx] = off; }
+      }
+      __syncthreads();
+      const int nx = s_next, nitems = s_xoff[nx];
+      // (c) chains
+      for (int i = blockIdx.x; i < nx; i += gridDim.x) ext_chains<IO>(p, smem, s_xb[i]);
+      // (d) segments: item j of the running list on workgroup j mod grid, once its utterance's chains are done
+      for (int j = blockIdx.x; j < nitems; j += gridDim.x) {
+        int lo = 0, hi = nx - 1;                                    // the utterance of item j: last i with s_xoff[i] <= j
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_xoff[mid] <= j) lo = mid; else hi = mid - 1; }
+        const int ub = s_xb[lo], seg = j - s_xoff[lo];
+        if (tid == 0) {
+          int f, spins = 0;
+          while (((f = __hip_atomic_load(&p.flags[ub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kExtDone) == 0 && ++spins < (1 << 16))
+            __builtin_amdgcn_s_sleep(8);
+          if ((f & kExtDone) == 0) { atomicOr(&p.flags[ub], kExtBad); atomicAdd(&p.ctl[4], 1); f |= kExtBad; }
+          s_go = (f & kExtBad) == 0;
+        }
+        __syncthreads();
+        if (s_go) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          ext_segment<IO>(p, smem, ub, seg);
+        }
+        __syncthreads();
+      }
+    }
+    // ---- 2. what is flagged for its INPUTS (bad lengths, a blank inside the targets, probabilities at the end of f32, a
+    //      protocol error): the reference's arithmetic, utterance h on workgroup h mod nslabs ----
     int h = 0;
     for (int c0 = 0; c0 < p.B; c0 += 64) {
       const int bb = c0 + lane;
       const int f = bb < p.B ? flag_of(bb) : 0;
-      unsigned long long hard = __ballot(f != 0 && !range_only(f));
+      unsigned long long hard = __ballot(f != 0 && !range_only(f) && !ext_candidate(f));
       while (hard) {
         const int l = __builtin_ctzll(hard); hard &= hard - 1;
         if ((int)blockIdx.x < p.nslabs && h % p.nslabs == (int)blockIdx.x) {
@@ -945,46 +1033,6 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
           __syncthreads();
         }
         h++;
-      }
-    }
-    // ---- 2b. what the segment redo could not settle (rows that do not reproduce the chains' log Z: f32 checkpoints that
-    //      lost what mattered -- 1 utterance in 7 with eight pairs per lane and sharp unrelated emissions), shared between
-    //      the workgroups that own an alpha slab.  They wait -- bounded -- until EVERY workgroup has reported the end of
-    //      its redos (nobody waits for them: no cycle); left to the last workgroup alone (3.), 33 such utterances of
-    //      2000 frames took 0.46 s. ----
-    if (P8 && p.mode == 1 && p.has_retry) {          // (the eight-pairs instance only: with narrower rows the redo hardly ever fails)
-      __shared__ int s_all;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __syncthreads();
-      if (tid == 0) {
-        atomicAdd(&p.ctl[2], 1);
-        s_all = 0;
-        if ((int)blockIdx.x < p.nslabs) {
-          int spins = 0;
-          while (__hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x && ++spins < (1 << 18))
-            __builtin_amdgcn_s_sleep(8);
-          s_all = __hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x ? 1 : 0;
-        }
-      }
-      __syncthreads();
-      if (s_all) {                               // (uniform; slab owners only)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        int hf = 0;
-        for (int c0 = 0; c0 < p.B; c0 += 64) {
-          const int bb = c0 + lane;
-          const int f = bb < p.B ? __hip_atomic_load(&p.flags[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-          unsigned long long failed = __ballot((f & kRedoFailed) != 0);
-          while (failed) {
-            const int l = __builtin_ctzll(failed); failed &= failed - 1;
-            if (hf % p.nslabs == (int)blockIdx.x) {
-              ctc_exact_one<IO, SCALED>(p, smem, c0 + l, blockIdx.x);
-              __syncthreads();
-              // (the failed bit stays -- the other slab owners number the same set --, a second bit tells 3. to skip it)
-              if (tid == 0) { atomicAdd(&p.ctl[1], 1); atomicOr(&p.flags[c0 + l], kRedoSettled); }
-            }
-            hf++;
-          }
-        }
       }
     }
   }
@@ -1001,7 +1049,9 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
     for (int c0 = 0; c0 < p.B; c0 += 64) {
       const int bb = c0 + lane;
       const int f = bb < p.B ? __hip_atomic_load(&p.flags[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      unsigned long long failed = __ballot((f & kRedoFailed) != 0 && (f & kRedoSettled) == 0);
+      // what nothing has settled: a failed segment redo or an extended-range candidate without good extended-range chains
+      const bool settled = (f & kExtDone) != 0 && (f & kExtBad) == 0;
+      unsigned long long failed = __ballot(((f & kRedoFailed) != 0 || ext_candidate(f & (kRedoFailed - 1))) && !settled);
       while (failed) {
         const int l = __builtin_ctzll(failed); failed &= failed - 1;
         if (tid == 0) atomicAdd(&p.ctl[1], 1);          // (diagnostics: redone in full although only the segments' range gave out)
@@ -1019,9 +1069,9 @@ size_t exact_lds_bytes(int V, int Smax) {
   const size_t Lmax = 2 * (size_t)Smax + 1, S1 = Smax > 0 ? Smax : 1;
   return sizeof(double) * (2 * Lmax + 2 * S1 + 40) + sizeof(int) * (Lmax + 2 * S1 + ((size_t)V + 31) / 32);
 }
-// waves per workgroup that fit the redo's LDS beside the kernel's static 8.5 KB (wide alphabets: fewer than 8)
+// waves per workgroup that fit the redo's LDS beside the kernel's static 12.5 KB (wide alphabets: fewer than 8)
 int retry_waves(int V, int ppl) {
-  const size_t n = (160 * 1024 - 10 * 1024) / retry_wave_lds_bytes(V, ppl);
+  const size_t n = (160 * 1024 - 14 * 1024) / retry_wave_lds_bytes(V, ppl);
   return n < 1 ? 0 : n > (size_t)(kThreads / 64) ? kThreads / 64 : (int)n;
 }
 size_t retry_lds_bytes(int V, int ppl) { return retry_waves(V, ppl) * retry_wave_lds_bytes(V, ppl); }
@@ -1056,8 +1106,12 @@ int launch_exact(const LossArgs& a) { return launch_exact_flagged(a, nullptr, 0,
 int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetry* retry) {
   size_t lds = exact_lds_bytes(a.V, a.Smax);
   if (mode == 1 && retry && retry_lds_bytes(a.V, retry->PPL) > lds) lds = retry_lds_bytes(a.V, retry->PPL);
-  if (lds > 160 * 1024) {
-    set_error("exact CTC kernel: V=%d, Smax=%d need %zu B of LDS (> 160 KiB)", a.V, a.Smax, lds);
+  // the extended-range redo stands in where the scaled form may (f32 lattice behind an AUTO call); its LDS must fit beside the rest
+  const bool ext_ok = mode == 1 && retry && a.scaled_exact && (a.dtype == E2E_F32 || dtype_is_16bit(a.dtype)) &&
+                      retry->PPL >= 1 && 2 * a.Smax + 2 <= retry->CELLS && ExtLds::bytes(a.V) <= 120 * 1024 && getenv("E2E_NO_EXT") == nullptr;
+  if (ext_ok && ExtLds::bytes(a.V) > lds) lds = ExtLds::bytes(a.V);
+  if (lds > 146 * 1024) {
+    set_error("exact CTC kernel: V=%d, Smax=%d need %zu B of LDS (> 146 KiB beside its static 12.5)", a.V, a.Smax, lds);
     return E2E_ERR_UNSUPPORTED;
   }
   const int slabs = mode == 0 ? a.B : (a.B < kFallbackSlabs ? a.B : kFallbackSlabs);
@@ -1079,7 +1133,8 @@ int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetr
   p.has_retry = (mode == 1 && retry && f32_lattice && retry_waves(a.V, retry->PPL) > 0 &&
                  (retry->PPL <= 4 || (retry->PPL == 8 && a.scaled_exact))) ? 1 : 0;      // (eight pairs per lane: the scaled instances only)
   p.redo_waves = retry ? retry_waves(a.V, retry->PPL) : 0;
-  if (p.has_retry) p.retry = *retry; else memset(&p.retry, 0, sizeof(p.retry));
+  p.has_ext = ext_ok ? 1 : 0;
+  if (p.has_retry || p.has_ext) p.retry = *retry; else memset(&p.retry, 0, sizeof(p.retry));
   p.ws_alpha = reinterpret_cast<double*>(a.ws);
   p.ws_lse = reinterpret_cast<double*>(reinterpret_cast<char*>(a.ws) +
                                        align_up((size_t)slabs * a.T * p.Lmax * sizeof(double), 256));

@@ -255,7 +255,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(512) void ctc_fast_chain_kernel(Fa
   const int V = p.V;
   const F1Lds lds(smem, V);
 
-  if (b == 0 && tid < 4) p.ctl[tid] = 0;     // (this kernel ends before the fallback launch, which counts there, starts)
+  if (b == 0 && tid < 8) p.ctl[tid] = 0;     // (this kernel ends before the fallback launch, which counts there, starts)
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
   if (bad) {                       // the exact kernel poisons this utterance
@@ -773,7 +773,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
   const int V = p.V;
   const HfLds hl = HfLds::of<X>(V);
 
-  if (b == 0 && tid < 4) p.ctl[tid] = 0;
+  if (b == 0 && tid < 8) p.ctl[tid] = 0;
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
   if (bad) {                       // the exact kernel poisons this utterance
@@ -1859,7 +1859,7 @@ int ppl_of(int V, int Smax) {
 }
 
 struct FastLayout {
-  size_t ytab, ckA, ckQ, ckE, cumA, cumB, trkA, trkB, logz, zt2, flags, segmask, cinfo, lstart, ctl, total;
+  size_t ytab, ckA, ckQ, ckE, cumA, cumB, trkA, trkB, logz, zt2, flags, segmask, cinfo, lstart, ctl, ckXA, ckXQ, extz, total;
   int NS, NB, CELLS, MW, LS;
 };
 
@@ -1887,6 +1887,10 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
   l.cinfo = o; o += align_up((size_t)B * (l.CELLS / 2) * sizeof(unsigned), 256);
   l.lstart = o; o += align_up((size_t)B * l.LS * sizeof(int), 256);
   l.ctl = o; o += 256;
+  // the extended-range redo of the flagged-utterance launch (ctc_ext.h): one exponent per checkpoint cell, both directions
+  l.ckXA = o; o += align_up((size_t)B * l.NS * l.CELLS * sizeof(int), 256);
+  l.ckXQ = o; o += align_up((size_t)B * l.NS * l.CELLS * sizeof(int), 256);
+  l.extz = o; o += align_up((size_t)B * 2 * sizeof(double), 256);
   l.total = o;
   return l;
 }
@@ -1947,6 +1951,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   rt.ytab = p.ytab; rt.ytab_segments = a.V <= kMaxSmallV ? 1 : 0; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.cumA = p.cumA; rt.cumB = p.cumB;
   rt.NS = p.NS; rt.NB = p.NB; rt.CELLS = p.CELLS; rt.PPL = ppl_of(a.V, a.Smax); rt.logz = p.logz; rt.ctl = p.ctl;
   rt.segmask = p.segmask; rt.MW = p.MW;
+  rt.ckXA = reinterpret_cast<int*>(ws + l.ckXA); rt.ckXQ = reinterpret_cast<int*>(ws + l.ckXQ); rt.extz = reinterpret_cast<double*>(ws + l.extz);
   return launch_exact_flagged(e, p.flags, fallback_to_exact ? 1 : 2, &rt);
 }
 

@@ -579,7 +579,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(Hx<NP>::kWaves * 64) void ctc_fast
   const int V = p.V;
   const HxLds hl(V);
 
-  if (b == 0 && tid < 4) p.ctl[tid] = 0;
+  if (b == 0 && tid < 8) p.ctl[tid] = 0;
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
   if (bad) {                       // the exact kernel poisons this utterance

@@ -1,0 +1,113 @@
+"""-m gpu: the loss on emissions OTHER than unit-variance noise, at the headline's lattice size (T=1000, S<=200), against the
+oracle: what a trained model emits (peaky, consistent with the targets), mislabelled utterances in front of such a model,
+and sharp emissions that have nothing to do with the targets.  The last two defeat any lattice scaled by one power of
+two per row; they are settled inside the same call by the extended-range redo (end2end_amd/csrc/ctc_ext.h), not by the
+exact kernel's full recomputation -- asserted through the call's diagnostics."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import gpu_util as U
+from end2end_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+F32_RTOL, F32_ATOL = 1e-4, 2e-6
+
+
+def aligned(rng, B, T, V, S, boost, blank=0, short=()):
+    """unit noise + `boost` on one random monotone alignment of each utterance's own targets (bench.py aligned_batch);
+    short: (utterance, frames) pairs -- utterances that end early (their alignment lies inside their own frames)"""
+    x = rng.standard_normal((B, T, V)).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, S))
+    tl = rng.integers(max(S // 2, 1), S + 1, size=B)
+    xl = np.full(B, T)
+    for b, frames in short:
+        xl[b] = frames
+    for b in range(B):
+        n, Tb = int(tl[b]), int(xl[b])
+        slots = np.sort(rng.choice(Tb, size=n, replace=False))
+        path = np.full(Tb, blank)
+        path[slots] = tg[b, :n]
+        clash = np.nonzero((tg[b, 1:n] == tg[b, :n - 1]) & (slots[1:] == slots[:-1] + 1))[0] + 1
+        path[slots[clash]] = blank
+        x[b, np.arange(Tb), path] += boost
+    return x, tg, xl, tl
+
+
+def unsettled(keep, B, T, V, S):
+    L = _lib.load()
+    L.e2e_debug_fast_redo_failures.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    cnt = ctypes.c_int(-1)
+    assert L.e2e_debug_fast_redo_failures(keep["workspace"].data_ptr(), B, T, V, S, ctypes.byref(cnt)) == 0
+    return cnt.value
+
+
+def check(x, tg, xl, tl, want_unsettled=0, loss_atol=2e-5):
+    B, T, V = x.shape
+    S = tg.shape[1]
+    xt = torch.from_numpy(x)
+    lp = torch.log_softmax(xt.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg, xl, tl, 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0.0
+    keep = {}
+    la, ga = U.c_abi_loss(xt, tg, xl, tl, 0, False, _lib.ALGO_AUTO, keep=keep)
+    U.assert_same(la, l_o, F32_RTOL, loss_atol, "losses")
+    U.assert_same(ga, g_o, F32_RTOL, F32_ATOL, "grads")
+    if want_unsettled is not None:
+        assert unsettled(keep, B, T, V, S) == want_unsettled
+    return l_o
+
+
+@pytest.mark.parametrize("boost", [6.0, 10.0, 14.0])
+def test_trained_regime_at_the_headline_size_stays_on_the_fast_path(boost):
+    rng = np.random.default_rng(int(boost))
+    x, tg, xl, tl = aligned(rng, 6, 1000, 29, 200, boost, short=[(2, 871)])
+    lf, _ = U.c_abi_loss(torch.from_numpy(x), tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    assert not np.isnan(lf).any(), "the fast path gave up on %s" % np.nonzero(np.isnan(lf))[0].tolist()
+    check(x, tg, xl, tl)
+
+
+def test_mislabelled_utterances_are_settled_in_extended_range():
+    rng = np.random.default_rng(21)
+    x, tg, xl, tl = aligned(rng, 8, 1000, 29, 200, 10.0, short=[(5, 933)])
+    tg[1], tl[1] = tg[2].copy(), tl[2]              # utterance 1 carries utterance 2's transcript, utterance 5 utterance 6's
+    tg[5], tl[5] = tg[6].copy(), tl[6]
+    lf, _ = U.c_abi_loss(torch.from_numpy(x), tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    assert np.isnan(lf[[1, 5]]).all() and np.isnan(lf).sum() == 2, "expected exactly the mislabelled utterances to leave the f32 lattice"
+    l_o = check(x, tg, xl, tl)
+    assert l_o[1] > 20 * l_o[0]
+
+
+@pytest.mark.parametrize("shape", [(6, 1000, 29, 200, 8.0), (4, 500, 29, 100, 8.0), (3, 2000, 29, 400, 3.0), (3, 1000, 80, 200, 8.0),
+                                   (3, 700, 29, 447, 8.0), (3, 600, 150, 150, 8.0), (2, 512, 300, 200, 8.0)],
+                         ids=lambda s: "B%d_T%d_V%d_S%d_x%g" % s)
+def test_sharp_unrelated_emissions_are_settled_in_extended_range(shape):
+    B, T, V, S, scale = shape
+    rng = np.random.default_rng(B + T)
+    x = (rng.standard_normal((B, T, V)) * scale).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, S))
+    tl = rng.integers(S // 2, S + 1, size=B)
+    tl[0] = S
+    xl = np.full(B, T)
+    xl[1] = T - 21
+    check(x, tg, xl, tl)
+
+
+def test_logprob_input_with_impossible_symbols_in_extended_range():
+    """log-probabilities with -inf entries (symbols that cannot be emitted at a frame) under sharp unrelated emissions: the
+    extended-range cells treat an exact zero as such."""
+    rng = np.random.default_rng(4)
+    B, T, V, S = 4, 400, 20, 60
+    x = rng.standard_normal((B, T, V)) * 8.0
+    x[:, ::7, 3] = -np.inf
+    lp = torch.log_softmax(torch.from_numpy(x), -1)
+    tg = rng.integers(1, V, size=(B, S)); tl = rng.integers(S // 2, S + 1, size=B); xl = np.full(B, T)
+    l_o, g_o = O.ctc_loss(lp.numpy(), tg, xl, tl, 0)
+    la, ga = U.c_abi_loss(lp.float(), tg, xl, tl, 0, True, _lib.ALGO_AUTO)
+    U.assert_same(la, l_o, F32_RTOL, 2e-5, "losses")
+    U.assert_same(ga, g_o, F32_RTOL, F32_ATOL, "grads")
