@@ -12,7 +12,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libe2e_ctc.so")
+LIB_PATH = os.environ.get("E2E_CTC_LIB") or os.path.join(_HERE, "csrc", "libe2e_ctc.so")      # (E2E_CTC_LIB: tools/diag A/B builds)
 
 F32, F64, F16, BF16 = 0, 1, 2, 3
 ALGO_AUTO, ALGO_EXACT, ALGO_FAST = 0, 1, 2

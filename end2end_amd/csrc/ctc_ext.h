@@ -25,6 +25,9 @@
 //   Every workgroup of the launch takes segments; utterances are handed from the chains to the segments through flag bits.
 #pragma once
 
+#ifndef E2E_EXT_ABL                 // tools/diag: timing builds with parts of the chain waves' work switched off (results meaningless)
+#define E2E_EXT_ABL 0               //  1: probabilities loaded once, 2: no lattice arithmetic, 4: no halo exchange, 8: no checkpoint stores
+#endif
 constexpr int kXZero = -(1 << 30);            // exponent of a zero cell (below anything a row of 2^22 frames can reach)
 constexpr int kXHalo = 8, kXOwnLanes = 64 - kXHalo;
 constexpr int kExtDone = 2048;                // flag bit: the extended-range chains of the utterance are done (checkpoints, Z, loss)
@@ -43,14 +46,18 @@ __device__ __forceinline__ int x_shift_down_e(int e) { return __builtin_amdgcn_u
 // One step of a label pair, both directions (alpha: slot (blank g, label g), P = label g-1 of the row before; beta with
 // emission: slot (blank g, label g-1), P = label g of the row after -- the mirror image, see ctc_loss_fast_h1.hip):
 //   B' = (B + P) yb,   L' = (L + B + skip P) yl              ctc_loss.cpp:47-60 / 84-99
+// A result is zero exactly when its emission is zero or every term is (then the largest exponent IS kXZero): a term that is
+// not zero never underflows (the mantissas are renormalised every fourth step and lose < 2^-127 per step), nothing is
+// subtracted.  So the new exponents need only the emissions' zero tests -- known before the step -- and the exponent
+// chain (shift, max, select) runs beside the mantissa chain (shift, ldexp, add, multiply) instead of behind its compare.
 __device__ __forceinline__ void x_pair_step(double& Bm, int& Be, double& Lm, int& Le, double Pm, int Pe, double sk,
                                             double yb, double yl) {
   const int PeL = sk != 0.0 ? Pe : kXZero;
   const int eB = max(Be, Pe), eL = max(Le, max(Be, PeL));
   const double nB = (ldexp(Bm, Be - eB) + ldexp(Pm, Pe - eB)) * yb;
   const double nL = fma(sk, ldexp(Pm, PeL - eL), ldexp(Lm, Le - eL) + ldexp(Bm, Be - eL)) * yl;
-  Bm = nB; Be = x_fix(nB, eB);
-  Lm = nL; Le = x_fix(nL, eL);
+  Bm = nB; Be = yb != 0.0 ? eB : kXZero;
+  Lm = nL; Le = yl != 0.0 ? eL : kXZero;
 }
 
 struct ExtLds {
@@ -132,7 +139,7 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
   for (int si = 0; si < NSu; si++) {
     const int s = DIR == 0 ? si : NSu - 1 - si;
     const int s_next = DIR == 0 ? s + 1 : s - 1;
-    if (active && si + 1 < NSu) {                                   // the next segment's rows: asked for a segment ahead
+    if (!(E2E_EXT_ABL & 1) && active && si + 1 < NSu) {             // the next segment's rows: asked for a segment ahead
       x_load_rows(rt, b, s_next, Tmax, V, blank, nyb);
 #pragma unroll
       for (int r = 0; r < NP; r++) x_load_rows(rt, b, s_next, Tmax, V, lab[r], nyl[r]);
@@ -145,7 +152,7 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
       // halo refill: alpha before the steps t = kPeriod i > 0, beta before the steps t = kPeriod i - 1 < T - 1 -- the same
       // number of exchanges in both directions, so that every wave of the workgroup meets every barrier
       const bool exchange = DIR == 0 ? (tt % kPeriod == 0 && t > 0) : ((tt + 1) % kPeriod == 0 && t < T - 1);
-      if (exchange) {
+      if (!(E2E_EXT_ABL & 4) && exchange) {
         if (active && edge) {
 #pragma unroll
           for (int r = 0; r < NP; r++) {
@@ -154,7 +161,9 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
             *reinterpret_cast<int2*>(q + 16) = int2{Be[r], Le[r]};
           }
         }
-        __syncthreads();
+        // (a barrier that waits for LDS only: __syncthreads() would also drain the loads of the next segment's probabilities and
+        //  the checkpoint stores -- a round trip to HBM every 8 NP steps)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (has_up && halo) {
 #pragma unroll
           for (int r = 0; r < NP; r++) {
@@ -177,6 +186,9 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
           const double vb = (isB && cond) ? ybt : 0.0, vl = isL ? (double)yl[r][tt] : 0.0;
           Bm[r] = vb; Be[r] = x_fix(vb, 0); Lm[r] = vl; Le[r] = x_fix(vl, 0);
         }
+      } else if (E2E_EXT_ABL & 2) {
+#pragma unroll
+        for (int r = 0; r < NP; r++) { Bm[r] += ybt; Lm[r] += (double)yl[r][tt]; }
       } else if (DIR == 0) {
         double Pm = lane_shift_up(Lm[NP - 1]); int Pe = x_shift_up_e(Le[NP - 1]);
 #pragma unroll
@@ -194,13 +206,13 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
           Pm = om; Pe = oe;
         }
       }
-      if ((k & 3) == 3 || (DIR == 0 ? t == T - 1 : t == 0)) {
+      if ((k & 3) == 3) {                                           // (includes the checkpoint rows: tt = 15 / tt = 0)
 #pragma unroll
         for (int r = 0; r < NP; r++) { x_norm(Bm[r], Be[r]); x_norm(Lm[r], Le[r]); }
       }
       // checkpoints: alpha row t = 16 k - 1 -> slot k, beta-with-emission row t = 16 k -> slot k (0 < 16 k < T), cells in
       // lattice order (blank g = cell 2 g, label g = cell 2 g + 1); freshly normalised, the mantissa as f32
-      if (DIR == 0 ? (tt == 15 && t + 1 < T) : (tt == 0 && t > 0)) {
+      if (!(E2E_EXT_ABL & 8) && (DIR == 0 ? (tt == 15 && t + 1 < T) : (tt == 0 && t > 0))) {
         const int slot = DIR == 0 ? s + 1 : s;
         if (!halo) {
 #pragma unroll
@@ -216,7 +228,7 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
         }
       }
     }
-    if (active && si + 1 < NSu) {
+    if (!(E2E_EXT_ABL & 1) && active && si + 1 < NSu) {
 #pragma unroll
       for (int q = 0; q < 16; q++) {
         yb[q] = nyb[q];
@@ -256,7 +268,10 @@ __device__ __forceinline__ void ext_chains(const ExactParams& p, unsigned char* 
     z[tid] = (tid & 1) ? (double)kXZero : 0.0;
   }
   __syncthreads();
-  if (S + 1 <= 4 * kXOwnLanes) {
+#ifndef E2E_EXT_FORCE_NP2          // (tools/diag A/B: two pairs per lane whatever the width)
+#define E2E_EXT_FORCE_NP2 0
+#endif
+  if (!E2E_EXT_FORCE_NP2 && S + 1 <= 4 * kXOwnLanes) {
     if (dir == 0) ext_chain_wave<0, 1, LT>(p, smem, b, T, S, w, lane); else ext_chain_wave<1, 1, LT>(p, smem, b, T, S, w, lane);
   } else {
     if (dir == 0) ext_chain_wave<0, 2, LT>(p, smem, b, T, S, w, lane); else ext_chain_wave<1, 2, LT>(p, smem, b, T, S, w, lane);
@@ -360,12 +375,10 @@ __device__ __forceinline__ void ext_segment(const ExactParams& p, unsigned char*
         const double nBm = lane_shift_down(qBm), nLm = lane_shift_down(qLm);
         const int nBe = x_shift_down_e(qBe), nLe = x_shift_down_e(qLe);
         bBe = max(qBe, qLe);
-        bBm = ldexp(qBm, qBe - bBe) + ldexp(qLm, qLe - bBe);
-        bBe = x_fix(bBm, bBe);
+        bBm = ldexp(qBm, qBe - bBe) + ldexp(qLm, qLe - bBe);         // (zero exactly when both terms are: then bBe is kXZero already)
         const int nLeS = skn != 0.0 ? nLe : kXZero;
         bLe = max(qLe, max(nBe, nLeS));
         bLm = fma(skn, ldexp(nLm, nLeS - bLe), ldexp(qLm, qLe - bLe) + ldexp(nBm, nBe - bLe));
-        bLe = x_fix(bLm, bLe);
       }
       // posteriors of the lane's two cells (ordinary doubles: a posterior below 2^-1074 IS zero)
       const double pB = ldexp(aBm[tt] * bBm * Zinv, aBe[tt] + bBe - Ze);
@@ -376,8 +389,8 @@ __device__ __forceinline__ void ext_segment(const ExactParams& p, unsigned char*
       if (own && lvalid && pL != 0.0) atomicAdd(&post[tt * (V + 1) + lab], pL);
       // q of row t
       const double ybt = (double)yb[tt], ylt = lvalid ? (double)yl[tt] : 0.0;
-      qBm = bBm * ybt; qBe = x_fix(qBm, bBe);
-      qLm = bLm * ylt; qLe = x_fix(qLm, bLe);
+      qBm = bBm * ybt; qBe = ybt != 0.0 ? bBe : kXZero;
+      qLm = bLm * ylt; qLe = ylt != 0.0 ? bLe : kXZero;
       if ((tt & 3) == 0) { x_norm(qBm, qBe); x_norm(qLm, qLe); }
     }
   }

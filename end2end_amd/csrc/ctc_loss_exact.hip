@@ -876,10 +876,19 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
     if (blockIdx.x == 0) write_reduction(false);
     return;
   }
+  // (diagnostics, flagged calls only: workgroup 0 leaves the 100 MHz clock at the end of every phase in ctl[16 ..], two ints each)
+  auto stamp = [&](int k) {
+    if (blockIdx.x == 0 && tid == 0) {
+      const unsigned long long t = wall_clock64();
+      p.ctl[16 + 2 * k] = (int)(unsigned)t; p.ctl[17 + 2 * k] = (int)(unsigned)(t >> 32);
+    }
+  };
+  stamp(0);
   auto flag_of = [&](int b) -> int { return b < kFlagCache ? (int)s_flag[b] : (p.flags[b] & (kRedoFailed - 1)); };
   auto range_only = [&](int f) -> bool { return p.mode == 1 && p.has_retry && f != 0 && (f & ~(8 | 16)) == 0; };
-  // flagged for its numbers, not for its inputs (1: lengths, 2: blank inside the targets, 64: probabilities at the end of f32, 128: protocol)
-  auto ext_candidate = [&](int f) -> bool { return p.mode == 1 && p.has_ext && (f & (4 | 32)) != 0 && (f & (1 | 2 | 64 | 128)) == 0; };
+  // flagged for its numbers, not for its inputs (1: lengths, 2: blank inside the targets, 128: protocol, 256: probabilities the f32
+  // table cannot hold; 64 alone -- probabilities below 2^-100 but still normal f32 numbers -- is a matter of range)
+  auto ext_candidate = [&](int f) -> bool { return p.mode == 1 && p.has_ext && (f & (4 | 32 | 64)) != 0 && (f & (1 | 2 | 128 | 256)) == 0; };
 
   if (p.mode == 2) {
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
@@ -887,11 +896,72 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
       __syncthreads();
     }
   } else {
-    // ---- 1. segments of the utterances flagged for range only: item i of the running list goes to wave i mod NW ----
-    const int NW = (int)gridDim.x * p.redo_waves, me = (int)blockIdx.x * p.redo_waves + wid;
+    // ---- X. extended-range redo (ctc_ext.h) of what is flagged for its NUMBERS.  Round 0, known from the start: alpha / beta
+    //      log Z mismatch (32), a partition sum out of range (4), probabilities below 2^-100 (64).  Round 1, known once every
+    //      workgroup has reported the end of step 1: what the f64 redo of single segments could not settle (512).
+    //      Chains: utterance i of a round's list on workgroup i mod grid; then every workgroup takes segments. ----
+    __shared__ int s_dec, s_next, s_go;
+    __shared__ int s_xb[kExtMaxList];                   // a round's list: utterance numbers ...
+    __shared__ int s_xoff[kExtMaxList + 1];             // ... and the running count of their segments
+    // the list of a round, in utterance order, the same in every workgroup (s_flag holds what the round looks at)
+    auto build_list = [&](int round) {
+      if (wid == 0) {
+        int nx = 0, off = 0;
+        for (int c0 = 0; c0 < p.B && nx < kExtMaxList; c0 += 64) {
+          const int bb = c0 + lane;
+          int f = 0;
+          if (bb < p.B) f = bb < kFlagCache ? (int)s_flag[bb] : (__hip_atomic_load(&p.flags[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (2 * kRedoFailed - 1));
+          const bool take = bb < p.B && (round == 0 ? ext_candidate(f) : ((f & kRedoFailed) != 0 && range_only(f & (kRedoFailed - 1))));
+          const int nseg = take ? ((int)p.x_len[bb] + kFastSeg - 1) / kFastSeg : 0;
+          const unsigned long long m = __ballot(take);
+          const int before = __builtin_popcountll(m & ((1ull << lane) - 1));
+          const int incl = wave_incl_scan(nseg, lane);
+          const int cnt = __builtin_popcountll(m);
+          if (nx + cnt > kExtMaxList) break;              // (a list that overflows is cut at a chunk boundary: the rest is left to step 3)
+          if (take) { s_xb[nx + before] = bb; s_xoff[nx + before] = off + incl - nseg; }
+          nx += cnt; off += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (lane == 0) { s_next = nx; s_xoff[nx] = off; }
+      }
+      __syncthreads();
+    };
+    auto ext_segments_of_list = [&](int nx) {
+      // item j of the running list on workgroup j mod grid, once its utterance's chains are done
+      const int nitems = s_xoff[nx];
+      for (int j = blockIdx.x; j < nitems; j += gridDim.x) {
+        int lo = 0, hi = nx - 1;                                    // the utterance of item j: last i with s_xoff[i] <= j
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_xoff[mid] <= j) lo = mid; else hi = mid - 1; }
+        const int ub = s_xb[lo], seg = j - s_xoff[lo];
+        if (tid == 0) {
+          int f, spins = 0;
+          while (((f = __hip_atomic_load(&p.flags[ub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kExtDone) == 0 && ++spins < (1 << 16))
+            __builtin_amdgcn_s_sleep(8);
+          if ((f & kExtDone) == 0) { atomicOr(&p.flags[ub], kExtBad); atomicAdd(&p.ctl[4], 1); f |= kExtBad; }
+          s_go = (f & kExtBad) == 0;
+        }
+        __syncthreads();
+        if (s_go) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          ext_segment<IO>(p, smem, ub, seg);
+        }
+        __syncthreads();
+      }
+    };
+    int nx0 = 0;
+    if (p.has_ext) {
+      build_list(0);
+      nx0 = s_next;
+      for (int i = blockIdx.x; i < nx0; i += gridDim.x) ext_chains<IO>(p, smem, s_xb[i]);
+    }
+    stamp(1);
+    // ---- 1. segments of the utterances flagged for range only: item i of the running list goes to wave i mod NW.  (The
+    //      workgroups that run round 0's chains take none, unless that is all of them: a chain is ~0.1 ms, a segment ~50 us.) ----
+    const int chain_wgs = nx0 < (int)gridDim.x ? nx0 : 0;
+    const int NW = ((int)gridDim.x - chain_wgs) * p.redo_waves;
+    const int me = (int)blockIdx.x >= chain_wgs ? ((int)blockIdx.x - chain_wgs) * p.redo_waves + wid : -1;
     unsigned char* wsmem = smem + (size_t)wid * retry_wave_lds_bytes(p.V, p.retry.PPL);
     int base = 0;
-    for (int c0 = 0; c0 < p.B && wid < p.redo_waves; c0 += 64) {
+    for (int c0 = 0; c0 < p.B && wid < p.redo_waves && me >= 0; c0 += 64) {
       const int bb = c0 + lane;
       const int f = bb < p.B ? flag_of(bb) : 0;
       // (only the segments that failed in the segment kernel: the others' rows passed their self-check and stay)
@@ -930,27 +1000,23 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
             else if (p.retry.PPL == 1) ok = retry_segment_f64<IO, 1>(p, wsmem, ub, seg, lane);
             else if (p.retry.PPL == 2) ok = retry_segment_f64<IO, 2>(p, wsmem, ub, seg, lane);
             else ok = retry_segment_f64<IO, 4>(p, wsmem, ub, seg, lane);
-            if (!ok && lane == 0) atomicOr(&p.flags[ub], kRedoFailed);
+            if (!ok && lane == 0) { atomicOr(&p.flags[ub], kRedoFailed); atomicAdd(&p.ctl[5], 1); }
           }
         }
       }
       base += tot;
     }
     __syncthreads();                         // (the waves' LDS is taken over by what follows)
-    // ---- X. extended-range redo (ctc_ext.h) of what is flagged for its NUMBERS: alpha / beta log Z mismatch (32), a partition
-    //      sum out of range (4), and -- once every workgroup has reported the end of its redos -- what step 1 could not
-    //      settle (512).  Chains: utterance i of the list on workgroup i mod grid; then every workgroup takes segments. ----
-    __shared__ int s_dec, s_next, s_go;
-    __shared__ int s_xb[kExtMaxList];                   // the list: utterance numbers ...
-    __shared__ int s_xoff[kExtMaxList + 1];             // ... and the running count of their segments
+    stamp(2);
     if (p.has_ext) {
-      // (a) have all workgroups finished step 1?  Bounded wait (a grid that is not resident at once -- a partitioned or shared
-      //     GPU -- must not hang): all workgroups adopt ONE decision, 1 = everybody arrived, 2 = some wait ran out (then what
-      //     step 1 could not settle is left to step 3).  No wait at all when step 1 had nothing to do.
+      if (nx0 > 0) ext_segments_of_list(nx0);
+      stamp(3);
+      // Round 1.  Have all workgroups finished step 1?  Bounded wait (a grid that is not resident at once -- a partitioned or
+      // shared GPU -- must not hang): all workgroups adopt ONE decision, 1 = everybody arrived, 2 = some wait ran out (then
+      // what step 1 could not settle is left to step 3).  No wait at all when step 1 had nothing to do.
       bool any_range = false;
       for (int b = tid; b < p.B; b += kThreads) any_range |= range_only(flag_of(b));
-      const int have_range = __syncthreads_or(any_range ? 1 : 0);
-      if (have_range) {
+      if (__syncthreads_or(any_range ? 1 : 0)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (tid == 0) {
@@ -963,62 +1029,25 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
           const int was = atomicCAS(&p.ctl[3], 0, mine);
           s_dec = was != 0 ? was : mine;
           if (was == 0 && mine == 2) atomicAdd(&p.ctl[4], 1);       // (diagnostics: a wait ran out)
+          // (has any redo failed at all?  ctl[5] counts them: the usual answer is no, and the list need not be built)
+          if (s_dec == 1 && __hip_atomic_load(&p.ctl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) s_dec = 3;
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      } else {
-        if (tid == 0) s_dec = 1;
-        __syncthreads();
-      }
-      const bool see_failed = s_dec == 1 && have_range;
-      // (b) the list, in utterance order, the same in every workgroup
-      if (wid == 0) {
-        int nx = 0, off = 0;
-        for (int c0 = 0; c0 < p.B && nx < kExtMaxList; c0 += 64) {
-          const int bb = c0 + lane;
-          int f = 0;
-          if (bb < p.B) {
-            f = flag_of(bb);
-            if (see_failed && range_only(f) &&
-                (__hip_atomic_load(&p.flags[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kRedoFailed)) f |= kRedoFailed;
-          }
-          const bool take = bb < p.B && (ext_candidate(f) || (f & kRedoFailed) != 0);
-          const int nseg = take ? ((int)p.x_len[bb] + kFastSeg - 1) / kFastSeg : 0;
-          const unsigned long long m = __ballot(take);
-          const int before = __builtin_popcountll(m & ((1ull << lane) - 1));
-          const int incl = wave_incl_scan(nseg, lane);
-          if (take && nx + before < kExtMaxList) { s_xb[nx + before] = bb; s_xoff[nx + before] = off + incl - nseg; }
-          const int cnt = __builtin_popcountll(m);
-          // (a list that overflows is cut at a chunk boundary: the rest is left to step 3)
-          if (nx + cnt > kExtMaxList) break;
-          nx += cnt; off += __builtin_amdgcn_readlane(incl, 63);
-        }
-        if (lane == 0) { s_next = nx; s_xoff[nx] = off; }
-      }
-      __syncthreads();
-      const int nx = s_next, nitems = s_xoff[nx];
-      // (c) chains
-      for (int i = blockIdx.x; i < nx; i += gridDim.x) ext_chains<IO>(p, smem, s_xb[i]);
-      // (d) segments: item j of the running list on workgroup j mod grid, once its utterance's chains are done
-      for (int j = blockIdx.x; j < nitems; j += gridDim.x) {
-        int lo = 0, hi = nx - 1;                                    // the utterance of item j: last i with s_xoff[i] <= j
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_xoff[mid] <= j) lo = mid; else hi = mid - 1; }
-        const int ub = s_xb[lo], seg = j - s_xoff[lo];
-        if (tid == 0) {
-          int f, spins = 0;
-          while (((f = __hip_atomic_load(&p.flags[ub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kExtDone) == 0 && ++spins < (1 << 16))
-            __builtin_amdgcn_s_sleep(8);
-          if ((f & kExtDone) == 0) { atomicOr(&p.flags[ub], kExtBad); atomicAdd(&p.ctl[4], 1); f |= kExtBad; }
-          s_go = (f & kExtBad) == 0;
-        }
-        __syncthreads();
-        if (s_go) {
+        if (s_dec == 1) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          ext_segment<IO>(p, smem, ub, seg);
+          for (int b = tid; b < p.B && b < kFlagCache; b += kThreads)     // the flag words as they are now, in one round trip
+            s_flag[b] = (unsigned short)(__hip_atomic_load(&p.flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (2 * kRedoFailed - 1));
+          __syncthreads();
+          build_list(1);
+          const int nx1 = s_next;
+          for (int i = blockIdx.x; i < nx1; i += gridDim.x) ext_chains<IO>(p, smem, s_xb[i]);
+          if (nx1 > 0) ext_segments_of_list(nx1);
+          for (int b = tid; b < p.B && b < kFlagCache; b += kThreads) s_flag[b] &= (unsigned short)(kRedoFailed - 1);
+          __syncthreads();
         }
-        __syncthreads();
       }
     }
+    stamp(4);
     // ---- 2. what is flagged for its INPUTS (bad lengths, a blank inside the targets, probabilities at the end of f32, a
     //      protocol error): the reference's arithmetic, utterance h on workgroup h mod nslabs ----
     int h = 0;
@@ -1063,6 +1092,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
     __syncthreads();
   }
   write_reduction(true);
+  if (tid == 0) { const unsigned long long t = wall_clock64(); p.ctl[28] = (int)(unsigned)t; p.ctl[29] = (int)(unsigned)(t >> 32); }
 }
 
 size_t exact_lds_bytes(int V, int Smax) {

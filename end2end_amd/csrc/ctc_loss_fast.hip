@@ -255,7 +255,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(512) void ctc_fast_chain_kernel(Fa
   const int V = p.V;
   const F1Lds lds(smem, V);
 
-  if (b == 0 && tid < 8) p.ctl[tid] = 0;     // (this kernel ends before the fallback launch, which counts there, starts)
+  if (b == 0 && tid < 32) p.ctl[tid] = 0;     // (this kernel ends before the fallback launch, which counts there, starts)
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
   if (bad) {                       // the exact kernel poisons this utterance
@@ -773,7 +773,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
   const int V = p.V;
   const HfLds hl = HfLds::of<X>(V);
 
-  if (b == 0 && tid < 8) p.ctl[tid] = 0;
+  if (b == 0 && tid < 32) p.ctl[tid] = 0;
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
   if (bad) {                       // the exact kernel poisons this utterance
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(256) void ctc_fast_prob_kernel(FastParams p) {
     float y[NK];
     if (p.logprobs) {
 #pragma unroll
-      for (int k = 0; k < NK; k++) y[k] = (x[r][k] > ninf && x[r][k] < -69.f) ? kTinyProb : exp_le0(x[r][k]);
+      for (int k = 0; k < NK; k++) y[k] = (x[r][k] > ninf && x[r][k] < -78.f) ? kTinyProb : exp_le0(x[r][k]);
     } else {
       float m = x[r][0];
 #pragma unroll
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void ctc_fast_prob_kernel(FastParams p) {
       float inv = __builtin_amdgcn_rcpf(ssum);
       inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);        // one Newton step: ~0.5 ulp
 #pragma unroll
-      for (int k = 0; k < NK; k++) y[k] = (x[r][k] > ninf && x[r][k] - m < -69.f) ? kTinyProb : y[k] * inv;
+      for (int k = 0; k < NK; k++) y[k] = (x[r][k] > ninf && x[r][k] - m < -78.f) ? kTinyProb : y[k] * inv;
     }
     float* yrow = p.ytab + (size_t)(row0 + r) * V;
 #pragma unroll
@@ -1993,6 +1993,20 @@ extern "C" int e2e_debug_fast_redo_failures(const void* workspace, int B, int T,
   int ctl[4];
   if (hipMemcpy(ctl, ws + l.ctl, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) return E2E_ERR_HIP;
   *count_host = ctl[1];
+  return E2E_OK;
+}
+// Diagnostics: the flagged-utterance launch's phases as workgroup 0 saw them, in microseconds since its start: end of its
+// extended-range chains (round 0), of its f64 redos of single segments, of its extended-range segments (round 0), of the wait for
+// the other workgroups and round 1, and the end of the launch's last workgroup.  Zeros if nothing was flagged.  Synchronises.
+extern "C" int e2e_debug_flagged_phases(const void* workspace, int B, int T, int V, int Smax, double* us_host) {
+  uintptr_t base = reinterpret_cast<uintptr_t>(workspace);
+  const char* ws = reinterpret_cast<const char*>((base + 255) & ~(uintptr_t)255);
+  const e2e::FastLayout l = e2e::fast_layout(B, T, V, Smax);
+  if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
+  unsigned long long st[8];
+  if (hipMemcpy(st, ws + l.ctl + 64, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return E2E_ERR_HIP;
+  for (int k = 1; k <= 4; k++) us_host[k - 1] = st[0] && st[k] ? (double)(long long)(st[k] - st[0]) * 0.01 : 0.0;
+  us_host[4] = st[0] && st[6] ? (double)(long long)(st[6] - st[0]) * 0.01 : 0.0;
   return E2E_OK;
 }
 extern "C" int e2e_debug_fast_state(const void* workspace, int B, int T, int V, int Smax, int* flags_host, double* logz_host) {

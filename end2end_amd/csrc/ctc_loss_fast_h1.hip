@@ -518,7 +518,7 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
   };
   if (p.xdt == E2E_F32) run(std::true_type{}); else run(std::false_type{});
   // (see prep_wave: emissions near the end of f32 -> the utterance is recomputed entirely by the exact kernel)
-  if (DIR == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], 64); }       // e^-69 = 2^-100
+  if (DIR == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], __any(lpmin < -78.f) ? 64 | 256 : 64); }       // e^-69 = 2^-100
 }
 
 // The checkpoint wave of a direction: reads a checkpoint row's true cells in lattice order (pair i: cells 2i, 2i+1), finds the
@@ -579,7 +579,7 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(Hx<NP>::kWaves * 64) void ctc_fast
   const int V = p.V;
   const HxLds hl(V);
 
-  if (b == 0 && tid < 8) p.ctl[tid] = 0;
+  if (b == 0 && tid < 32) p.ctl[tid] = 0;
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   const bool bad = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
   if (bad) {                       // the exact kernel poisons this utterance

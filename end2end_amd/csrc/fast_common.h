@@ -538,7 +538,9 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
   // Probabilities are f32: below ~2^-126 they are flushed, and a chain that ran through such frames carries a loss that
   // is off by the flushed amount (a symbol with log-probability -inf is exactly impossible and does not count).  Reason bit 64 ("emissions near the end of f32"): such an utterance is recomputed
   // entirely by the exact kernel, never by the f64 redo of the segments alone, which would keep the chains' loss.
-  if (dir == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], 64); }       // e^-69 = 2^-100
+  // (bit 256 on top: a finite log-probability below -78 -- within a few bits of where an f32 probability stops being a normal
+  //  number -- , which the extended-range redo cannot take from the table either: the exact kernel's own softmax)
+  if (dir == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], __any(lpmin < -78.f) ? 64 | 256 : 64); }       // e^-69 = 2^-100
 #ifdef E2E_FAST_PROFILE
   if (lane == 0 && b < 256 && first == 0) { g_prof[(b * 4 + 2 + dir) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + 2 + dir) * 4 + 1] = prof_spin; }
 #endif
@@ -561,7 +563,8 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 // (alpha side, beta side) and the producers, not the chains, set the kernel's speed (510 cycles per step against 150).  The
 // probabilities are therefore computed ONCE, by the whole chip, in a launch of their own (ctc_fast_prob_kernel, which fills
 // ytab); a producer only moves a block's rows from ytab into the ring, transposed.
-constexpr float kTinyProb = 1e-35f;       // ytab marker: a FINITE log-probability below -69 (e^-69 = 1.08e-30 = 2^-100)
+constexpr float kTinyProb = 1e-37f;       // ytab marker: a FINITE log-probability below -78 (e^-78 / 448 = 3e-37; the table keeps the true
+                                          // probability down to there: what lies below 1e-30 = e^-69 raises reason bit 64, the marker 256 as well)
 template <int NV, int RING, int SETS = 2>
 __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T, int dir, int first, int stride,
                                               unsigned char* myring_bytes, int blk_bytes, volatile int* myfilled, int lane,
@@ -580,7 +583,7 @@ __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T,
     for (int k = 0; k < NV; k++) out[k] = yr[l8 + 8 * k < V ? 8 * k : 0];
   };
   int consumed = 0;
-  bool tiny = false;
+  bool tiny = false, tiny2 = false;
   auto process = [&](int n, const float (&yraw)[NV]) {
     if (n >= nblk) return;
     const int t = block_time(dir, n, tt, T);
@@ -593,7 +596,7 @@ __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T,
       const int v = l8 + 8 * k;
       if (v < V) {
         const float y = row_live ? yraw[k] : 0.f;
-        tiny |= y > 0.f && y < 1e-30f;
+        tiny |= y > 0.f && y < 1e-30f; tiny2 |= y > 0.f && y < 2e-37f;
         blk32[v * kRow32 + tt] = y;                                        // transposed: [label][step]
       }
     }
@@ -619,7 +622,7 @@ __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T,
   }
   // Probabilities are f32: below ~2^-126 they are flushed (see prep_wave: reason bit 64, the exact kernel recomputes the
   // utterance); the launch that filled ytab left kTinyProb wherever a finite log-probability lay below -69
-  if (dir == 0 && __any(tiny)) { if (lane == 0) atomicOr(&p.flags[b], 64); }
+  if (dir == 0 && __any(tiny)) { if (lane == 0) atomicOr(&p.flags[b], __any(tiny2) ? 64 | 256 : 64); }
 }
 
 // Per-utterance lattice description for F2, computed once here instead of once per 16-step segment there (63x at

@@ -181,12 +181,13 @@ def test_bench_helpers(tmp_path, monkeypatch):
     assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
 
 
-def test_workspace_of_the_headline_shape_stays_under_200_megabytes():
-    # 924 MB (256 alpha slabs of the flagged-utterance launch) -> the fast path's own 100 MB + 24 slabs
+def test_workspace_of_the_headline_shape_stays_under_250_megabytes():
+    # 924 MB (256 alpha slabs of the flagged-utterance launch) -> the fast path's own 100 MB + 24 slabs;
+    # round 5: + 66 MB, one int exponent per checkpoint cell for the extended-range redo (ctc_ext.h)
     from end2end_amd import _lib
     L = _lib.load()
     n = L.e2e_ctc_loss_workspace_bytes(256, 1000, 29, 200, _lib.F32, _lib.ALGO_AUTO)
-    assert 50e6 < n <= 200e6, n
+    assert 50e6 < n <= 250e6, n
     # and it no longer grows with the batch beyond the fast path's own share
     n4 = L.e2e_ctc_loss_workspace_bytes(1024, 1000, 29, 200, _lib.F32, _lib.ALGO_AUTO)
     assert n4 - n < 3.2 * (n - 77e6), (n, n4)
