@@ -24,6 +24,7 @@
 //     posteriors alpha beta / Z are ordinary doubles in [0, 1] (THEIR underflow is exact) and are summed per label in LDS.
 //   Every workgroup of the launch takes segments; utterances are handed from the chains to the segments through flag bits.
 #pragma once
+#include <type_traits>
 
 #ifndef E2E_EXT_ABL                 // tools/diag: timing builds with parts of the chain waves' work switched off (results meaningless)
 #define E2E_EXT_ABL 0               //  1: probabilities loaded once, 2: no lattice arithmetic, 4: no halo exchange, 8: no checkpoint stores
@@ -65,10 +66,12 @@ struct ExtLds {
   static constexpr int kRec = 32;                                   // an edge record: Bm, Lm (doubles), Be, Le (ints), padding
   static constexpr int edge = 0;                                    // [2 dirs][4 waves][2 buffers][8 lanes][2 slots] records
   static constexpr int zrec = edge + 2 * 4 * 2 * kXHalo * 2 * kRec; // [2 dirs][2] (m, e as double): the cells of Z
-  static constexpr int chain_total = zrec + 64;
+  static constexpr int tiles = zrec + 64;                           // [2 dirs][2 buffers] probability tiles of tile_bytes(V)
+  __host__ __device__ static size_t tile_bytes(int V) { return ((size_t)V * 8 * sizeof(float) + 15) & ~(size_t)15; }
+  __host__ __device__ static size_t chain_bytes(int V) { return tiles + 4 * tile_bytes(V); }
   // segments: post[16][V + 1] doubles
   __host__ __device__ static size_t seg_bytes(int V) { return sizeof(double) * 16 * ((size_t)V + 1); }
-  __host__ __device__ static size_t bytes(int V) { return seg_bytes(V) > (size_t)chain_total ? seg_bytes(V) : (size_t)chain_total; }
+  __host__ __device__ static size_t bytes(int V) { return seg_bytes(V) > chain_bytes(V) ? seg_bytes(V) : chain_bytes(V); }
 };
 
 // probabilities of one 16-step segment for a lane's labels: y[tt] of label `lab` (clamped by the caller) out of ytab
@@ -87,14 +90,70 @@ __device__ __forceinline__ void x_load_rows(const FastRetry& rt, int b, int seg,
 
 // ---- the chains ------------------------------------------------------------------------------------------------------
 // All 8 waves of the workgroup call this (wave = 2 w + DIR); waves that hold no cell only keep the barriers.
+// global-memory accesses spelled as such: inside this (very large) kernel the compiler no longer proves that the pointers of the
+// parameter block are global ones, and a FLAT load counts on lgkmcnt as well -- every wait for LDS then waits for HBM too
+typedef __attribute__((address_space(1))) const float g_cfloat;
+typedef float x_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const x_f4 g_cfloat4;
+typedef __attribute__((address_space(1))) float g_float;
+typedef __attribute__((address_space(1))) int g_int;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) x_f4 lds_f32x4;
+
+// Probability tiles: the 8 steps t = 8 m .. 8 m + 7 of every column, [column][8 steps] floats, staged in LDS by the four waves of
+// a direction together (256 threads, coalesced out of the fast path's table) one tile ahead of its use, double-buffered.  A
+// lane reads its labels' rows of a tile with two 16-byte LDS reads each.  (First form: every lane loaded its own labels' rows
+// of the next 16 steps into registers -- the compiler's waits for those loads, and with them for the checkpoint stores, sat in
+// front of every segment: 327 us per 1000 frames of which 92 were arithmetic.)
+constexpr int kXTile = 8;
+constexpr int kXTileLoads = 14;                                     // elements a thread fetches per tile at most (448 columns x 8 / 256)
+template <int DIR>
+struct XTileFetch {
+  x_f4 q;                        // segment-major table (<= 96 columns): one 16-byte piece
+  float e[kXTileLoads];          // row-major table: elements idx = d_tid + 256 i of the tile's [8][V]
+  // ask for tile m of utterance b (clamped to the utterance's tiles by the caller)
+  __device__ __forceinline__ void load(const FastRetry& rt, int b, int m, int Tmax, int V, int d_tid) {
+    if (rt.ytab_segments) {
+      // [b][seg][V][16]: tile m = half (m & 1) of segment m >> 1; piece j of the tile: column j >> 1, steps 4 (j & 1) .. + 3
+      const int j = d_tid < 2 * V ? d_tid : 0;
+      g_cfloat4* src = (g_cfloat4*)(rt.ytab + (((size_t)b * rt.NS + (m >> 1)) * V + (j >> 1)) * kFastSeg + 8 * (m & 1) + 4 * (j & 1));
+      q = *src;
+    } else {
+      g_cfloat* src = (g_cfloat*)(rt.ytab + ((size_t)b * Tmax + (size_t)m * kXTile) * V);
+      const int cnt = min(kXTile, Tmax - m * kXTile) * V;           // (rows of the table that exist)
+#pragma unroll
+      for (int i = 0; i < kXTileLoads; i++) { const int idx = d_tid + 256 * i; e[i] = src[idx < cnt ? idx : 0]; }
+    }
+  }
+  // ... and leave it in the LDS buffer `dst` ([V][8] floats)
+  __device__ __forceinline__ void store(const FastRetry& rt, unsigned char* dst, int V, int d_tid) const {
+    if (rt.ytab_segments) {
+      if (d_tid < 2 * V) *(lds_f32x4*)(dst + 16 * d_tid) = q;
+    } else {
+      const float rV = 1.0f / (float)V;
+#pragma unroll
+      for (int i = 0; i < kXTileLoads; i++) {
+        const int idx = d_tid + 256 * i;
+        // (idx / V by a float product: idx + 0.5 is never within 0.5 / V of a multiple of V, f32 rounding is 1e-6 of that)
+        if (idx < kXTile * V) { const int tt = (int)(((float)idx + 0.5f) * rV), v = idx - tt * V; *(lds_f32*)(dst + (v * kXTile + tt) * 4) = e[i]; }
+      }
+    }
+  }
+};
+
+// ---- the chains ------------------------------------------------------------------------------------------------------
+// All 8 waves of the workgroup call this (wave = 2 w + DIR); waves that hold no cell keep the barriers and stage tiles.
+// Tiles and exchanges: the 8-step tiles t = 8 m .. 8 m + 7 are walked m = 0 .. M by alpha and M .. 0 by beta (M = (T-1) / 8); at
+// every tile boundary the waves publish their edge lanes, meet at a barrier (waiting for LDS only), refill their halo (which
+// lasts 8 NP steps: at NP = 2 it is refreshed twice as often as it must be), stage the next tile, ask for the one after.
 template <int DIR, int NP, typename LT>
 __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned char* smem, int b, int T, int S, int w, int lane) {
-  constexpr int kOwn = NP * kXOwnLanes, kPeriod = 8 * NP;           // pairs a wave owns; steps a halo lasts
+  constexpr int kOwn = NP * kXOwnLanes;                             // pairs a wave owns
   const FastRetry& rt = p.retry;
   const int V = p.V, blank = p.blank, L = 2 * S + 1, Tmax = p.T;
-  const int NSu = (T + kFastSeg - 1) / kFastSeg;
+  const int M = (T - 1) >> 3;
   const int W = (S + kOwn) / kOwn;                                  // waves that hold a cell: pairs 0 .. S
-  const bool active = w < W;
+  const bool active = __builtin_amdgcn_readfirstlane(w < W ? 1 : 0) != 0;
   const bool cond = (T > 1 || L == 1);                              // ctc_loss.cpp:39,76
   const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
   // slot r of the lane: pair g = g0 + r; alpha holds (blank g, label g), beta (blank g, label g - 1)
@@ -124,60 +183,94 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
   const int upw = DIR == 0 ? w - 1 : w + 1;
   const bool has_up = active && (DIR == 0 ? w > 0 : w + 1 < W);
   unsigned char* rec_up = smem + ExtLds::edge + (size_t)((DIR * 4 + (has_up ? upw : 0)) * 2) * kXHalo * 2 * ExtLds::kRec;
-  int nex = 0;                                                      // exchanges so far (buffer = nex & 1)
+  unsigned char* tiles = smem + ExtLds::tiles + (size_t)DIR * 2 * ExtLds::tile_bytes(V);      // this direction's two buffers
+  const int tile_b = (int)ExtLds::tile_bytes(V);
+  const int d_tid = w * 64 + lane;
+  g_float* ckm = (g_float*)(const_cast<float*>(DIR == 0 ? rt.ckA : rt.ckQ) + (size_t)b * rt.NS * rt.CELLS);
+  g_int* cke = (g_int*)((DIR == 0 ? rt.ckXA : rt.ckXQ) + (size_t)b * rt.NS * rt.CELLS);
+  auto tile_of = [&](int q) { const int m = DIR == 0 ? q : M - q; return min(max(m, 0), M); };   // (clamped: past the end, the last one again)
 
-  float yb[16], yl[NP][16], nyb[16], nyl[NP][16];
-  const int s_first = DIR == 0 ? 0 : NSu - 1;
-  if (active) {
-    x_load_rows(rt, b, s_first, Tmax, V, blank, yb);
-#pragma unroll
-    for (int r = 0; r < NP; r++) x_load_rows(rt, b, s_first, Tmax, V, lab[r], yl[r]);
-  }
-  float* ckm = const_cast<float*>(DIR == 0 ? rt.ckA : rt.ckQ) + (size_t)b * rt.NS * rt.CELLS;
-  int* cke = (DIR == 0 ? rt.ckXA : rt.ckXQ) + (size_t)b * rt.NS * rt.CELLS;
+  // tile 0 of the walk into buffer 0
+  XTileFetch<DIR> fetch;
+  fetch.load(rt, b, tile_of(0), Tmax, V, d_tid);
+  fetch.store(rt, tiles, V, d_tid);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-  for (int si = 0; si < NSu; si++) {
-    const int s = DIR == 0 ? si : NSu - 1 - si;
-    const int s_next = DIR == 0 ? s + 1 : s - 1;
-    if (!(E2E_EXT_ABL & 1) && active && si + 1 < NSu) {             // the next segment's rows: asked for a segment ahead
-      x_load_rows(rt, b, s_next, Tmax, V, blank, nyb);
-#pragma unroll
-      for (int r = 0; r < NP; r++) x_load_rows(rt, b, s_next, Tmax, V, lab[r], nyl[r]);
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int tt = DIR == 0 ? k : 15 - k;
-      const int t = s * kFastSeg + tt;
-      if (t >= T) continue;                                         // (uniform: the utterance's last segment may be short)
-      // halo refill: alpha before the steps t = kPeriod i > 0, beta before the steps t = kPeriod i - 1 < T - 1 -- the same
-      // number of exchanges in both directions, so that every wave of the workgroup meets every barrier
-      const bool exchange = DIR == 0 ? (tt % kPeriod == 0 && t > 0) : ((tt + 1) % kPeriod == 0 && t < T - 1);
-      if (!(E2E_EXT_ABL & 4) && exchange) {
+  // STEADY: a tile strictly inside the walk -- all 8 rows live, none of them the chain's first
+  auto do_tile = [&](int q, auto steady_tag) {
+    constexpr bool STEADY = decltype(steady_tag)::value;
+    const int m = DIR == 0 ? q : M - q;
+    if (q > 0) {
+      // ---- the boundary: edge lanes out, barrier, halo in ----
+      if (!(E2E_EXT_ABL & 4)) {
         if (active && edge) {
 #pragma unroll
           for (int r = 0; r < NP; r++) {
-            unsigned char* q = rec_mine + (size_t)(((nex & 1) * kXHalo + (lane & (kXHalo - 1))) * 2 + r) * ExtLds::kRec;
-            *reinterpret_cast<double2*>(q) = double2{Bm[r], Lm[r]};
-            *reinterpret_cast<int2*>(q + 16) = int2{Be[r], Le[r]};
+            unsigned char* a = rec_mine + (size_t)(((q & 1) * kXHalo + (lane & (kXHalo - 1))) * 2 + r) * ExtLds::kRec;
+            *reinterpret_cast<double2*>(a) = double2{Bm[r], Lm[r]};
+            *reinterpret_cast<int2*>(a + 16) = int2{Be[r], Le[r]};
           }
         }
-        // (a barrier that waits for LDS only: __syncthreads() would also drain the loads of the next segment's probabilities and
-        //  the checkpoint stores -- a round trip to HBM every 8 NP steps)
+        // (a barrier that waits for LDS only: __syncthreads() would also drain the tile loads and the checkpoint stores)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (has_up && halo) {
 #pragma unroll
           for (int r = 0; r < NP; r++) {
-            const unsigned char* q = rec_up + (size_t)(((nex & 1) * kXHalo + (lane & (kXHalo - 1))) * 2 + r) * ExtLds::kRec;
-            const double2 v = *reinterpret_cast<const double2*>(q);
-            const int2 e = *reinterpret_cast<const int2*>(q + 16);
+            const unsigned char* a = rec_up + (size_t)(((q & 1) * kXHalo + (lane & (kXHalo - 1))) * 2 + r) * ExtLds::kRec;
+            const double2 v = *reinterpret_cast<const double2*>(a);
+            const int2 e = *reinterpret_cast<const int2*>(a + 16);
             Bm[r] = v.x; Lm[r] = v.y; Be[r] = e.x; Le[r] = e.y;
           }
         }
-        nex++;
       }
-      if (!active) continue;
+    }
+    // ---- the tile after this one is asked for now and staged at this tile's end (into the other buffer: its readers left it
+    //      before the barrier above): one tile -- 8 steps, ~2 us -- hides the round trip, and no loaded register lives across
+    //      the loop's back edge (where the compiler waits for everything outstanding) ----
+    if (!(E2E_EXT_ABL & 1)) fetch.load(rt, b, tile_of(q + 1), Tmax, V, d_tid);
+    if (!active) { if (!(E2E_EXT_ABL & 1)) fetch.store(rt, tiles + ((q + 1) & 1) * tile_b, V, d_tid); return; }
+    // ---- checkpoints: alpha row t = 16 k - 1 -> slot k, beta-with-emission row t = 16 k -> slot k (0 < 16 k < T), cells in lattice
+    //      order (blank g = cell 2 g, label g = cell 2 g + 1), the mantissa as f32.  The row is the one the tile before ended
+    //      with (freshly normalised; the halo refill above does not touch the lanes that store).  Stored HERE, behind the
+    //      request for the next tile: vmcnt counts in order, and a store issued in front of that request would have to
+    //      land before the tile can be staged (measured: 30 us per 1000 frames) ----
+    if (!(E2E_EXT_ABL & 8) && q > 0) {
+      const int tb_ = DIR == 0 ? 8 * m : 8 * m + 8;                   // alpha: the row 8 m - 1 -> slot m / 2; beta: the row 8 (m + 1)
+      if ((tb_ & 15) == 0 && tb_ > 0 && tb_ < T) {
+        const int slot = tb_ >> 4;
+        if (!halo) {
+#pragma unroll
+          for (int r = 0; r < NP; r++) {
+            const int g = g0 + r;
+            if (g >= 0 && g <= S) {
+              const size_t cb = (size_t)slot * rt.CELLS + 2 * g;
+              ckm[cb] = (float)Bm[r]; cke[cb] = Be[r];
+              if (DIR == 0) { ckm[cb + 1] = (float)Lm[r]; cke[cb + 1] = Le[r]; }
+              else if (g >= 1) { ckm[cb - 1] = (float)Lm[r]; cke[cb - 1] = Le[r]; }
+            }
+          }
+        }
+      }
+    }
+    // ---- this tile's probabilities of the lane's columns ----
+    float yb[kXTile], yl[NP][kXTile];
+    {
+      const unsigned char* tb = tiles + ((E2E_EXT_ABL & 1) ? 0 : (q & 1) * tile_b);
+      const x_f4 u0 = *(const lds_f32x4*)(tb + blank * 32), u1 = *(const lds_f32x4*)(tb + blank * 32 + 16);
+      yb[0] = u0.x; yb[1] = u0.y; yb[2] = u0.z; yb[3] = u0.w; yb[4] = u1.x; yb[5] = u1.y; yb[6] = u1.z; yb[7] = u1.w;
+#pragma unroll
+      for (int r = 0; r < NP; r++) {
+        const x_f4 v0 = *(const lds_f32x4*)(tb + lab[r] * 32), v1 = *(const lds_f32x4*)(tb + lab[r] * 32 + 16);
+        yl[r][0] = v0.x; yl[r][1] = v0.y; yl[r][2] = v0.z; yl[r][3] = v0.w; yl[r][4] = v1.x; yl[r][5] = v1.y; yl[r][6] = v1.z; yl[r][7] = v1.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kXTile; k++) {
+      const int tt = DIR == 0 ? k : kXTile - 1 - k;
+      const int t = m * kXTile + tt;
+      if (!STEADY && t >= T) continue;                              // (uniform: the utterance's last tile may be short)
       const double ybt = (double)yb[tt];
-      if (DIR == 0 ? t == 0 : t == T - 1) {
+      if (!STEADY && (DIR == 0 ? t == 0 : t == T - 1)) {
         // the first row: ctc_loss.cpp:39-42 (alpha), :76-78 with the emission (beta)
 #pragma unroll
         for (int r = 0; r < NP; r++) {
@@ -206,37 +299,16 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
           Pm = om; Pe = oe;
         }
       }
-      if ((k & 3) == 3) {                                           // (includes the checkpoint rows: tt = 15 / tt = 0)
+      if ((k & 3) == 3) {                                           // (includes the checkpoint rows: the last step of every second tile)
 #pragma unroll
         for (int r = 0; r < NP; r++) { x_norm(Bm[r], Be[r]); x_norm(Lm[r], Le[r]); }
       }
-      // checkpoints: alpha row t = 16 k - 1 -> slot k, beta-with-emission row t = 16 k -> slot k (0 < 16 k < T), cells in
-      // lattice order (blank g = cell 2 g, label g = cell 2 g + 1); freshly normalised, the mantissa as f32
-      if (!(E2E_EXT_ABL & 8) && (DIR == 0 ? (tt == 15 && t + 1 < T) : (tt == 0 && t > 0))) {
-        const int slot = DIR == 0 ? s + 1 : s;
-        if (!halo) {
-#pragma unroll
-          for (int r = 0; r < NP; r++) {
-            const int g = g0 + r;
-            if (g >= 0 && g <= S) {
-              const size_t cb = (size_t)slot * rt.CELLS + 2 * g;
-              ckm[cb] = (float)Bm[r]; cke[cb] = Be[r];
-              if (DIR == 0) { ckm[cb + 1] = (float)Lm[r]; cke[cb + 1] = Le[r]; }
-              else if (g >= 1) { ckm[cb - 1] = (float)Lm[r]; cke[cb - 1] = Le[r]; }
-            }
-          }
-        }
-      }
     }
-    if (!(E2E_EXT_ABL & 1) && active && si + 1 < NSu) {
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        yb[q] = nyb[q];
-#pragma unroll
-        for (int r = 0; r < NP; r++) yl[r][q] = nyl[r][q];
-      }
-    }
-  }
+    if (!(E2E_EXT_ABL & 1)) fetch.store(rt, tiles + ((q + 1) & 1) * tile_b, V, d_tid);
+  };
+  do_tile(0, std::false_type{});
+  for (int q = 1; q < M; q++) do_tile(q, std::true_type{});
+  if (M > 0) do_tile(M, std::false_type{});
   // ---- Z from this side: alpha (ctc_loss.cpp:63-70): blank S + label S-1 of the last row; beta: sum_j alpha_0[j] beta_0[j]
   //      = [cond] blank 0 + label 0 of the row t = 0 (with their emissions) ----
   if (active && !halo) {
@@ -257,8 +329,11 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
 
 // One utterance's chains on this workgroup.  Ends with the utterance's flag word carrying kExtDone (and kExtBad if the
 // partition sum is not a positive number or the two sides disagree), after a release fence.
+// (out of line: inside the flagged kernel -- 255 registers, its own spills -- the chains' loops spilled too; as a function of
+//  their own they get their own register allocation.  The dynamic LDS is found again through its own declaration.)
 template <typename IO>
-__device__ __forceinline__ void ext_chains(const ExactParams& p, unsigned char* smem, int b) {
+__device__ __attribute__((noinline)) void ext_chains(const ExactParams& p, int b) {
+  extern __shared__ __align__(16) unsigned char smem[];
   typedef typename LossOf<IO>::type LT;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = (int)p.x_len[b], S = (int)p.t_len[b];
@@ -305,7 +380,8 @@ __device__ __forceinline__ void ext_chains(const ExactParams& p, unsigned char* 
 // One (utterance, 16-step segment) on this workgroup: wave c takes the label pairs 32 c .. 32 c + 31 (its lanes hold the
 // pairs 32 c - 16 .. 32 c + 47: what the 16 steps can reach from either side), c = wid, wid + 8, ...
 template <typename IO>
-__device__ __forceinline__ void ext_segment(const ExactParams& p, unsigned char* smem, int b, int seg) {
+__device__ __attribute__((noinline)) void ext_segment(const ExactParams& p, int b, int seg) {
+  extern __shared__ __align__(16) unsigned char smem[];
   const FastRetry& rt = p.retry;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V, blank = p.blank, Tmax = p.T;

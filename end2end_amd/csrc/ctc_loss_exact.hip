@@ -304,7 +304,11 @@ __device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned
       }
       // ---- the row: check against the chains' log Z, then y - posterior ----
       const double st = mine;
-      if (!(st > 0.0) || !(st < __builtin_huge_val())) bad = true;
+      // (a row sum near the end of f64 -- rows sink by up to ~110 bits per step between the chains' rescales, nine steps apart --
+      //  has lost cells that matter to denormals, and its reciprocal overflows: until round 5 such rows passed the check below
+      //  and were written as NaN (inf - inf in the Newton step) while the redo reported success.  They fail now: the
+      //  extended-range redo, or the exact kernel, takes the utterance.)
+      if (!(st > 0x1p-960) || !(st < __builtin_huge_val())) bad = true;
       {
         const int EA = cumA_at((t + 1) >> 3), EB = cumB_at((t + 8) >> 3);
         int ex;
@@ -885,10 +889,17 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   };
   stamp(0);
   auto flag_of = [&](int b) -> int { return b < kFlagCache ? (int)s_flag[b] : (p.flags[b] & (kRedoFailed - 1)); };
-  auto range_only = [&](int f) -> bool { return p.mode == 1 && p.has_retry && f != 0 && (f & ~(8 | 16)) == 0; };
+  // (any_ext0, set below: some utterance of the call goes to the extended-range redo for its chains' sake -- then the ones whose
+  //  f32 segment rows alone gave out (8 / 16) join it instead of the f64 redo of single segments: the chains' 0.25 ms is paid
+  //  anyway, theirs run beside it, and nobody has to wait to learn which redos failed)
+  bool any_ext0 = false;
+  auto range_only = [&](int f) -> bool { return p.mode == 1 && p.has_retry && !any_ext0 && f != 0 && (f & ~(8 | 16)) == 0; };
+  auto range_bits_only = [&](int f) -> bool { return f != 0 && (f & ~(8 | 16)) == 0; };
   // flagged for its numbers, not for its inputs (1: lengths, 2: blank inside the targets, 128: protocol, 256: probabilities the f32
   // table cannot hold; 64 alone -- probabilities below 2^-100 but still normal f32 numbers -- is a matter of range)
-  auto ext_candidate = [&](int f) -> bool { return p.mode == 1 && p.has_ext && (f & (4 | 32 | 64)) != 0 && (f & (1 | 2 | 128 | 256)) == 0; };
+  auto ext_candidate = [&](int f) -> bool {
+    return p.mode == 1 && p.has_ext && ((f & (4 | 32 | 64)) != 0 || (!p.has_retry && (f & (8 | 16)) != 0)) && (f & (1 | 2 | 128 | 256)) == 0;
+  };
 
   if (p.mode == 2) {
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
@@ -911,7 +922,8 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
           const int bb = c0 + lane;
           int f = 0;
           if (bb < p.B) f = bb < kFlagCache ? (int)s_flag[bb] : (__hip_atomic_load(&p.flags[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (2 * kRedoFailed - 1));
-          const bool take = bb < p.B && (round == 0 ? ext_candidate(f) : ((f & kRedoFailed) != 0 && range_only(f & (kRedoFailed - 1))));
+          const bool take = bb < p.B && (round == 0 ? (ext_candidate(f) || (any_ext0 && range_bits_only(f)))
+                                                    : ((f & kRedoFailed) != 0 && range_only(f & (kRedoFailed - 1))));
           const int nseg = take ? ((int)p.x_len[bb] + kFastSeg - 1) / kFastSeg : 0;
           const unsigned long long m = __ballot(take);
           const int before = __builtin_popcountll(m & ((1ull << lane) - 1));
@@ -942,16 +954,19 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
         __syncthreads();
         if (s_go) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          ext_segment<IO>(p, smem, ub, seg);
+          ext_segment<IO>(p, ub, seg);
         }
         __syncthreads();
       }
     };
     int nx0 = 0;
     if (p.has_ext) {
+      bool mine = false;
+      for (int b = tid; b < p.B; b += kThreads) mine |= ext_candidate(flag_of(b));
+      any_ext0 = __syncthreads_or(mine ? 1 : 0) != 0;
       build_list(0);
       nx0 = s_next;
-      for (int i = blockIdx.x; i < nx0; i += gridDim.x) ext_chains<IO>(p, smem, s_xb[i]);
+      for (int i = blockIdx.x; i < nx0; i += gridDim.x) ext_chains<IO>(p, s_xb[i]);
     }
     stamp(1);
     // ---- 1. segments of the utterances flagged for range only: item i of the running list goes to wave i mod NW.  (The
@@ -1040,7 +1055,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
           __syncthreads();
           build_list(1);
           const int nx1 = s_next;
-          for (int i = blockIdx.x; i < nx1; i += gridDim.x) ext_chains<IO>(p, smem, s_xb[i]);
+          for (int i = blockIdx.x; i < nx1; i += gridDim.x) ext_chains<IO>(p, s_xb[i]);
           if (nx1 > 0) ext_segments_of_list(nx1);
           for (int b = tid; b < p.B && b < kFlagCache; b += kThreads) s_flag[b] &= (unsigned short)(kRedoFailed - 1);
           __syncthreads();
@@ -1054,7 +1069,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
     for (int c0 = 0; c0 < p.B; c0 += 64) {
       const int bb = c0 + lane;
       const int f = bb < p.B ? flag_of(bb) : 0;
-      unsigned long long hard = __ballot(f != 0 && !range_only(f) && !ext_candidate(f));
+      unsigned long long hard = __ballot(f != 0 && !range_only(f) && !ext_candidate(f) && !(any_ext0 && range_bits_only(f)));
       while (hard) {
         const int l = __builtin_ctzll(hard); hard &= hard - 1;
         if ((int)blockIdx.x < p.nslabs && h % p.nslabs == (int)blockIdx.x) {
@@ -1080,7 +1095,8 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
       const int f = bb < p.B ? __hip_atomic_load(&p.flags[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       // what nothing has settled: a failed segment redo or an extended-range candidate without good extended-range chains
       const bool settled = (f & kExtDone) != 0 && (f & kExtBad) == 0;
-      unsigned long long failed = __ballot(((f & kRedoFailed) != 0 || ext_candidate(f & (kRedoFailed - 1))) && !settled);
+      const int f0 = f & (kRedoFailed - 1);
+      unsigned long long failed = __ballot(((f & kRedoFailed) != 0 || ext_candidate(f0) || (any_ext0 && range_bits_only(f0))) && !settled);
       while (failed) {
         const int l = __builtin_ctzll(failed); failed &= failed - 1;
         if (tid == 0) atomicAdd(&p.ctl[1], 1);          // (diagnostics: redone in full although only the segments' range gave out)

@@ -1717,6 +1717,9 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   } else if (smin < __builtin_huge_valf()) {
     if (lane == 0) atomicOr(&p.segmask[(size_t)b * p.MW + (seg >> 5)], 1u << (seg & 31));
   }
+#ifdef E2E_F2_MASK_ALL              // (tools/diag: every segment of a range-flagged utterance is redone)
+  if (lane == 0) atomicOr(&p.segmask[(size_t)b * p.MW + (seg >> 5)], 1u << (seg & 31));
+#endif
   if (seg == 0 && lane == 0) {
     const double za = p.logz[2 * b], zb = p.logz[2 * b + 1];
     if (!(fabs(za - zb) <= 1e-6 * fabs(za) + 1e-4)) atomicOr(&p.flags[b], 32);
@@ -1767,8 +1770,12 @@ int launch_segments(const FastParams& p, size_t lds, hipStream_t stream) {
 // gradient stores drain under the next segment -- were built, parity-green, and measured: 137 against 131 us per step.  The
 // one-segment waves already overlap each other's load latency and store tails; a register prefetch spills (tried twice).)
 // targets of 256..447 labels: the halo chains on four waves per direction, the segment kernel with eight pairs per lane
+// ... over the f32 ring and the probability table of the wide-row form (ChainF64LW) where the alphabet asks for it -- or where the
+// f64 ring of ChainF64L on its sixteen waves does not fit the LDS (73..96 columns: 170..192 KB; until round 5 such a call failed
+// with "hipFuncSetAttribute: invalid argument")
+bool long_wide_rows(int V) { return V > kMaxSmallV || HfLds::of<ChainF64L>(V).total > 160 * 1024; }
 int launch_fast_long(const FastParams& p, hipStream_t stream) {
-  if (p.V > kMaxSmallV) {          // the wide-row form (see ChainF64LW)
+  if (long_wide_rows(p.V)) {       // the wide-row form (see ChainF64LW)
     hipLaunchKernelGGL(ctc_fast_prob_kernel<(kMaxHugeV + 63) / 64>, dim3((unsigned)(((int64_t)p.B * p.T + 4 * kProbRows - 1) / (4 * kProbRows))), dim3(256), 0, stream, p);
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_prob_kernel launch");
     const HfLds hl = HfLds::of<ChainF64LW>(p.V);
@@ -1948,7 +1955,7 @@ int launch_fast(const LossArgs& a, bool fallback_to_exact) {
   e.ws = ws + l.total; e.ws_bytes = a.ws_bytes - l.total;
   // mode 1: redo flagged utterances exactly; mode 2: no fallback requested -> poison them
   FastRetry rt;
-  rt.ytab = p.ytab; rt.ytab_segments = a.V <= kMaxSmallV ? 1 : 0; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.cumA = p.cumA; rt.cumB = p.cumB;
+  rt.ytab = p.ytab; rt.ytab_segments = (a.V <= kMaxSmallV && !(ppl_of(a.V, a.Smax) == 8 && long_wide_rows(a.V))) ? 1 : 0; rt.ckA = p.ckA; rt.ckQ = p.ckQ; rt.ckE = p.ckE; rt.cumA = p.cumA; rt.cumB = p.cumB;
   rt.NS = p.NS; rt.NB = p.NB; rt.CELLS = p.CELLS; rt.PPL = ppl_of(a.V, a.Smax); rt.logz = p.logz; rt.ctl = p.ctl;
   rt.segmask = p.segmask; rt.MW = p.MW;
   rt.ckXA = reinterpret_cast<int*>(ws + l.ckXA); rt.ckXQ = reinterpret_cast<int*>(ws + l.ckXQ); rt.extz = reinterpret_cast<double*>(ws + l.extz);

@@ -574,7 +574,8 @@ def test_scaled_exact_form_scales_rows_by_their_feasible_cells():
     U.assert_same(ge, grads, 1e-6, 1e-9, "grads: scaled form against the log-domain kernel")
 
 
-@pytest.mark.parametrize("shape", [(3, 700, 29, 300), (2, 2000, 29, 400), (2, 1100, 48, 447)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)
+@pytest.mark.parametrize("shape", [(3, 700, 29, 300), (2, 2000, 29, 400), (2, 1100, 48, 447), (2, 1000, 96, 425), (2, 900, 80, 300)],
+                         ids=lambda s: "B%d_T%d_V%d_S%d" % s)
 def test_long_transcripts_take_the_fast_path(shape):
     """Targets of 256..447 labels: the halo chains on four waves per direction and the segment kernel with
     eight pairs per lane -- served by the fast path itself (ALGO_FAST leaves no NaN), equal to the oracle at the default
