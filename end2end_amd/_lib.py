@@ -53,6 +53,8 @@ def load():
         L.e2e_last_error.restype = C.c_char_p
         L.e2e_ctc_loss_workspace_bytes.restype = C.c_size_t
         L.e2e_ctc_loss_workspace_bytes.argtypes = [C.c_int] * 6
+        L.e2e_ctc_loss_takes_dtype.restype = C.c_int
+        L.e2e_ctc_loss_takes_dtype.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64, i64, vp, vp]
         L.e2e_ctc_loss_fwd_bwd.restype = C.c_int
         L.e2e_ctc_loss_fwd_bwd.argtypes = [vp, C.c_int, C.c_int, i64, i64, i64, i64p, i64, i64p, i64p,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -92,6 +94,12 @@ def load():
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i64p, i64, vp, C.c_size_t, vp]
         L.e2e_debug_stream_copy.restype = C.c_int
         L.e2e_debug_stream_copy.argtypes = [vp, vp, C.c_size_t, vp]
+        # (the dtype codes above are include/e2e_ctc.h's: the pybind layer, which is compiled against the header, carries them)
+        try:
+            from . import _C as _ext
+            assert (F32, F64, F16, BF16) == (_ext.F32, _ext.F64, _ext.F16, _ext.BF16), "dtype codes of _lib.py and include/e2e_ctc.h differ"
+        except ImportError:
+            pass
         if L.e2e_ctc_abi_version() != ABI_VERSION:
             raise ImportError("end2end_amd: %s has ABI %d, expected %d" % (LIB_PATH, L.e2e_ctc_abi_version(), ABI_VERSION))
         _lib = L

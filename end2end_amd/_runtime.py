@@ -20,7 +20,7 @@ except ImportError as e:                                   # pragma: no cover - 
         "(hipcc --offload-arch=gfx950 + g++/pybind11). There is no CPU fallback." % e) from e
 
 F32, F64 = _C.F32, _C.F64
-F16, BF16 = 2, 3            # E2E_F16 / E2E_BF16 (include/e2e_ctc.h): read and written natively by the fast and wide loss paths
+F16, BF16 = _C.F16, _C.BF16    # (read and written natively by the fast and wide loss paths)
 ALGO_AUTO, ALGO_EXACT, ALGO_FAST = _C.ALGO_AUTO, _C.ALGO_EXACT, _C.ALGO_FAST
 ABI_VERSION = 2
 E2EError = _C.E2EError

@@ -171,6 +171,18 @@ size_t e2e_ctc_loss_workspace_bytes(int B, int T, int V, int Smax, int dtype, in
   return n + 256;
 }
 
+// Does a loss call with these logits run as it is (1), or does the caller have to up-cast 16-bit logits to f32 first (0)?
+// Mirrors the dispatch of e2e_ctc_loss_fwd_bwd_opt below and launch_wide's single-read condition (ctc_loss_wide.hip).
+int e2e_ctc_loss_takes_dtype(int dtype, int algo, int T, int V, int Smax, int64_t sB, int64_t sT, int64_t sV,
+                             const void* x, const void* grads) {
+  if (dtype == E2E_F32 || dtype == E2E_F64) return 1;
+  if (!dtype_is_16bit(dtype) || T < 1 || V < 1 || Smax < 0) return 0;
+  if (resolve_algo(algo, dtype, T, V, Smax) == E2E_ALGO_EXACT) return 0;
+  if (!use_wide(dtype, T, V, Smax)) return 1;                      // the lattice kernels read any stride, any alignment
+  return (sV == 1 && sT % 8 == 0 && sB % 8 == 0 && V % 8 == 0 && V <= 8192 &&
+          reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(grads) % 16 == 0) ? 1 : 0;
+}
+
 int e2e_ctc_loss_fwd_bwd(const void* x, int dtype, int input_is_logprobs,
                          int64_t sB, int64_t sT, int64_t sV,
                          const int64_t* targets, int64_t tgt_stride,
@@ -224,7 +236,7 @@ int e2e_ctc_loss_fwd_bwd_opt(const void* x, int dtype, int input_is_logprobs,
   if (r == E2E_ALGO_EXACT) { const int rc = launch_exact(a); return rc != E2E_OK ? rc : launch_reduce_losses(a); }
   if (use_wide(dtype, T, V, Smax)) {
     if (r == E2E_ALGO_FAST && !wide_takes_fast_lattice(T, V, Smax, dtype)) {
-      set_error("fast CTC path does not support this shape/dtype (more than 95 distinct labels: the compact lattice is the exact kernel's)");
+      set_error("fast CTC path does not support this shape/dtype (Smax + 1 = %d > 448 compact columns, or T >= 2^22: the compact lattice is the exact kernel's)", Smax + 1);
       return E2E_ERR_UNSUPPORTED;
     }
     const int rc = launch_wide(a, r == E2E_ALGO_AUTO);

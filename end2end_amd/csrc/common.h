@@ -39,7 +39,7 @@ int hip_fail(hipError_t e, const char* what);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize = `bytes` for kernel `fn`, set once per (kernel, device, size class) and process --
+// hipFuncAttributeMaxDynamicSharedMemorySize = `bytes` for kernel `fn`, raised when a launch needs more than the largest size asked for so far per (kernel, device) --
 // not on every launch: a host call that an entry point meant to be captured into a graph should not repeat.  Returns a hipError_t.
 hipError_t allow_dynamic_lds(const void* fn, int bytes);
 

@@ -326,7 +326,10 @@ __device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
   // kernel ran 1.70 ms against the f32 kernel's 1.62 at V = 8000): every pass converts the chunk it works on, and the
   // exponentials exp(x - max) in [0, 1] go back into the same registers in the row's own 16-bit type (the sum is taken
   // from the unrounded values; the gradient is that value times 1/sum, rounded once more: <= 1.5 ulp of the output type).
+  // (f16: the held exponentials are scaled by 2^14 -- unscaled, everything below 6e-5 would sit in f16's subnormals with an absolute
+  //  error of 3e-8 that a fused grad_scale > 1, a loss-scaling factor, multiplies up beyond an ulp of what is written)
   typedef typename std::conditional<PACKED, ev, fv>::type held;
+  constexpr float kHeld = (PACKED && std::is_same<E, f16_t>::value) ? 16384.f : 1.f;
   held v[NCH];
   const int last = n4 - 1;
   const int part_idx = min(lane + (n4 & ~63), last);      // this lane's chunk in the partial group
@@ -362,14 +365,14 @@ __device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
         float part = 0.f;
 #pragma unroll
         for (int e = 0; e < EPC; e++) { f[e] = exp_acc(f[e] - M); part += f[e]; }
-        v[u] = to_held(f);
+        v[u] = to_held(f * kHeld);
         sum += (64 * u + 64 <= n4 || part_in) ? part : 0.f;
       }
       if ((u * EPC / 4) & 1) __builtin_amdgcn_sched_barrier(0);       // (8 exps in flight are enough; interleaving all of them costs registers)
     }
     sum = wave_sum_f(sum);
     const float inv = 1.f / sum;
-    const float invg = inv * p.gscale;
+    const float invg = inv * p.gscale * (1.f / kHeld);
     lse = M + logf(sum);
 #pragma unroll
     for (int u = 0; u < NCH; u++) {

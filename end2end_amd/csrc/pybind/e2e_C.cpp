@@ -63,6 +63,9 @@ PYBIND11_MODULE(_C, m) {
   m.attr("ABI_VERSION") = E2E_CTC_ABI_VERSION;
   m.attr("F32") = E2E_F32;
   m.attr("F64") = E2E_F64;
+  m.attr("F16") = E2E_F16;
+  m.attr("BF16") = E2E_BF16;
+  m.attr("ERR_UNSUPPORTED") = E2E_ERR_UNSUPPORTED;
   m.attr("ALGO_AUTO") = E2E_ALGO_AUTO;
   m.attr("ALGO_EXACT") = E2E_ALGO_EXACT;
   m.attr("ALGO_FAST") = E2E_ALGO_FAST;
@@ -77,6 +80,10 @@ PYBIND11_MODULE(_C, m) {
 
   m.def("ctc_loss_workspace_bytes", [](int B, int T, int V, int Smax, int dtype, int algo) {
     return e2e_ctc_loss_workspace_bytes(B, T, V, Smax, dtype, algo);
+  });
+
+  m.def("ctc_loss_takes_dtype", [](int dtype, int algo, int T, int V, int Smax, int64_t sB, int64_t sT, int64_t sV, uintptr_t x, uintptr_t grads) {
+    return e2e_ctc_loss_takes_dtype(dtype, algo, T, V, Smax, sB, sT, sV, reinterpret_cast<const void*>(x), reinterpret_cast<const void*>(grads)) != 0;
   });
 
   // (grad_scale / reduced / reduction / chains: e2e_ctc_loss_opts; the defaults are the plain call)

@@ -54,13 +54,15 @@ class CTCLossEngine:
         if x.dtype in (torch.float16, torch.bfloat16) and self.algo != R.ALGO_EXACT:
             # 16-bit logits (raw autocast outputs): the fast and wide paths read them as they are and write the gradient in
             # the same dtype -- no f32 copy of the (B,T,V) tensors (the reference converts once to double,
-            # src/losses/forward_backward.cpp:15,55-56).  Shapes those paths do not take are up-cast below.
-            try:
+            # src/losses/forward_backward.cpp:15,55-56).  Shapes those paths do not take (the library says which:
+            # e2e_ctc_loss_takes_dtype) are up-cast below.  The gradient of a fresh allocation is 256-byte aligned.
+            B, T, V = x.shape
+            targets = _as_long(targets, dev)
+            Smax = targets.shape[1] if targets.dim() == 2 else 0
+            sB, sT, sV = x.stride()
+            if _C.ctc_loss_takes_dtype(R.dtype_code(x.dtype), self.algo, T, V, Smax, sB, sT, sV, x.data_ptr(), 0):
                 return self._compute_on_device(x, src_device, src_dtype, dev, targets, logits_lengths, targets_lengths,
                                                input_is_logprobs, grad_scale, reduction)
-            except R.E2EError as err:
-                if "up-cast" not in str(err) and "16-bit" not in str(err):
-                    raise
         if x.dtype not in (torch.float32, torch.float64):
             x = x.to(torch.float32)
         return self._compute_on_device(x, src_device, src_dtype, dev, targets, logits_lengths, targets_lengths,

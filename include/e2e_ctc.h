@@ -62,7 +62,8 @@ const char* e2e_last_error(void);
  *   src/losses/ctc_loss.cpp:15-118.
  *
  *   x            (B,T,V) tensor with element strides sB,sT,sV (a time-major
- *                permuted view is fine); dtype E2E_F32 / E2E_F64
+ *                permuted view is fine); dtype E2E_F32, E2E_F64, or -- where e2e_ctc_loss_takes_dtype() says so --
+ *                E2E_F16 / E2E_BF16 (read as they are: no f32 copy exists)
  *   input_is_logprobs
  *                1: x holds log-probabilities -- exactly the reference engine:
  *                   grads = exp(x) - posterior over the full (T,V) slab, rows
@@ -76,12 +77,19 @@ const char* e2e_last_error(void);
  *                outside these ranges, or whose first t_len[b] targets contain a value outside [0,V), gets
  *                loss = NaN and a NaN gradient slab (the reference reads out of bounds there); the other
  *                utterances of the batch are unaffected and the call still returns 0.
- *   losses       (B)  same dtype as x;  +inf for an infeasible alignment (Q2)
- *   grads        (B,T,V) contiguous, same dtype as x; NaN slab when infeasible
+ *   losses       (B)  same dtype as x -- f32 for 16-bit x;  +inf for an infeasible alignment (Q2)
+ *   grads        (B,T,V) contiguous, same dtype as x (16-bit x: 16-bit gradient); NaN slab when infeasible
  *   workspace    >= e2e_ctc_loss_workspace_bytes(...) bytes, 256-B aligned
  *   algo         E2E_ALGO_*
  */
 size_t e2e_ctc_loss_workspace_bytes(int B, int T, int V, int Smax, int dtype, int algo);
+
+/* 1 if a loss call with these logits runs as it is; 0 if the caller has to up-cast them to f32 first (then the call would
+ * return E2E_ERR_UNSUPPORTED).  Always 1 for E2E_F32 / E2E_F64.  16-bit logits are read natively by the lattice kernels
+ * (alphabets of <= 448 columns, targets of <= 447 labels: any strides) and by the wide-alphabet path when its rows can be
+ * read in one pass: contiguous (sV == 1), V % 8 == 0, V <= 8192, strides of whole 16-byte pieces, x and grads 16-byte aligned. */
+int e2e_ctc_loss_takes_dtype(int dtype, int algo, int T, int V, int Smax, int64_t sB, int64_t sT, int64_t sV,
+                             const void* x, const void* grads);
 
 int e2e_ctc_loss_fwd_bwd(const void* x, int dtype, int input_is_logprobs,
                          int64_t sB, int64_t sT, int64_t sV,

@@ -27,7 +27,8 @@ def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_
     xl = torch.as_tensor(np.asarray(x_len)).to(d, torch.long)
     tl = torch.as_tensor(np.asarray(t_len)).to(d, torch.long)
     Smax = targets.shape[1]
-    losses = torch.full((B,), 7.0, dtype=x.dtype, device=d)
+    loss_dtype = torch.float32 if x.dtype in (torch.float16, torch.bfloat16) else x.dtype     # (16-bit calls keep their losses in f32)
+    losses = torch.full((B,), 7.0, dtype=loss_dtype, device=d)
     grads = torch.full((B, T, V), 7.0, dtype=x.dtype, device=d)
     code = _lib.dtype_code(x.dtype)
     n = L.e2e_ctc_loss_workspace_bytes(B, T, V, Smax, code, algo)
@@ -44,13 +45,15 @@ def c_abi_loss(x, targets, x_len, t_len, blank=0, logprobs=True, algo=_lib.ALGO_
         o = _lib.LossOpts(1.0, None, _lib.REDUCE_NONE, int(chains))
         _lib.check(L.e2e_ctc_loss_fwd_bwd_opt(*args, ctypes.byref(o)))
     else:
-        reduced = torch.full((1,), 7.0, dtype=x.dtype, device=d)
+        reduced = torch.full((1,), 7.0, dtype=loss_dtype, device=d)
         o = _lib.LossOpts(float(opts[0]), reduced.data_ptr() if opts[1] else None, int(opts[1]))
         import ctypes
         _lib.check(L.e2e_ctc_loss_fwd_bwd_opt(*args, ctypes.byref(o)))
     torch.cuda.synchronize()
     if keep is not None:
         keep["workspace"] = ws              # (diagnostics read the fast path's flag words out of it)
+    if grads.dtype in (torch.float16, torch.bfloat16):
+        grads = grads.float()                                # (numpy has no bf16)
     if opts is not None:
         return losses.cpu().numpy(), grads.cpu().numpy(), reduced.cpu().numpy()[0]
     return losses.cpu().numpy(), grads.cpu().numpy()

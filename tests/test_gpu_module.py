@@ -7,7 +7,7 @@ import torch
 import golden_util as G
 import oracle_lib as O
 import gpu_util as U
-from end2end_amd import CTCDecoder, CTCLoss, DecoderResults
+from end2end_amd import CTCDecoder, CTCLoss, DecoderResults, _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -297,3 +297,29 @@ def test_half_precision_logits_are_read_and_written_natively(dtype, shape):
     eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
     U.assert_same(x.grad.float().cpu().numpy(), g_o / B, 4 * eps, 4 * eps / B, "input grad")
     U.assert_same(loss.detach().float().cpu().numpy(), l_o.mean(), 4 * eps, 4 * eps, "loss")
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 8000, 20), (4, 100, 150, 60)], ids=["wide_path_V8000", "fast_path_V150"])
+def test_f16_gradients_with_a_fused_loss_scale_keep_their_resolution(shape):
+    """e2e_ctc_loss_opts.grad_scale = 1024 (a loss-scaling factor) on f16 logits.  The wide path keeps a row's
+    exponentials packed in f16 between its passes; unscaled, values below 6e-5 sat in f16's subnormals and the factor
+    multiplied their absolute error up.  Every written element must be within 1.5 ulp (f16) of the exact scaled gradient,
+    small elements included."""
+    import ctypes
+    B, T, V, S = shape
+    g = torch.Generator().manual_seed(9)
+    x0 = (torch.randn(B, T, V, generator=g) * 2.0).to(torch.float16)
+    tg = torch.randint(1, V, (B, S), generator=g)
+    xl = torch.full((B,), T); tl = torch.randint(S // 2, S + 1, (B,), generator=g)
+    scale = 1024.0
+    losses, grads, _ = U.c_abi_loss(x0, tg, xl, tl, 0, False, _lib.ALGO_AUTO, opts=(scale, _lib.REDUCE_NONE))
+    lp = torch.log_softmax(x0.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg.numpy(), xl.numpy(), tl.numpy(), 0)
+    want = g_o * scale
+    got = grads.astype(np.float64)
+    ulp = np.maximum(np.abs(want), 2.0 ** -14) * 2.0 ** -10          # an f16 ulp of the exact value (normal range)
+    err = np.abs(got - want)
+    # (the lattice itself is f32: 2e-6 * scale absolute on top of the output rounding)
+    assert (err <= 1.5 * ulp + 2e-6 * scale + 1e-4 * np.abs(want)).all(), "worst %.3g ulp at |g| = %.3g" % (
+        (err / ulp).max(), np.abs(want).flat[(err / ulp).argmax()])
+    U.assert_same(losses, l_o, 1e-4, 2e-5, "losses")

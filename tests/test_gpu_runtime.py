@@ -103,3 +103,56 @@ def test_tiny_model_trains_with_the_drop_in_loss_and_decodes_its_targets():
     greedy = CTCDecoder(beam_width=1, blank_idx=0, labels=labels).decode(logits, xl)
     beam = CTCDecoder(beam_width=16, blank_idx=0, labels=labels, wip=0.0).decode(logits, xl)
     assert greedy.decoded_sentences == want and beam.decoded_sentences == want
+
+
+def _events_ms(fn, reps):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2]
+
+
+def test_headline_call_is_not_pathologically_slow():
+    """A performance guard, not a benchmark: the same ISA has run 6.5x slower when a kernel's code object was laid out
+    differently (61 -> 401 us for the segment kernel), and nothing else in the suite would notice.  HIP events
+    around the C-ABI calls at the sizes BASELINE.json names, limits ~3x the recorded numbers (boxes of the pool differ by
+    12 %): configs[1] loss call 0.15 ms -> < 0.45; one GPU's share of configs[4] 1.75 ms -> < 5; configs[3] beam search
+    13 ms -> < 40; the mislabelled-utterance regime of round 5 (0.45 ms) -> < 1.5."""
+    import bench
+    d = U.dev()
+    w = bench.WORKLOAD
+    _, db = bench.make_batch(1000, w["B"], w["T"], w["V"], w["S"], d)
+    hp = bench.HotPath(db)
+    for _ in range(3):
+        hp.call(hp.means[0, :1])
+    ms = _events_ms(lambda: hp.call(hp.means[0, :1]), 20)
+    assert ms < 0.45, "configs[1] loss call: %.3f ms" % ms
+    del hp, db
+    x, tg, xl, tl = bench.aligned_batch(10, w["B"], w["T"], w["V"], w["S"], 10.0)
+    for k in range(8):
+        tg[32 * k], tl[32 * k] = tg[32 * k + 1].clone(), tl[32 * k + 1].clone()
+    hp = bench.HotPath(tuple(t.to(d) for t in (x, tg, xl, tl)))
+    for _ in range(3):
+        hp.call(hp.means[0, :1])
+    ms = _events_ms(lambda: hp.call(hp.means[0, :1]), 10)
+    assert ms < 1.5, "configs[1] shape with 8 mislabelled utterances: %.3f ms" % ms
+    assert torch.isfinite(hp.losses).all()
+    del hp
+    ww = bench.WIDE
+    _, wb = bench.make_batch(5000, ww["B"], ww["T"], ww["V"], ww["S"], d)
+    hp = bench.HotPath(wb)
+    for _ in range(2):
+        hp.call()
+    ms = _events_ms(hp.call, 5)
+    assert ms < 5.0, "configs[4] share: %.3f ms" % ms
+    del hp, wb
+    torch.cuda.empty_cache()
+    g = torch.Generator().manual_seed(2)
+    xb = torch.log_softmax(torch.randn(64, 1500, 29, generator=g) * 3, -1).to(d)
+    xlb = torch.full((64,), 1500, dtype=torch.long, device=d)
+    labels = ["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]
+    eng = CTCDecoder(beam_width=100, blank_idx=0, after_logsoftmax=True, labels=labels, wip=1.0)._decoder
+    eng.decode(xb, xlb)
+    ms = _events_ms(lambda: eng.decode(xb, xlb), 3)
+    assert ms < 40.0, "configs[3] beam search without LM: %.3f ms" % ms
