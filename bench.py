@@ -638,6 +638,31 @@ def main():
     module_loss = float(lm_.item())
     c_abi_loss = float(hp.means[0, 0].item())
 
+    # ---- leg 2b (under the launcher): what the package ships for a batch spread over ranks -- end2end_amd.parallel.ShardedCTCLoss
+    #      (per-utterance losses, ONE synchronous 16-byte all-reduce of [sum, count] per call, gradient of the GLOBAL mean) +
+    #      backward().  The C-ABI leg above reduces its scalar losses in buckets of 8 steps, asynchronously; this is the module. ----
+    sharded_wall = None
+    if distributed:
+        from end2end_amd.parallel import ShardedCTCLoss
+        scrit = ShardedCTCLoss(size_average=True, blank_idx=0)
+        xs = dev_batch[0].clone().requires_grad_()
+
+        def sharded_step():
+            xs.grad = None
+            loss = scrit(xs, tg, xl, tl)
+            loss.backward()
+            return loss
+
+        for _ in range(args.warmup):
+            sharded_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ls_ = sharded_step()
+        fence()
+        sharded_wall = max_over_ranks(time.perf_counter() - t0)
+        sharded_loss = float(ls_.item())
+
     # ---- leg 3: one GPU's share of configs[4] (V=8000), the HBM-bound shape, at every N ------------------------------
     wide = wide_bf16 = None
     if not args.no_wide:
@@ -717,6 +742,12 @@ def main():
             "module_api": "loss = end2end_amd.CTCLoss(reduce=True, size_average=True)(logits, targets, lengths...); "
                           "loss.backward()  (same batch; loss %.6f vs C-ABI %.6f)" % (module_loss, c_abi_loss),
         }
+        if sharded_wall is not None:
+            out["sharded_module_ms_per_step"] = sharded_wall * 1e3 / args.steps
+            out["sharded_module_frames_per_s"] = total_frames * args.steps / sharded_wall
+            out["sharded_module_api"] = ("loss = end2end_amd.parallel.ShardedCTCLoss(size_average=True)(logits, ...); loss.backward(): every rank "
+                                         "its own %d utterances, one synchronous all-reduce of [sum of losses, count] per call "
+                                         "(global mean loss %.6f)" % (w["B"], sharded_loss))
         out["ragged_lengths"] = {
             "workload": "the headline batch with x_len = randint(T//2, T+1) (SURVEY.md 8d's ragged variant)",
             "kernel_ms": ragged_ms, "frames": ragged_frames, "frames_per_s_per_gpu": ragged_frames / (ragged_ms * 1e-3)}

@@ -264,7 +264,7 @@ extern "C" int e2e_ctc_align(const void* lp, int dtype, int64_t sB, int64_t sT, 
                              int B, int T, int V, int Smax, int blank, int is_ctc,
                              int64_t* out, int64_t pad_value,
                              void* workspace, size_t workspace_bytes, void* stream) {
-  if (dtype != E2E_F32 && dtype != E2E_F64) { set_error("dtype must be E2E_F32 or E2E_F64"); return E2E_ERR_ARG; }
+  if (dtype != E2E_F32 && dtype != E2E_F64 && !dtype_is_16bit(dtype)) { set_error("dtype must be E2E_F32, E2E_F64, E2E_F16 or E2E_BF16"); return E2E_ERR_ARG; }
   if (B < 0 || T < 1 || V < 1 || Smax < 0) { set_error("bad sizes B=%d T=%d V=%d Smax=%d", B, T, V, Smax); return E2E_ERR_ARG; }
   if (blank < 0 || blank >= V) { set_error("blank=%d outside [0,%d)", blank, V); return E2E_ERR_ARG; }
   if (B > 0 && (!lp || !x_len || !t_len || !out || (Smax > 0 && !targets))) { set_error("null pointer argument"); return E2E_ERR_ARG; }
@@ -282,13 +282,11 @@ extern "C" int e2e_ctc_align(const void* lp, int dtype, int64_t sB, int64_t sT, 
   p.x_len = x_len; p.t_len = t_len; p.B = B; p.T = T; p.V = V; p.Smax = Smax; p.Lmax = Lmax; p.Lpad = Lpad; p.blank = blank;
   p.is_ctc = is_ctc ? 1 : 0; p.out = out; p.pad = pad_value; p.bp = reinterpret_cast<unsigned char*>(aligned);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == E2E_F32) {
-    E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_align_kernel<float>), (int)lds), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_align_kernel<float>, dim3(B), dim3(kThreads), lds, s, p);
-  } else {
-    E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_align_kernel<double>), (int)lds), "hipFuncSetAttribute");
-    hipLaunchKernelGGL(ctc_align_kernel<double>, dim3(B), dim3(kThreads), lds, s, p);
-  }
+  // (16-bit log-probabilities are read as they are: the sweep's rows are doubles either way)
+#define E2E_ALIGN_GO(IO) { E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_align_kernel<IO>), (int)lds), "hipFuncSetAttribute"); \
+                           hipLaunchKernelGGL(ctc_align_kernel<IO>, dim3(B), dim3(kThreads), lds, s, p); }
+  if (dtype == E2E_F32) E2E_ALIGN_GO(float) else if (dtype == E2E_F64) E2E_ALIGN_GO(double) else if (dtype == E2E_F16) E2E_ALIGN_GO(f16_t) else E2E_ALIGN_GO(bf16_t)
+#undef E2E_ALIGN_GO
   E2E_HIP_CHECK(hipGetLastError(), "ctc_align_kernel launch");
   return E2E_OK;
 }

@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(kGenThreads) void ctc_beam_general_kernel(BeamParam
     // W = 100).  Exact unless two DIFFERENT lp values could round to the same score, i.e. unless |full| is within 2^24 of
     // their spacing: f32 inputs and |full| < 2^20 only; otherwise, with a language model, for tiny alphabets or if the ties
     // overflow the list, every character is taken as before.
-    bool pre = LMK == 0 && sizeof(IO) == 4 && V <= 65536 && V - 1 > 3 * W + 2;
+    bool pre = LMK == 0 && sizeof(IO) <= 4 && V <= 65536 && V - 1 > 3 * W + 2;      // (16-bit inputs are f32 numbers too)
     if (pre) {
       if (tid == 0) s_fmax = 0u;
       __syncthreads();
@@ -1951,7 +1951,7 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
                             double lmwt, double wip, double oov_penalty,
                             int64_t* out, int64_t max_out, int64_t* out_len,
                             void* workspace, size_t workspace_bytes, void* stream) {
-  if (dtype != E2E_F32 && dtype != E2E_F64) { set_error("dtype must be E2E_F32 or E2E_F64"); return E2E_ERR_ARG; }
+  if (dtype != E2E_F32 && dtype != E2E_F64 && !dtype_is_16bit(dtype)) { set_error("dtype must be E2E_F32, E2E_F64, E2E_F16 or E2E_BF16"); return E2E_ERR_ARG; }
   if (B < 0 || T < 1 || V < 1 || beam_width < 1 || max_out < 1) { set_error("bad sizes"); return E2E_ERR_ARG; }
   if (blank < 0 || blank >= V) { set_error("blank=%d outside [0,%d)", blank, V); return E2E_ERR_ARG; }
   if (B > 0 && (!lp || !x_len || !out || !out_len)) { set_error("null pointer argument"); return E2E_ERR_ARG; }
@@ -2004,26 +2004,19 @@ extern "C" int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, i
     g.lmc = lm ? reinterpret_cast<LmAnswer*>(ws + l.total + gl.lmc) : nullptr;
     g.gmem = gl.members_in_ws ? reinterpret_cast<unsigned char*>(ws + l.total + gl.gmem) : nullptr;
     g.CH = gl.CH;
-    const void* gfn;
-    if (dtype == E2E_F32)
-      gfn = !lm ? (const void*)&ctc_beam_general_kernel<float, 0>
-                : fast_lm ? (const void*)&ctc_beam_general_kernel<float, 2> : (const void*)&ctc_beam_general_kernel<float, 1>;
-    else
-      gfn = !lm ? (const void*)&ctc_beam_general_kernel<double, 0>
-                : fast_lm ? (const void*)&ctc_beam_general_kernel<double, 2> : (const void*)&ctc_beam_general_kernel<double, 1>;
+    // (16-bit log-probabilities are read as they are -- every one of them is an f32 number, so the search is the f32 one's, bit for bit)
+#define E2E_GEN_OF(IO) (!lm ? (const void*)&ctc_beam_general_kernel<IO, 0> : fast_lm ? (const void*)&ctc_beam_general_kernel<IO, 2> : (const void*)&ctc_beam_general_kernel<IO, 1>)
+    const void* gfn = dtype == E2E_F32 ? E2E_GEN_OF(float) : dtype == E2E_F64 ? E2E_GEN_OF(double) : dtype == E2E_F16 ? E2E_GEN_OF(f16_t) : E2E_GEN_OF(bf16_t);
+#undef E2E_GEN_OF
     E2E_HIP_CHECK(allow_dynamic_lds(gfn, (int)gl.lds), "hipFuncSetAttribute");
     void* gargs[] = { &p, &g };
     E2E_HIP_CHECK(hipLaunchKernel(gfn, dim3(B), dim3(kGenThreads), gargs, gl.lds, s), "ctc_beam_general_kernel launch");
     E2E_HIP_CHECK(hipGetLastError(), "ctc_beam_general_kernel launch");
     return E2E_OK;
   }
-  const void* fn;
-  if (dtype == E2E_F32)
-    fn = !lm ? (const void*)&ctc_beam_kernel<float, 0, kThreadsNoLm>
-             : fast_lm ? (const void*)&ctc_beam_kernel<float, 2, kThreadsLm> : (const void*)&ctc_beam_kernel<float, 1, kThreadsLm>;
-  else
-    fn = !lm ? (const void*)&ctc_beam_kernel<double, 0, kThreadsNoLm>
-             : fast_lm ? (const void*)&ctc_beam_kernel<double, 2, kThreadsLm> : (const void*)&ctc_beam_kernel<double, 1, kThreadsLm>;
+#define E2E_BEAM_OF(IO) (!lm ? (const void*)&ctc_beam_kernel<IO, 0, kThreadsNoLm> : fast_lm ? (const void*)&ctc_beam_kernel<IO, 2, kThreadsLm> : (const void*)&ctc_beam_kernel<IO, 1, kThreadsLm>)
+  const void* fn = dtype == E2E_F32 ? E2E_BEAM_OF(float) : dtype == E2E_F64 ? E2E_BEAM_OF(double) : dtype == E2E_F16 ? E2E_BEAM_OF(f16_t) : E2E_BEAM_OF(bf16_t);
+#undef E2E_BEAM_OF
   const int nthreads = lm ? kThreadsLm : kThreadsNoLm;
   E2E_HIP_CHECK(allow_dynamic_lds(fn, (int)l.lds), "hipFuncSetAttribute");
   void* args[] = { &p };

@@ -213,12 +213,13 @@ class CTCDecoderEngine:
             rows = rows.tolist()
         return ["".join(self.labels[k] for k in row[:n] if k >= 0) for row, n in zip(rows, lens)]
 
-    def _prep(self, logits_, logits_lengths_, native16=False):
+    def _prep(self, logits_, logits_lengths_, native16=True):
         if logits_.dim() != 3:
             raise ValueError("logits must be (batch, time, alphabet)")
         dev = R.compute_device(logits_)
         x = logits_.detach()
-        # (16-bit logits: the greedy kernels compare them as they are; the beam search takes f32 / f64 log-probabilities)
+        # (16-bit inputs: the greedy kernels compare them as they are, the beam search reads them as they are -- each is an f32
+        #  number, so the search is the f32 one's; upstream converts whatever arrives once, ctc_decoder.cpp:157-160)
         if x.dtype not in ((torch.float32, torch.float64, torch.float16, torch.bfloat16) if native16 else (torch.float32, torch.float64)):
             x = x.to(torch.float32)
         x = x.to(dev)
@@ -238,7 +239,7 @@ class CTCDecoderEngine:
 
     def decode_greedy(self, logits_, logits_lengths_):
         """argmax + blank/repeat collapse -> (targets (B,Tmax) int64 zero padded, lengths (B), sentences)."""
-        x, xl, dev = self._prep(logits_, logits_lengths_, native16=True)
+        x, xl, dev = self._prep(logits_, logits_lengths_)
         B, T, V = x.shape
         out = torch.empty((B, T), dtype=torch.long, device=dev)
         out_len = torch.empty(B, dtype=torch.long, device=dev)

@@ -18,7 +18,7 @@ def get_alignment_3d(log_probs, targets, logits_lengths, targets_lengths, is_ctc
         raise ValueError("log_probs must be (batch, time, alphabet)")
     dev = R.compute_device(log_probs)
     x = log_probs.detach()
-    if x.dtype not in (torch.float32, torch.float64):
+    if x.dtype not in (torch.float32, torch.float64, torch.float16, torch.bfloat16):      # (16-bit log-probabilities are read as they are)
         x = x.to(torch.float32)
     x = x.to(dev)
     B, T, V = x.shape

@@ -187,7 +187,8 @@ double e2e_lm_score(const e2e_lm* lm, const uint32_t* ctx /* host */, int ctx_le
  * Prefix beam search.  Replaces cpp_ctc_decoder.CTCDecoder.decode
  *   src/decoders/ctc_decoder.cpp:153-201 (driver), :353-441 (decode_sentence),
  *   :247-312 (get_next_prefix), :314-318 (score).
- *   lp        (B,T,V) LOG-PROBABILITIES, strides sB,sT,sV, f32/f64
+ *   lp        (B,T,V) LOG-PROBABILITIES, strides sB,sT,sV, f32 / f64 / f16 / bf16 (16-bit values are read as they are: the
+ *             search is the one of their f32 images, bit for bit)
  *   space_id  index of " " among the labels, or -1 (:55-59)
  *   lm        NULL for none (lmwt then counts as 0, :72-74); else a model loaded on the current device
  *             with exactly V labels (E2E_ERR_ARG otherwise)
@@ -227,7 +228,7 @@ int e2e_ctc_beam(const void* lp, int dtype, int64_t sB, int64_t sT, int64_t sV,
  * Replaces pytorch_end2end/utils/alignment.py:50-106 (_get_alignment_ctc_1d), :10-47
  * (_get_alignment_asg_1d, is_ctc = 0: no blanks) and the batch driver :109-138
  * (get_alignment_3d), which run as numba-jitted Python on the host upstream.
- *   lp        (B,T,V) LOG-PROBABILITIES, strides sB,sT,sV, f32/f64 (alpha is f64 either way, as upstream)
+ *   lp        (B,T,V) LOG-PROBABILITIES, strides sB,sT,sV, f32 / f64 / f16 / bf16 (alpha is f64 either way, as upstream)
  *   targets   (B,*) int64, first t_len[b] entries used; x_len, t_len (B) int64
  *   blank     the blank id (upstream hard-codes 0, :57); ignored when is_ctc = 0
  *   out       (B,T) int64: out[b, t] = the label (or blank) frame t is aligned to for t < x_len[b], pad_value beyond

@@ -83,3 +83,17 @@ def test_invalid_rows_are_padding_and_errors_are_reported():
     assert (got[1] == -100).all() and (got[2] == -100).all() and (got[0] >= 0).all()
     L = _lib.load()
     assert L.e2e_ctc_align(None, 7, 1, 1, 1, None, 0, None, None, 1, 1, 1, 0, 0, 1, None, 0, None, 0, None) == -1
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_sixteen_bit_log_probabilities_are_aligned_as_their_f32_images(dtype):
+    """get_alignment_3d reads f16 / bf16 log-probabilities as they are (no up-cast pass): the result is the f32 call's on the same
+    values, bit for bit."""
+    from end2end_amd.utils.alignment import get_alignment_3d
+    g = torch.Generator().manual_seed(8)
+    lp16 = torch.log_softmax(torch.randn(4, 120, 29, generator=g) * 2, -1).to(dtype)
+    tg = torch.randint(1, 29, (4, 30), generator=g)
+    xl, tl = torch.tensor([120, 100, 77, 120]), torch.tensor([30, 12, 25, 1])
+    a16 = get_alignment_3d(lp16.cuda(), tg, xl, tl)
+    a32 = get_alignment_3d(lp16.float().cuda(), tg, xl, tl)
+    assert torch.equal(torch.as_tensor(a16), torch.as_tensor(a32))

@@ -491,3 +491,19 @@ def test_whole_suite_through_the_general_kernel():
                          env=env, capture_output=True, text=True, timeout=1500,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("V,W", [(29, 100), (29, 20), (600, 40)], ids=["V29_W100", "V29_W20", "V600_W40_general"])
+def test_sixteen_bit_log_probabilities_are_searched_as_their_f32_images(dtype, V, W):
+    """The beam search reads f16 / bf16 log-probabilities as they are (no up-cast pass; upstream converts whatever arrives once,
+    ctc_decoder.cpp:157-160): every such value is an f32 number, so the result must be the f32 call's on the same values,
+    bit for bit."""
+    g = torch.Generator().manual_seed(V + W)
+    lp16 = torch.log_softmax(torch.randn(3, 70, V, generator=g) * 3, -1).to(dtype)
+    xl = [70, 51, 64]
+    labels = (["_"] + [chr(97 + i) for i in range(26)] + [" ", "'"]) if V == 29 else None
+    ids16, len16 = U.c_abi_beam(lp16, xl, 0, W, labels, wip=1.0 if labels else 0.0)
+    ids32, len32 = U.c_abi_beam(lp16.float(), xl, 0, W, labels, wip=1.0 if labels else 0.0)
+    assert len16.tolist() == len32.tolist() and ids16.tolist() == ids32.tolist()
+    assert (len16 > 0).all()

@@ -41,6 +41,8 @@ def test_bench_runs_under_the_launcher_and_reduces_over_rccl():
     assert out["n_gpus"] == n and out["steps"] == 3 and out["scaling"] == "weak"
     assert "RCCL all_reduce" in out["config"]["api"]
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    # the shipped module's own leg (ShardedCTCLoss + backward, one synchronous all-reduce per call) beside the C-ABI leg
+    assert out["sharded_module_ms_per_step"] > 0 and "ShardedCTCLoss" in out["sharded_module_api"]
     # weak scaling: every rank has its own 256 utterances
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 - n * 256 * 1000) <= 1e-6 * n * 256 * 1000
 
