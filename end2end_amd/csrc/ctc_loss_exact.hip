@@ -819,7 +819,6 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
 
 constexpr int kFlagCache = 2048;    // utterances whose flag words and segment counts a workgroup keeps in LDS
 constexpr int kRedoFailed = 512;    // flag bit set by the segment redo
-constexpr int kRedoSettled = 1024;  // ... and by the slab owner that then recomputed the utterance in full (2b.)
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
