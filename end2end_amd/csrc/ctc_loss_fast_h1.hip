@@ -518,7 +518,8 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
   };
   if (p.xdt == E2E_F32) run(std::true_type{}); else run(std::false_type{});
   // (see prep_wave: emissions near the end of f32 -> the utterance is recomputed entirely by the exact kernel)
-  if (DIR == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], __any(lpmin < -78.f) ? 64 | 256 : 64); }       // e^-69 = 2^-100
+  { const bool t1 = __any(lpmin < -69.f), t2 = __any(lpmin < -78.f);      // (both votes by the whole wave, outside the lane test)
+    if (DIR == 0 && t1 && lane == 0) atomicOr(&p.flags[b], t2 ? 64 | 256 : 64); }       // e^-69 = 2^-100
 }
 
 // The checkpoint wave of a direction: reads a checkpoint row's true cells in lattice order (pair i: cells 2i, 2i+1), finds the

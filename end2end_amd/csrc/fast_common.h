@@ -540,7 +540,8 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
   // entirely by the exact kernel, never by the f64 redo of the segments alone, which would keep the chains' loss.
   // (bit 256 on top: a finite log-probability below -78 -- within a few bits of where an f32 probability stops being a normal
   //  number -- , which the extended-range redo cannot take from the table either: the exact kernel's own softmax)
-  if (dir == 0 && __any(lpmin < -69.f)) { if (lane == 0) atomicOr(&p.flags[b], __any(lpmin < -78.f) ? 64 | 256 : 64); }       // e^-69 = 2^-100
+  { const bool t1 = __any(lpmin < -69.f), t2 = __any(lpmin < -78.f);      // (both votes by the whole wave, outside the lane test)
+    if (dir == 0 && t1 && lane == 0) atomicOr(&p.flags[b], t2 ? 64 | 256 : 64); }       // e^-69 = 2^-100
 #ifdef E2E_FAST_PROFILE
   if (lane == 0 && b < 256 && first == 0) { g_prof[(b * 4 + 2 + dir) * 4 + 0] = __builtin_amdgcn_s_memtime() - prof_t0; g_prof[(b * 4 + 2 + dir) * 4 + 1] = prof_spin; }
 #endif
@@ -622,7 +623,8 @@ __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T,
   }
   // Probabilities are f32: below ~2^-126 they are flushed (see prep_wave: reason bit 64, the exact kernel recomputes the
   // utterance); the launch that filled ytab left kTinyProb wherever a finite log-probability lay below -69
-  if (dir == 0 && __any(tiny)) { if (lane == 0) atomicOr(&p.flags[b], __any(tiny2) ? 64 | 256 : 64); }
+  { const bool t1 = __any(tiny), t2 = __any(tiny2);                      // (both votes by the whole wave, outside the lane test)
+    if (dir == 0 && t1 && lane == 0) atomicOr(&p.flags[b], t2 ? 64 | 256 : 64); }
 }
 
 // Per-utterance lattice description for F2, computed once here instead of once per 16-step segment there (63x at

@@ -111,3 +111,20 @@ def test_logprob_input_with_impossible_symbols_in_extended_range():
     la, ga = U.c_abi_loss(lp.float(), tg, xl, tl, 0, True, _lib.ALGO_AUTO)
     U.assert_same(la, l_o, F32_RTOL, 2e-5, "losses")
     U.assert_same(ga, g_o, F32_RTOL, F32_ATOL, "grads")
+
+
+@pytest.mark.parametrize("V", [40, 150], ids=["segment_table_V40", "row_table_V150"])
+def test_probabilities_at_the_end_of_f32_go_where_they_can_be_held(V):
+    """Sharp unrelated emissions with, on top, a frame whose blank -- which nearly every path of a three-label transcript crosses --
+    has log-probability -74 (utterance 1: below 2^-100, flag 64, but a normal f32 number: the extended-range redo takes it from the
+    fast path's table) or -82 (utterance 0: the table holds a marker instead, flag 256: only the exact kernel's own softmax can
+    serve it).  Round 5 shipped this for an hour with the 256 vote taken inside `if (lane == 0)`: the marker was then used as a
+    probability and the loss came out 4.4 nats off with perfect gradients (tools/diag/fuzz_ext_vs_oracle.py, case 196 of seed 3)."""
+    rng = np.random.default_rng(V)
+    B, T, S = 4, 400, 3
+    x = (rng.standard_normal((B, T, V)) * 8.0).astype(np.float32)
+    x[0, 100, 0] = x[0, 100].max() - 82.0
+    x[1, 100, 0] = x[1, 100].max() - 74.0
+    x[1, 300, 0] = x[1, 300].max() - 71.0
+    tg = rng.integers(1, V, size=(B, S)); tl = np.full(B, S); xl = np.array([T, T, T - 13, T])
+    check(x, tg, xl, tl, want_unsettled=None, loss_atol=2e-5)

@@ -64,6 +64,10 @@ for case in range(n_cases):
     except AssertionError as e:
         bad += 1
         if os.environ.get("FUZZ_ONLY"):
+            fl = (ctypes.c_int * B)(); lz = (ctypes.c_double * (2 * B))()
+            L.e2e_debug_fast_state.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
+            L.e2e_debug_fast_state(keep["workspace"].data_ptr(), B, T, V, Smax, fl, lz)
+            print(" flag words:", list(fl))
             for b in range(B):
                 nn = np.argwhere(np.isnan(ga[b]) != np.isnan(g_o[b]))
                 d = np.abs(np.nan_to_num(ga[b].astype(np.float64)) - np.nan_to_num(g_o[b]))
