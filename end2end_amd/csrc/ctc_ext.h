@@ -332,7 +332,7 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
 // (out of line: inside the flagged kernel -- 255 registers, its own spills -- the chains' loops spilled too; as a function of
 //  their own they get their own register allocation.  The dynamic LDS is found again through its own declaration.)
 template <typename IO>
-__device__ __attribute__((noinline)) void ext_chains(const ExactParams& p, int b) {
+__device__ __forceinline__ void ext_chains(const ExactParams& p, int b) {
   extern __shared__ __align__(16) unsigned char smem[];
   typedef typename LossOf<IO>::type LT;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -380,7 +380,7 @@ __device__ __attribute__((noinline)) void ext_chains(const ExactParams& p, int b
 // One (utterance, 16-step segment) on this workgroup: wave c takes the label pairs 32 c .. 32 c + 31 (its lanes hold the
 // pairs 32 c - 16 .. 32 c + 47: what the 16 steps can reach from either side), c = wid, wid + 8, ...
 template <typename IO>
-__device__ __attribute__((noinline)) void ext_segment(const ExactParams& p, int b, int seg) {
+__device__ __forceinline__ void ext_segment(const ExactParams& p, int b, int seg) {
   extern __shared__ __align__(16) unsigned char smem[];
   const FastRetry& rt = p.retry;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;

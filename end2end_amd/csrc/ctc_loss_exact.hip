@@ -331,6 +331,9 @@ __device__ __forceinline__ bool retry_segment_f64(const ExactParams& p, unsigned
   return !__any(bad);
 }
 
+#ifndef E2E_EXT_ON                   // (tools/diag: 0 compiles the extended-range redo out of the flagged kernel)
+#define E2E_EXT_ON 1
+#endif
 #include "ctc_ext.h"
 
 // One utterance b, with the alpha slab `slot` of the workspace.
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   // flagged for its numbers, not for its inputs (1: lengths, 2: blank inside the targets, 128: protocol, 256: probabilities the f32
   // table cannot hold; 64 alone -- probabilities below 2^-100 but still normal f32 numbers -- is a matter of range)
   auto ext_candidate = [&](int f) -> bool {
-    return p.mode == 1 && p.has_ext && ((f & (4 | 32 | 64)) != 0 || (!p.has_retry && (f & (8 | 16)) != 0)) && (f & (1 | 2 | 128 | 256)) == 0;
+    return E2E_EXT_ON && p.mode == 1 && p.has_ext && ((f & (4 | 32 | 64)) != 0 || (!p.has_retry && (f & (8 | 16)) != 0)) && (f & (1 | 2 | 128 | 256)) == 0;
   };
 
   if (p.mode == 2) {
@@ -958,24 +961,18 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
         __syncthreads();
       }
     };
-    int nx0 = 0;
-    if (p.has_ext) {
+    if (E2E_EXT_ON && p.has_ext) {
       bool mine = false;
       for (int b = tid; b < p.B; b += kThreads) mine |= ext_candidate(flag_of(b));
       any_ext0 = __syncthreads_or(mine ? 1 : 0) != 0;
-      build_list(0);
-      nx0 = s_next;
-      for (int i = blockIdx.x; i < nx0; i += gridDim.x) ext_chains<IO>(p, s_xb[i]);
     }
-    stamp(1);
-    // ---- 1. segments of the utterances flagged for range only: item i of the running list goes to wave i mod NW.  (The
-    //      workgroups that run round 0's chains take none, unless that is all of them: a chain is ~0.1 ms, a segment ~50 us.) ----
-    const int chain_wgs = nx0 < (int)gridDim.x ? nx0 : 0;
-    const int NW = ((int)gridDim.x - chain_wgs) * p.redo_waves;
-    const int me = (int)blockIdx.x >= chain_wgs ? ((int)blockIdx.x - chain_wgs) * p.redo_waves + wid : -1;
+    // ---- 1. segments of the utterances flagged for range only: item i of the running list goes to wave i mod NW.  (Only when no
+    //      utterance needs the extended-range chains: otherwise the range-flagged ones join those, and this step has nothing to do.) ----
+    const int NW = (int)gridDim.x * p.redo_waves;
+    const int me = (int)blockIdx.x * p.redo_waves + wid;
     unsigned char* wsmem = smem + (size_t)wid * retry_wave_lds_bytes(p.V, p.retry.PPL);
     int base = 0;
-    for (int c0 = 0; c0 < p.B && wid < p.redo_waves && me >= 0; c0 += 64) {
+    for (int c0 = 0; c0 < p.B && wid < p.redo_waves; c0 += 64) {
       const int bb = c0 + lane;
       const int f = bb < p.B ? flag_of(bb) : 0;
       // (only the segments that failed in the segment kernel: the others' rows passed their self-check and stay)
@@ -1021,41 +1018,51 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
       base += tot;
     }
     __syncthreads();                         // (the waves' LDS is taken over by what follows)
-    stamp(2);
-    if (p.has_ext) {
-      if (nx0 > 0) ext_segments_of_list(nx0);
-      stamp(3);
-      // Round 1.  Have all workgroups finished step 1?  Bounded wait (a grid that is not resident at once -- a partitioned or
-      // shared GPU -- must not hang): all workgroups adopt ONE decision, 1 = everybody arrived, 2 = some wait ran out (then
-      // what step 1 could not settle is left to step 3).  No wait at all when step 1 had nothing to do.
-      bool any_range = false;
-      for (int b = tid; b < p.B; b += kThreads) any_range |= range_only(flag_of(b));
-      if (__syncthreads_or(any_range ? 1 : 0)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (tid == 0) {
-          atomicAdd(&p.ctl[2], 1);
-          int spins = 0;
-          while (__hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x &&
-                 __hip_atomic_load(&p.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 15))
-            __builtin_amdgcn_s_sleep(8);
-          const int mine = __hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x ? 1 : 2;
-          const int was = atomicCAS(&p.ctl[3], 0, mine);
-          s_dec = was != 0 ? was : mine;
-          if (was == 0 && mine == 2) atomicAdd(&p.ctl[4], 1);       // (diagnostics: a wait ran out)
-          // (has any redo failed at all?  ctl[5] counts them: the usual answer is no, and the list need not be built)
-          if (s_dec == 1 && __hip_atomic_load(&p.ctl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) s_dec = 3;
-        }
-        __syncthreads();
-        if (s_dec == 1) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          for (int b = tid; b < p.B && b < kFlagCache; b += kThreads)     // the flag words as they are now, in one round trip
-            s_flag[b] = (unsigned short)(__hip_atomic_load(&p.flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (2 * kRedoFailed - 1));
+    stamp(1);
+    if (E2E_EXT_ON && p.has_ext) {
+      // Which round?  0 (known from the start): some utterance needs the chains -- alpha / beta log Z mismatch, a partition sum out
+      // of range, probabilities below 2^-100 -- and everything flagged for its numbers goes with it.  1: step 1 ran, and some redo
+      // could not settle its utterance.  To learn that, every workgroup has to have finished step 1: a bounded wait (a grid
+      // that is not resident at once -- a partitioned or shared GPU -- must not hang); all workgroups adopt ONE decision, 1 =
+      // everybody arrived and some redo failed, 2 = some wait ran out (then what step 1 could not settle is left to step 3),
+      // 3 = everybody arrived, nothing failed (the usual case: ctl[5] counts the failures).  No wait when step 1 had nothing to do.
+      int round = any_ext0 ? 0 : -1;
+      if (!any_ext0) {
+        bool any_range = false;
+        for (int b = tid; b < p.B; b += kThreads) any_range |= range_only(flag_of(b));
+        if (__syncthreads_or(any_range ? 1 : 0)) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
           __syncthreads();
-          build_list(1);
-          const int nx1 = s_next;
-          for (int i = blockIdx.x; i < nx1; i += gridDim.x) ext_chains<IO>(p, s_xb[i]);
-          if (nx1 > 0) ext_segments_of_list(nx1);
+          if (tid == 0) {
+            atomicAdd(&p.ctl[2], 1);
+            int spins = 0;
+            while (__hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x &&
+                   __hip_atomic_load(&p.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 15))
+              __builtin_amdgcn_s_sleep(8);
+            const int mine = __hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x ? 1 : 2;
+            const int was = atomicCAS(&p.ctl[3], 0, mine);
+            s_dec = was != 0 ? was : mine;
+            if (was == 0 && mine == 2) atomicAdd(&p.ctl[4], 1);       // (diagnostics: a wait ran out)
+            if (s_dec == 1 && __hip_atomic_load(&p.ctl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) s_dec = 3;
+          }
+          __syncthreads();
+          if (s_dec == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int b = tid; b < p.B && b < kFlagCache; b += kThreads)     // the flag words as they are now, in one round trip
+              s_flag[b] = (unsigned short)(__hip_atomic_load(&p.flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (2 * kRedoFailed - 1));
+            __syncthreads();
+            round = 1;
+          }
+        }
+      }
+      stamp(2);
+      if (round >= 0) {
+        build_list(round);
+        const int nx = s_next;
+        for (int i = blockIdx.x; i < nx; i += gridDim.x) ext_chains<IO>(p, s_xb[i]);
+        stamp(3);
+        if (nx > 0) ext_segments_of_list(nx);
+        if (round == 1) {
           for (int b = tid; b < p.B && b < kFlagCache; b += kThreads) s_flag[b] &= (unsigned short)(kRedoFailed - 1);
           __syncthreads();
         }

@@ -2002,9 +2002,9 @@ extern "C" int e2e_debug_fast_redo_failures(const void* workspace, int B, int T,
   *count_host = ctl[1];
   return E2E_OK;
 }
-// Diagnostics: the flagged-utterance launch's phases as workgroup 0 saw them, in microseconds since its start: end of its
-// extended-range chains (round 0), of its f64 redos of single segments, of its extended-range segments (round 0), of the wait for
-// the other workgroups and round 1, and the end of the launch's last workgroup.  Zeros if nothing was flagged.  Synchronises.
+// Diagnostics: the flagged-utterance launch's phases as workgroup 0 saw them, in microseconds since its start: end of its f64
+// redos of single segments, of the wait for the other workgroups, of its extended-range chains, of its extended-range segments,
+// and the end of the launch's last workgroup.  Zeros if nothing was flagged.  Synchronises.
 extern "C" int e2e_debug_flagged_phases(const void* workspace, int B, int T, int V, int Smax, double* us_host) {
   uintptr_t base = reinterpret_cast<uintptr_t>(workspace);
   const char* ws = reinterpret_cast<const char*>((base + 255) & ~(uintptr_t)255);

@@ -30,9 +30,8 @@ int e2e_debug_fast_state(const void* workspace, int B, int T, int V, int Smax, i
 int e2e_debug_fast_redo_failures(const void* workspace, int B, int T, int V, int Smax, int* count_host);
 
 /* The flagged-utterance launch of that call as its workgroup 0 saw it, microseconds since the launch's start (100 MHz clock):
- * us[0] end of its extended-range chains (round 0), [1] of its f64 redos of single segments, [2] of its extended-range segments
- * (round 0), [3] of the wait for the other workgroups and of round 1, [4] end of the launch's last workgroup.  Zeros when nothing
- * was flagged.  Synchronises. */
+ * us[0] end of its f64 redos of single segments, [1] of the wait for the other workgroups, [2] of its extended-range chains,
+ * [3] of its extended-range segments, [4] end of the launch's last workgroup.  Zeros when nothing was flagged.  Synchronises. */
 int e2e_debug_flagged_phases(const void* workspace, int B, int T, int V, int Smax, double* us_host);
 
 #ifdef E2E_FAST_PROFILE   /* only in builds made by tools/diag/build_profile_lib.sh */

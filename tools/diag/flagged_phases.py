@@ -15,7 +15,7 @@ def run(name, host):
     ms = bench.time_events(torch, lambda: hp.call(hp.means[0, :1]), 5)
     us = (ctypes.c_double * 5)()
     L.e2e_debug_flagged_phases(hp.ws.data_ptr(), B, T, V, S, us)
-    print("%-16s %.3f ms per call; flagged launch: chains0 %.0f, redo %.0f, segments0 %.0f, wait + round 1 %.0f, end %.0f us" % (name, ms, *us))
+    print("%-16s %.3f ms per call; flagged launch: redo %.0f, wait %.0f, chains %.0f, segments %.0f, end %.0f us" % (name, ms, *us))
 x, tg, xl, tl = bench.aligned_batch(10, B, T, V, S, 10.0)
 tg2, tl2 = tg.clone(), tl.clone()
 for k in range(8): tg2[32 * k], tl2[32 * k] = tg[32 * k + 1], tl[32 * k + 1]
