@@ -584,7 +584,7 @@ __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T,
     for (int k = 0; k < NV; k++) out[k] = yr[l8 + 8 * k < V ? 8 * k : 0];
   };
   int consumed = 0;
-  bool tiny = false, tiny2 = false;
+  float ymin = 1.f;                 // smallest POSITIVE probability this wave has moved (one select + one minimum per element)
   auto process = [&](int n, const float (&yraw)[NV]) {
     if (n >= nblk) return;
     const int t = block_time(dir, n, tt, T);
@@ -597,7 +597,7 @@ __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T,
       const int v = l8 + 8 * k;
       if (v < V) {
         const float y = row_live ? yraw[k] : 0.f;
-        tiny |= y > 0.f && y < 1e-30f; tiny2 |= y > 0.f && y < 2e-37f;
+        ymin = fminf(ymin, y > 0.f ? y : 1.f);
         blk32[v * kRow32 + tt] = y;                                        // transposed: [label][step]
       }
     }
@@ -623,7 +623,7 @@ __device__ __forceinline__ void prep_wave_big(const FastParams& p, int b, int T,
   }
   // Probabilities are f32: below ~2^-126 they are flushed (see prep_wave: reason bit 64, the exact kernel recomputes the
   // utterance); the launch that filled ytab left kTinyProb wherever a finite log-probability lay below -69
-  { const bool t1 = __any(tiny), t2 = __any(tiny2);                      // (both votes by the whole wave, outside the lane test)
+  { const bool t1 = __any(ymin < 1e-30f), t2 = __any(ymin < 2e-37f);      // (both votes by the whole wave, outside the lane test)
     if (dir == 0 && t1 && lane == 0) atomicOr(&p.flags[b], t2 ? 64 | 256 : 64); }
 }
 
