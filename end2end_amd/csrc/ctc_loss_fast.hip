@@ -2016,6 +2016,19 @@ extern "C" int e2e_debug_flagged_phases(const void* workspace, int B, int T, int
   us_host[4] = st[0] && st[6] ? (double)(long long)(st[6] - st[0]) * 0.01 : 0.0;
   return E2E_OK;
 }
+// Diagnostics: bounded waits of the flagged-utterance launch that ran out (ctl[4]: a workgroup gave up waiting for the others, or a
+// segment for its utterance's chains -- what they left undone was recomputed by the exact kernel) and redos of single segments
+// that failed (ctl[5]).  Both 0 on an idle GPU.  Synchronises.
+extern "C" int e2e_debug_flagged_counters(const void* workspace, int B, int T, int V, int Smax, int* timeouts_host, int* failed_redos_host) {
+  uintptr_t base = reinterpret_cast<uintptr_t>(workspace);
+  const char* ws = reinterpret_cast<const char*>((base + 255) & ~(uintptr_t)255);
+  const e2e::FastLayout l = e2e::fast_layout(B, T, V, Smax);
+  if (hipDeviceSynchronize() != hipSuccess) return E2E_ERR_HIP;
+  int ctl[8];
+  if (hipMemcpy(ctl, ws + l.ctl, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) return E2E_ERR_HIP;
+  *timeouts_host = ctl[4]; *failed_redos_host = ctl[5];
+  return E2E_OK;
+}
 extern "C" int e2e_debug_fast_state(const void* workspace, int B, int T, int V, int Smax, int* flags_host, double* logz_host) {
   uintptr_t base = reinterpret_cast<uintptr_t>(workspace);
   const char* ws = reinterpret_cast<const char*>((base + 255) & ~(uintptr_t)255);

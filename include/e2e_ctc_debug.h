@@ -34,6 +34,10 @@ int e2e_debug_fast_redo_failures(const void* workspace, int B, int T, int V, int
  * [3] of its extended-range segments, [4] end of the launch's last workgroup.  Zeros when nothing was flagged.  Synchronises. */
 int e2e_debug_flagged_phases(const void* workspace, int B, int T, int V, int Smax, double* us_host);
 
+/* Bounded waits of that call's flagged-utterance launch that ran out (0 on an idle GPU; what they left undone was recomputed by the
+ * exact kernel) and f64 redos of single segments that failed (handed to the extended-range redo).  Synchronises. */
+int e2e_debug_flagged_counters(const void* workspace, int B, int T, int V, int Smax, int* timeouts_host, int* failed_redos_host);
+
 #ifdef E2E_FAST_PROFILE   /* only in builds made by tools/diag/build_profile_lib.sh */
 int e2e_debug_fast_zdev(float* host, int reset);
 int e2e_debug_fast_profile(unsigned long long* host, int n);

@@ -39,10 +39,14 @@ def aligned(rng, B, T, V, S, boost, blank=0, short=()):
 
 
 def unsettled(keep, B, T, V, S):
+    """utterances the exact kernel had to recompute in full; also: no bounded wait of the flagged launch may have run out"""
     L = _lib.load()
     L.e2e_debug_fast_redo_failures.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
-    cnt = ctypes.c_int(-1)
+    L.e2e_debug_flagged_counters.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
+    cnt, to, fr = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
     assert L.e2e_debug_fast_redo_failures(keep["workspace"].data_ptr(), B, T, V, S, ctypes.byref(cnt)) == 0
+    assert L.e2e_debug_flagged_counters(keep["workspace"].data_ptr(), B, T, V, S, ctypes.byref(to), ctypes.byref(fr)) == 0
+    assert to.value == 0, "%d bounded waits of the flagged launch ran out" % to.value
     return cnt.value
 
 
@@ -128,3 +132,26 @@ def test_probabilities_at_the_end_of_f32_go_where_they_can_be_held(V):
     x[1, 300, 0] = x[1, 300].max() - 71.0
     tg = rng.integers(1, V, size=(B, S)); tl = np.full(B, S); xl = np.array([T, T, T - 13, T])
     check(x, tg, xl, tl, want_unsettled=None, loss_atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_sixteen_bit_logits_through_the_extended_range_redo(dtype):
+    """16-bit logits (read natively, gradient written in the same type, losses f32) with sharp unrelated emissions: the flagged
+    launch's 16-bit instances carry the extended-range redo too.  Against the oracle on the rounded logits, at the output type's
+    resolution."""
+    rng = np.random.default_rng(12)
+    B, T, V, S = 4, 500, 29, 100
+    x16 = torch.from_numpy((rng.standard_normal((B, T, V)) * 8.0).astype(np.float32)).to(dtype)
+    tg = rng.integers(1, V, size=(B, S)); tl = rng.integers(S // 2, S + 1, size=B); xl = np.array([T, T - 30, T, 411])
+    lp = torch.log_softmax(x16.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg, xl, tl, 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0.0
+    keep = {}
+    lf, _ = U.c_abi_loss(x16, tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    assert np.isnan(lf).sum() >= 2, "this input no longer drives utterances off the f32 lattice"
+    la, ga = U.c_abi_loss(x16, tg, xl, tl, 0, False, _lib.ALGO_AUTO, keep=keep)
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    U.assert_same(la, l_o, 1e-4, 2e-5, "losses")
+    U.assert_same(ga, g_o, 2 * eps, 2e-6, "grads")
+    assert unsettled(keep, B, T, V, S) == 0
