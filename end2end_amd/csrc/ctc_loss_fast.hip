@@ -917,7 +917,10 @@ constexpr float kZTol = E2E_ZTOL;   // |log2| tolerance of the rows' self-check 
 #define E2E_ZTOL_F32 1e-5f
 #endif
 constexpr float kZTolF32 = E2E_ZTOL_F32;   // the same with f32 chains (ctc_fast_chain_hf_kernel), whose own rounding reaches 3e-6
-constexpr int kYs = kSeg + 4;      // row stride (floats) of the transposed probability tile: 80 B spreads the
+#ifndef E2E_KYS
+#define E2E_KYS (kSeg + 4)
+#endif
+constexpr int kYs = E2E_KYS;      // row stride (floats) of the transposed probability tile: 80 B spreads the
                                    // 16-byte gathers of different labels over the LDS bank row
 
 template <int PPL>
@@ -1091,7 +1094,7 @@ __device__ __forceinline__ void finish_rows(const P& p, int b, int t0, int n, in
             if (FULL || k < rows) {
               const float pv = (pre_hi[k * PROW] - pre_lo[k * PROW]) + gl.isblank[s] * btot8[k];
               const float g = (yrow[k] - pv * __builtin_amdgcn_rcpf(st8[k])) * p.gscale;
-              if (v < V) put((size_t)k * V + v, g);
+              if (v < V && (!(E2E_F2_ABL & 64) || g == 1234.5f)) put((size_t)k * V + v, g);
             }
           }
         }
@@ -1590,19 +1593,31 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   int s0 = 0, s1 = 0, s2 = 0;
   if (!BIG) { s0 = ls[lane]; s1 = ls[64 + lane]; s2 = ls[128 + (lane & 1)]; }      // (BIG: up to 514 entries, copied below)
   // (b) the segment's probabilities.  Small alphabets: F1 left them as the tile is laid out here -- [label][16 steps] -- so a
-  //     lane's 16-byte load IS four steps of a label (<= 6 loads per lane for V <= 96).  BIG: 16*V consecutive floats of the
-  //     row-major table from the aligned address below, eight loads now, the rest after these have been staged
-  constexpr int kTileLoads = BIG ? 8 : (4 * kMaxSmallV + 63) / 64;
-  const size_t g0 = ((size_t)b * Tmax + t0) * V;
-  const size_t a0 = g0 & ~(size_t)3;
-  const int skew = (int)(g0 - a0);
+  //     lane's 16-byte load IS four steps of a label (<= 6 loads per lane for V <= 96).  BIG: the table is row-major [frame][V];
+  //     a lane takes COLUMNS -- 64 c + lane, the 16 steps of each in 16 four-byte loads (a wave's load is 256 consecutive bytes
+  //     of a row) -- so that what it holds afterwards is four 16-byte runs of the transposed tile.  Four chunks of 64 columns
+  //     now, the rest after these have been staged.  (Until round 5 a lane loaded 16 consecutive bytes of a row and scattered
+  //     them into the tile float by float: the writes of a wave went to two of the 32 banks -- the tile's rows are 80 bytes apart
+  //     -- and with five such waves on a CU staging alone was 14.9k of a segment's 34k cycles at 200 columns.)
+  constexpr int kTileLoads = BIG ? 1 : (4 * kMaxSmallV + 63) / 64;
+  constexpr int kColChunks = BIG ? 4 : 1;
   f4 tile[kTileLoads];
-  if (BIG) {
-    const f4* src = reinterpret_cast<const f4*>(p.ytab + a0);
+  float col[kColChunks][kSeg];
+  const int rlast = min(kSeg, Tmax - t0) - 1;            // (rows past the table's end are not touched: they are dead steps, zeroed below)
+  const float* csrc = p.ytab + ((size_t)b * Tmax + t0) * V;
+  auto load_cols = [&](int c0) {
 #pragma unroll
-    for (int j = 0; j < kTileLoads; j++)
-      if (4 * 64 * j < kSeg * V + skew) tile[j] = src[64 * j + lane];       // (uniform test)
-  } else {
+    for (int c = 0; c < kColChunks; c++) {
+      if (64 * (c0 + c) < V) {                                              // (uniform)
+        const int vo = min(64 * (c0 + c) + lane, V - 1);
+        const float* row = csrc;                                            // (a running scalar row address and one lane offset)
+#pragma unroll
+        for (int tt = 0; tt < kSeg; tt++) { col[c][tt] = row[vo]; row += tt < rlast ? V : 0; }
+      }
+    }
+  };
+  if (BIG) load_cols(0);
+  else {
     const f4* src = reinterpret_cast<const f4*>(p.ytab + ((size_t)b * p.NS + seg) * V * kSeg);
 #pragma unroll
     for (int j = 0; j < kTileLoads; j++)
@@ -1635,8 +1650,6 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
   if (BIG) { for (int i = lane; i < lstart_ints(V); i += 64) lds.starts[i] = ls[i]; }
   else { lds.starts[lane] = s0; lds.starts[64 + lane] = s1; if (lane < 2) lds.starts[128 + lane] = s2; }
   if (lane < kYs) lds.ys[V * kYs + lane] = 0.f;                           // the zero row V
-  if (BIG && n < kSeg)
-    for (int i = lane; i < kYs * V; i += 64) lds.ys[i] = 0.f;            // dead steps of a short last segment
   if (!BIG) {
     // one 16-byte LDS write per load: label (lane >> 2) + 16 j, steps 4 (lane & 3) .. + 3
     float* dst = lds.ys + (lane >> 2) * kYs + 4 * (lane & 3);
@@ -1653,35 +1666,23 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
       }
     }
   } else if (!(E2E_F2_ABL & 32)) {
-    // scatter the rows into the transposed tile
-    const int count = n * V;
-    const unsigned magic = (1u << 24) / (unsigned)V + 1u;                // idx / V, exact for idx < 2^24 / V (>= 37 449 > 16 * 448);
-                                                                           // idx * magic < 7 172 * 172 962 < 2^32 for V >= 97
-    auto scatter = [&](const f4 (&tl)[kTileLoads], int jbase) {
+    // the lane's columns into the transposed tile: four 16-byte writes per column
+    auto put_cols = [&](int c0) {
 #pragma unroll
-      for (int j = 0; j < kTileLoads; j++) {
-        if (4 * 64 * (jbase + j) < kSeg * V + skew) {
+      for (int c = 0; c < kColChunks; c++) {
+        const int v = 64 * (c0 + c) + lane;
+        if (64 * (c0 + c) < V && v < V) {
+          f4* dst = reinterpret_cast<f4*>(lds.ys + v * kYs);
 #pragma unroll
-          for (int c = 0; c < 4; c++) {
-            const int idx = 4 * (64 * (jbase + j) + lane) + c - skew;
-            if (idx >= 0 && idx < count) {
-              const int tt = (int)(((unsigned)idx * magic) >> 24);
-              lds.ys[(idx - tt * V) * kYs + tt] = tl[j][c];
-            }
-          }
+          for (int k = 0; k < kSeg / 4; k++) dst[k] = f4{col[c][4 * k], col[c][4 * k + 1], col[c][4 * k + 2], col[c][4 * k + 3]};
         }
       }
     };
-    scatter(tile, 0);
-    // the rest of the tile, a round of eight loads at a time (16 * 224 floats: two rounds in all)
-    for (int jbase = kTileLoads; 4 * 64 * jbase < kSeg * V + skew; jbase += kTileLoads) {
-      const f4* src = reinterpret_cast<const f4*>(p.ytab + a0);
-      f4 more[kTileLoads];
-#pragma unroll
-      for (int j = 0; j < kTileLoads; j++)
-        if (4 * 64 * (jbase + j) < kSeg * V + skew) more[j] = src[64 * (jbase + j) + lane];
-      scatter(more, jbase);
-    }
+    put_cols(0);
+    for (int c0 = kColChunks; 64 * c0 < V; c0 += kColChunks) { load_cols(c0); put_cols(c0); }      // (beyond 256 columns: a second round)
+    if (n < kSeg)                                                          // dead steps of a short last segment: zeros
+      for (int v = lane; v < V; v += 64)
+        for (int tt = n; tt < kSeg; tt++) lds.ys[v * kYs + tt] = 0.f;
   }
   if (lane < kHalf) lds.Ps[lane * F2Lds<PPL>::PROW - 1] = 0.f;           // the rows' zero guards
   F2_LDS_ORDER   // staged rows visible to this (single) wave

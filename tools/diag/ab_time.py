@@ -1,4 +1,4 @@
-"""A/B two builds of libe2e_ctc.so in ONE process on the headline shape (interleaved rounds, median)."""
+"""A/B two builds of libe2e_ctc.so in ONE process on the headline shape (interleaved rounds, median); AB_B / AB_T / AB_V / AB_S: another shape."""
 import ctypes as C, os, sys, statistics
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
@@ -12,7 +12,7 @@ def bind(path):
     return L
 libs = {os.path.basename(p): bind(os.path.join(root, p)) for p in sys.argv[1:]}
 d = torch.device("cuda", 0)
-B, T, V, S = 256, 1000, 29, int(os.environ.get("AB_S", "200"))
+B, T, V, S = (int(os.environ.get(k, v)) for k, v in (("AB_B", "256"), ("AB_T", "1000"), ("AB_V", "29"), ("AB_S", "200")))
 gen = torch.Generator().manual_seed(0)
 x = torch.randn(B, T, V, generator=gen).to(d); tg = torch.randint(1, V, (B, S), generator=gen).to(d)
 tl = torch.randint(S // 2, S + 1, (B,), generator=gen).to(d); xl = torch.full((B,), T).to(d)
