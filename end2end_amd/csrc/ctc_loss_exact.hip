@@ -903,6 +903,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
     return E2E_EXT_ON && p.mode == 1 && p.has_ext && ((f & (4 | 32 | 64)) != 0 || (!p.has_retry && (f & (8 | 16)) != 0)) && (f & (1 | 2 | 128 | 256)) == 0;
   };
 
+  bool last_by_arrival = false;       // (set where step 1's bounded wait already told which workgroup is the last: see step 3)
   if (p.mode == 2) {
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
       ctc_exact_one<IO, false>(p, smem, b, 0);      // (poisons flagged utterances, touches no slab)
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
     //      log Z mismatch (32), a partition sum out of range (4), probabilities below 2^-100 (64).  Round 1, known once every
     //      workgroup has reported the end of step 1: what the f64 redo of single segments could not settle (512).
     //      Chains: utterance i of a round's list on workgroup i mod grid; then every workgroup takes segments. ----
-    __shared__ int s_dec, s_next, s_go;
+    __shared__ int s_dec, s_next, s_go, s_lastarr;
     __shared__ int s_xb[kExtMaxList];                   // a round's list: utterance numbers ...
     __shared__ int s_xoff[kExtMaxList + 1];             // ... and the running count of their segments
     // the list of a round, in utterance order, the same in every workgroup (s_flag holds what the round looks at)
@@ -1034,7 +1035,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
           __syncthreads();
           if (tid == 0) {
-            atomicAdd(&p.ctl[2], 1);
+            s_lastarr = atomicAdd(&p.ctl[2], 1) == (int)gridDim.x - 1;
             int spins = 0;
             while (__hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x &&
                    __hip_atomic_load(&p.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 15))
@@ -1052,6 +1053,17 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
               s_flag[b] = (unsigned short)(__hip_atomic_load(&p.flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (2 * kRedoFailed - 1));
             __syncthreads();
             round = 1;
+          } else if (s_dec == 3) {
+            // Everybody is here and nothing is left for the extended-range redo.  If nothing is flagged for its inputs either
+            // (step 2), the launch is over but for step 3 -- and the last workgroup is known: the one that arrived last.  The
+            // others leave now, without a second release + ticket (256 workgroups released at the same moment by the wait and
+            // all writing back their L2 at once: 18 us at the headline shape).
+            bool hard = false;
+            for (int b = tid; b < p.B; b += kThreads) { const int f = flag_of(b); hard |= f != 0 && !range_only(f) && !ext_candidate(f); }
+            if (!__syncthreads_or(hard ? 1 : 0)) {
+              if (!s_lastarr) return;
+              last_by_arrival = true;
+            }
           }
         }
       }
@@ -1089,12 +1101,15 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   // ---- 3. the last workgroup to get here: what the segment redo could not settle, then the reduction ----
   // (release / acquire at agent scope: what other workgroups stored must have left their XCD's L2)
   __shared__ int s_last;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  if (tid == 0) s_last = atomicAdd(&p.ctl[0], 1) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (!s_last) return;
+  if (!last_by_arrival) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&p.ctl[0], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (tid == 0) { const unsigned long long t = wall_clock64(); p.ctl[26] = (int)(unsigned)t; p.ctl[27] = (int)(unsigned)(t >> 32); }
   if (p.mode == 1) {
     for (int c0 = 0; c0 < p.B; c0 += 64) {
       const int bb = c0 + lane;

@@ -2015,6 +2015,7 @@ extern "C" int e2e_debug_flagged_phases(const void* workspace, int B, int T, int
   if (hipMemcpy(st, ws + l.ctl + 64, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return E2E_ERR_HIP;
   for (int k = 1; k <= 4; k++) us_host[k - 1] = st[0] && st[k] ? (double)(long long)(st[k] - st[0]) * 0.01 : 0.0;
   us_host[4] = st[0] && st[6] ? (double)(long long)(st[6] - st[0]) * 0.01 : 0.0;
+  us_host[5] = st[0] && st[5] ? (double)(long long)(st[5] - st[0]) * 0.01 : 0.0;
   return E2E_OK;
 }
 // Diagnostics: bounded waits of the flagged-utterance launch that ran out (ctl[4]: a workgroup gave up waiting for the others, or a

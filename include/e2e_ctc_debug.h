@@ -31,7 +31,8 @@ int e2e_debug_fast_redo_failures(const void* workspace, int B, int T, int V, int
 
 /* The flagged-utterance launch of that call as its workgroup 0 saw it, microseconds since the launch's start (100 MHz clock):
  * us[0] end of its f64 redos of single segments, [1] of the wait for the other workgroups, [2] of its extended-range chains,
- * [3] of its extended-range segments, [4] end of the launch's last workgroup.  Zeros when nothing was flagged.  Synchronises. */
+ * [3] of its extended-range segments, [4] end of the launch's last workgroup, [5] when that workgroup learnt it was the last
+ * (us_host holds six).  Zeros when nothing was flagged.  Synchronises. */
 int e2e_debug_flagged_phases(const void* workspace, int B, int T, int V, int Smax, double* us_host);
 
 /* Bounded waits of that call's flagged-utterance launch that ran out (0 on an idle GPU; what they left undone was recomputed by the

@@ -1,4 +1,4 @@
-"""A/B two builds of libe2e_ctc.so in ONE process on the headline shape (interleaved rounds, median); AB_B / AB_T / AB_V / AB_S: another shape."""
+"""A/B two builds of libe2e_ctc.so in ONE process on the headline shape (interleaved rounds, median); AB_B / AB_T / AB_V / AB_S: another shape; AB_SCALE: logits scaled (3 = the fallback regime)."""
 import ctypes as C, os, sys, statistics
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
@@ -14,7 +14,7 @@ libs = {os.path.basename(p): bind(os.path.join(root, p)) for p in sys.argv[1:]}
 d = torch.device("cuda", 0)
 B, T, V, S = (int(os.environ.get(k, v)) for k, v in (("AB_B", "256"), ("AB_T", "1000"), ("AB_V", "29"), ("AB_S", "200")))
 gen = torch.Generator().manual_seed(0)
-x = torch.randn(B, T, V, generator=gen).to(d); tg = torch.randint(1, V, (B, S), generator=gen).to(d)
+x = (torch.randn(B, T, V, generator=gen) * float(os.environ.get("AB_SCALE", "1"))).to(d); tg = torch.randint(1, V, (B, S), generator=gen).to(d)
 tl = torch.randint(S // 2, S + 1, (B,), generator=gen).to(d); xl = torch.full((B,), T).to(d)
 losses = torch.empty(B, device=d); grads = torch.empty(B, T, V, device=d)
 n = max(L.e2e_ctc_loss_workspace_bytes(B, T, V, S, 0, 2) for L in libs.values()); ws = torch.zeros(n, dtype=torch.uint8, device=d)

@@ -13,9 +13,9 @@ def run(name, host):
     hp = bench.HotPath(tuple(t.to(dev) for t in host))
     for _ in range(3): hp.call(hp.means[0, :1])
     ms = bench.time_events(torch, lambda: hp.call(hp.means[0, :1]), 5)
-    us = (ctypes.c_double * 5)()
+    us = (ctypes.c_double * 6)()
     L.e2e_debug_flagged_phases(hp.ws.data_ptr(), B, T, V, S, us)
-    print("%-16s %.3f ms per call; flagged launch: redo %.0f, wait %.0f, chains %.0f, segments %.0f, end %.0f us" % (name, ms, *us))
+    print("%-16s %.3f ms per call; flagged launch: redo %.0f, wait %.0f, chains %.0f, segments %.0f, end %.0f us (last workgroup known at %.0f)" % (name, ms, *us))
 x, tg, xl, tl = bench.aligned_batch(10, B, T, V, S, 10.0)
 tg2, tl2 = tg.clone(), tl.clone()
 for k in range(8): tg2[32 * k], tl2[32 * k] = tg[32 * k + 1], tl[32 * k + 1]
