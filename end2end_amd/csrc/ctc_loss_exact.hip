@@ -904,7 +904,12 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   };
 
   bool last_by_arrival = false;       // (set where step 1's bounded wait already told which workgroup is the last: see step 3)
+  // (this workgroup wrote what the last workgroup reads or may write again: losses, for its reduction; rows of an f64 segment redo
+  //  that failed, when no wait-and-release follows step 1 -- the last workgroup recomputes such an utterance, and rows left dirty in
+  //  another XCD's L2 would be written back over its own.  It owes a release before it takes its ticket: see step 3)
+  bool owes_release = false;
   if (p.mode == 2) {
+    owes_release = true;
     for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
       ctc_exact_one<IO, false>(p, smem, b, 0);      // (poisons flagged utterances, touches no slab)
       __syncthreads();
@@ -973,6 +978,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
     const int me = (int)blockIdx.x * p.redo_waves + wid;
     unsigned char* wsmem = smem + (size_t)wid * retry_wave_lds_bytes(p.V, p.retry.PPL);
     int base = 0;
+    bool failed_here = false;
     for (int c0 = 0; c0 < p.B && wid < p.redo_waves; c0 += 64) {
       const int bb = c0 + lane;
       const int f = bb < p.B ? flag_of(bb) : 0;
@@ -1012,42 +1018,49 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
             else if (p.retry.PPL == 1) ok = retry_segment_f64<IO, 1>(p, wsmem, ub, seg, lane);
             else if (p.retry.PPL == 2) ok = retry_segment_f64<IO, 2>(p, wsmem, ub, seg, lane);
             else ok = retry_segment_f64<IO, 4>(p, wsmem, ub, seg, lane);
-            if (!ok && lane == 0) { atomicOr(&p.flags[ub], kRedoFailed); atomicAdd(&p.ctl[5], 1); }
+            if (!ok) { failed_here = true; if (lane == 0) { atomicOr(&p.flags[ub], kRedoFailed); atomicAdd(&p.ctl[5], 1); } }
           }
         }
       }
       base += tot;
     }
-    __syncthreads();                         // (the waves' LDS is taken over by what follows)
+    const bool wg_failed = __syncthreads_or(failed_here ? 1 : 0) != 0;      // (and: the waves' LDS is taken over by what follows)
+    if (wg_failed) owes_release = true;
     stamp(1);
     if (E2E_EXT_ON && p.has_ext) {
       // Which round?  0 (known from the start): some utterance needs the chains -- alpha / beta log Z mismatch, a partition sum out
       // of range, probabilities below 2^-100 -- and everything flagged for its numbers goes with it.  1: step 1 ran, and some redo
       // could not settle its utterance.  To learn that, every workgroup has to have finished step 1: a bounded wait (a grid
-      // that is not resident at once -- a partitioned or shared GPU -- must not hang); all workgroups adopt ONE decision, 1 =
-      // everybody arrived and some redo failed, 2 = some wait ran out (then what step 1 could not settle is left to step 3),
-      // 3 = everybody arrived, nothing failed (the usual case: ctl[5] counts the failures).  No wait when step 1 had nothing to do.
+      // that is not resident at once -- a partitioned or shared GPU -- must not hang).  A workgroup arrives with ONE atomic that
+      // carries its own outcome (ctl[2]: arrivals in the low 16 bits, workgroups with a failed redo above), and all workgroups
+      // adopt ONE decision (ctl[3]): 1 = everybody arrived and some redo failed, 2 = some wait ran out (then what step 1 could not
+      // settle is left to step 3), 3 = everybody arrived, nothing failed (the usual case).  No wait when step 1 had nothing to do.
+      // (No release before the arrival: nothing a workgroup wrote in step 1 is read by another one, and the write-back of the
+      //  L2 -- 256 of them at once -- was 17 us of the usual case.  Round 1 REWRITES rows that step 1 wrote, possibly from another
+      //  XCD: there, and only there, every workgroup releases first, and the chains start when all have: see below.)
       int round = any_ext0 ? 0 : -1;
       if (!any_ext0) {
         bool any_range = false;
         for (int b = tid; b < p.B; b += kThreads) any_range |= range_only(flag_of(b));
         if (__syncthreads_or(any_range ? 1 : 0)) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          __syncthreads();
           if (tid == 0) {
-            s_lastarr = atomicAdd(&p.ctl[2], 1) == (int)gridDim.x - 1;
+            const int G = (int)gridDim.x;
+            s_lastarr = (atomicAdd(&p.ctl[2], 1 + (wg_failed ? 0x10000 : 0)) & 0xffff) == G - 1;
             int spins = 0;
-            while (__hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x &&
+            while ((__hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffff) < G &&
                    __hip_atomic_load(&p.ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 15))
               __builtin_amdgcn_s_sleep(8);
-            const int mine = __hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x ? 1 : 2;
+            const int now = __hip_atomic_load(&p.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int mine = (now & 0xffff) >= G ? ((now >> 16) != 0 ? 1 : 3) : 2;
             const int was = atomicCAS(&p.ctl[3], 0, mine);
             s_dec = was != 0 ? was : mine;
             if (was == 0 && mine == 2) atomicAdd(&p.ctl[4], 1);       // (diagnostics: a wait ran out)
-            if (s_dec == 1 && __hip_atomic_load(&p.ctl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) s_dec = 3;
           }
           __syncthreads();
           if (s_dec == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // step 1's rows leave this XCD's L2 before round 1 writes them again
+            __syncthreads();
+            if (tid == 0) atomicAdd(&p.ctl[6], 1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             for (int b = tid; b < p.B && b < kFlagCache; b += kThreads)     // the flag words as they are now, in one round trip
               s_flag[b] = (unsigned short)(__hip_atomic_load(&p.flags[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (2 * kRedoFailed - 1));
@@ -1071,7 +1084,22 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
       if (round >= 0) {
         build_list(round);
         const int nx = s_next;
-        for (int i = blockIdx.x; i < nx; i += gridDim.x) ext_chains<IO>(p, s_xb[i]);
+        for (int i = blockIdx.x; i < nx; i += gridDim.x) {
+          if (round == 1) {
+            // (every workgroup has released what step 1 wrote before any chain of this round reports itself done -- and only then
+            //  does a segment of the round write a row; the chains take > 100 us, the releases a few: nobody waits here in practice)
+            if (tid == 0) {
+              int spins = 0;
+              while (__hip_atomic_load(&p.ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x && ++spins < (1 << 15))
+                __builtin_amdgcn_s_sleep(8);
+              s_go = __hip_atomic_load(&p.ctl[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x;
+              if (!s_go) { atomicOr(&p.flags[s_xb[i]], kExtDone | kExtBad); atomicAdd(&p.ctl[4], 1); }      // left to step 3
+            }
+            __syncthreads();
+            if (!s_go) continue;
+          }
+          ext_chains<IO>(p, s_xb[i]); owes_release = true;
+        }
         stamp(3);
         if (nx > 0) ext_segments_of_list(nx);
         if (round == 1) {
@@ -1093,6 +1121,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
         if ((int)blockIdx.x < p.nslabs && h % p.nslabs == (int)blockIdx.x) {
           ctc_exact_one<IO, SCALED>(p, smem, c0 + l, blockIdx.x);
           __syncthreads();
+          owes_release = true;
         }
         h++;
       }
@@ -1102,7 +1131,10 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p) {
   // (release / acquire at agent scope: what other workgroups stored must have left their XCD's L2)
   __shared__ int s_last;
   if (!last_by_arrival) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // (the release is an L2 write-back; what the last workgroup reads of the others' work is their losses -- gradient rows need no
+    //  reader inside the launch -- so only a workgroup that wrote losses owes it: with all 256 released by the same event and
+    //  writing back at once it was 18 us of the launch)
+    if (__syncthreads_or(owes_release ? 1 : 0)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tid == 0) s_last = atomicAdd(&p.ctl[0], 1) == (int)gridDim.x - 1;
     __syncthreads();

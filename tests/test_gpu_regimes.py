@@ -47,10 +47,11 @@ def unsettled(keep, B, T, V, S):
     assert L.e2e_debug_fast_redo_failures(keep["workspace"].data_ptr(), B, T, V, S, ctypes.byref(cnt)) == 0
     assert L.e2e_debug_flagged_counters(keep["workspace"].data_ptr(), B, T, V, S, ctypes.byref(to), ctypes.byref(fr)) == 0
     assert to.value == 0, "%d bounded waits of the flagged launch ran out" % to.value
+    keep["failed_redos"] = fr.value
     return cnt.value
 
 
-def check(x, tg, xl, tl, want_unsettled=0, loss_atol=2e-5):
+def check(x, tg, xl, tl, want_unsettled=0, loss_atol=2e-5, keep=None):
     B, T, V = x.shape
     S = tg.shape[1]
     xt = torch.from_numpy(x)
@@ -58,7 +59,7 @@ def check(x, tg, xl, tl, want_unsettled=0, loss_atol=2e-5):
     l_o, g_o = O.ctc_loss(lp, tg, xl, tl, 0)
     for b in range(B):
         g_o[b, xl[b]:] = 0.0
-    keep = {}
+    keep = {} if keep is None else keep
     la, ga = U.c_abi_loss(xt, tg, xl, tl, 0, False, _lib.ALGO_AUTO, keep=keep)
     U.assert_same(la, l_o, F32_RTOL, loss_atol, "losses")
     U.assert_same(ga, g_o, F32_RTOL, F32_ATOL, "grads")
@@ -155,3 +156,17 @@ def test_sixteen_bit_logits_through_the_extended_range_redo(dtype):
     U.assert_same(la, l_o, 1e-4, 2e-5, "losses")
     U.assert_same(ga, g_o, 2 * eps, 2e-6, "grads")
     assert unsettled(keep, B, T, V, S) == 0
+
+
+def test_a_failed_segment_redo_is_settled_by_the_second_round():
+    """Logits of scale 4 against unrelated transcripts: flagged for range only, so the f64 redo of single segments runs first --
+    and cannot hold some rows (a segment's lattice spans more than f64's exponent range).  The flagged launch learns that at its
+    bounded wait and settles those utterances in extended range (round 1: every workgroup releases what the redo wrote before
+    the round rewrites the rows).  Nothing may be left to the full recomputation."""
+    B, T, V, S = 8, 1000, 29, 200              # (tools/diag/find_round1.py: which inputs take this path)
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((B, T, V)) * 4.0).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, S)); tl = rng.integers(S // 2, S + 1, size=B); xl = np.full(B, T)
+    keep = {}
+    check(x, tg, xl, tl, keep=keep)
+    assert keep["failed_redos"] > 0, "this input no longer makes a segment redo fail: the second round is not exercised"
