@@ -623,7 +623,9 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
   // (Chunking the batch -- lattice + fix-up of chunk k on an internal second stream under the row kernel of chunk k+1, so
   // that the fix-up would find its gradient lines in the Infinity Cache -- was built and measured at B=512, T=256, V=8000:
   // 16 utterances per chunk 3.37 ms, 32: 2.29, 64: 2.09, 128: 2.05 against 2.00 ms unchunked.  A chunk's lattice is
-  // latency-bound (~100 us of launches and serial steps whatever its size) and the fix-up is no faster behind it.)
+  // latency-bound (~100 us of launches and serial steps whatever its size) and the fix-up is no faster behind it.  Round 5, the
+  // second stream at the highest queue priority, two chunks: f32 1.76 against 1.70 ms, bf16 1.075 against 1.053 --
+  // tools/diag/experiments/wide_fork_r05.patch.)
   int rc = rows_part(0, a.B, a.stream);
   if (rc != E2E_OK) return rc;
   return lattice_part(0, a.B, a.stream);
