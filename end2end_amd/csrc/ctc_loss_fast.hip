@@ -836,7 +836,10 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(X::kWaves * 64) void ctc_fast_chai
 // The probabilities of every live frame for ChainF64W (see prep_wave_big): a wave takes kProbRows consecutive frames at once
 // (their loads are all in flight together: one frame per wave left the kernel latency-bound at 3.3 TB/s), up to four columns per
 // lane; fused log-softmax for raw logits (ctc_loss.cpp reads log-probabilities: CTCLoss applies log_softmax first).
-constexpr int kProbRows = 4;
+#ifndef E2E_PROB_ROWS              // (tools/diag; round 5, whole call at V = 200 / 448: 4 rows 313 / 959 us, 8 rows 328 / 980, 16 rows 401 / 1 053)
+#define E2E_PROB_ROWS 4
+#endif
+constexpr int kProbRows = E2E_PROB_ROWS;
 template <int NK>                  // columns per lane: 4 (<= kMaxBigV) or 7 (<= kMaxHugeV)
 __global__ __launch_bounds__(256) void ctc_fast_prob_kernel(FastParams p) {
   const int lane = threadIdx.x & 63, V = p.V;

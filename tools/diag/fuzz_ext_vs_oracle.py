@@ -14,7 +14,7 @@ L = _lib.load()
 L.e2e_debug_fast_redo_failures.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-bad = 0; tot = 0; off_fast = 0; exact = 0
+bad = 0; tot = 0; off_fast = 0; exact = 0; marginal = 0
 for case in range(n_cases):
     B = int(rng.integers(1, 7))
     V = int(rng.choice([3, 5, 29, 29, 48, 80, 96, 97, 150, 224, 300, 448]))
@@ -62,7 +62,15 @@ for case in range(n_cases):
     try:
         U.assert_same(la, l_o, 1e-4, 2e-5, "losses"); U.assert_same(ga, g_o, 1e-4, 2e-6, "grads")
     except AssertionError as e:
-        bad += 1
+        # (marginal: single elements off by < 1e-5 at emissions of scale 8 .. 12.  The softmax's x - max is an f32 subtraction: with
+        #  |x - max| up to 80 its half ulp is 3.8e-6 in the exponent, i.e. 4e-6 relative in a probability, and two alignments that
+        #  compete for a frame's posterior differ in dozens of such factors -- tools/diag/ext_case_row.py shows the mass moved between
+        #  two columns of a row whose sum is 1 to 1e-7.  The reference reads f32 log-probabilities, which carry the same rounding;
+        #  the oracle here takes the softmax in f64.)
+        try:
+            U.assert_same(la, l_o, 1e-4, 2e-5, "losses"); U.assert_same(ga, g_o, 1e-4, 1e-5, "grads"); marginal += 1
+        except AssertionError:
+            bad += 1
         if os.environ.get("FUZZ_ONLY"):
             fl = (ctypes.c_int * B)(); lz = (ctypes.c_double * (2 * B))()
             L.e2e_debug_fast_state.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
@@ -76,4 +84,4 @@ for case in range(n_cases):
                     b, xl[b], tl[b], la[b], l_o[b], len(nn), nn[:4].tolist(), d.max(), np.unravel_index(d.argmax(), d.shape)))
         print("case %d MISMATCH: mode %s B=%d T=%d V=%d Smax=%d blank=%d xl=%s tl=%s fast-flagged %s exact %d: %s" % (
             case, mode, B, T, V, Smax, blank, xl.tolist(), tl.tolist(), np.nonzero(np.isnan(lf))[0].tolist(), cnt.value, str(e).splitlines()[0:6]), flush=True)
-print("%d cases, %d utterances: %d left the f32 lattice, %d of them were recomputed by the exact kernel; %d mismatching cases" % (n_cases, tot, off_fast, exact, bad))
+print("%d cases, %d utterances: %d left the f32 lattice, %d of them were recomputed by the exact kernel; %d mismatching cases (+ %d marginal: one element within 1e-5)" % (n_cases, tot, off_fast, exact, bad, marginal))
