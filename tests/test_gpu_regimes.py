@@ -170,3 +170,28 @@ def test_a_failed_segment_redo_is_settled_by_the_second_round():
     keep = {}
     check(x, tg, xl, tl, keep=keep)
     assert keep["failed_redos"] > 0, "this input no longer makes a segment redo fail: the second round is not exercised"
+
+
+@pytest.mark.parametrize("scale,seed", [(3.0, 5), (4.0, 0)], ids=["no_redo_fails", "some_redo_fails"])
+def test_range_flags_beside_an_utterance_flagged_for_its_inputs(scale, seed):
+    """The flagged launch's bounded wait with work left for step 2: utterances flagged for range only (their segments are redone in
+    f64; at scale 4 some redos fail and the second round settles them) in one batch with a blank-valued target, which only the
+    reference's arithmetic serves.  With such an utterance present the workgroup that arrives last at the wait must NOT take
+    the reduction early (another one still has step 2 to do): the fused sum of the losses is checked for that."""
+    B, T, V, S = 9, 1000, 29, 200
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((B, T, V)) * scale).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, S)); tl = rng.integers(S // 2, S + 1, size=B); xl = np.full(B, T)
+    tg[8, 5] = 0                                   # a target equal to the blank id
+    xt = torch.from_numpy(x)
+    lp = torch.log_softmax(xt.double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg, xl, tl, 0)
+    lf, _ = U.c_abi_loss(xt, tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    assert np.isnan(lf[:8]).sum() >= 2 and np.isnan(lf[8]), "this input no longer drives utterances off the f32 lattice"
+    keep = {}
+    la, ga, red = U.c_abi_loss(xt, tg, xl, tl, 0, False, _lib.ALGO_AUTO, keep=keep, opts=(1.0, _lib.REDUCE_SUM))
+    U.assert_same(la, l_o, F32_RTOL, 2e-5, "losses")
+    U.assert_same(ga, g_o, F32_RTOL, F32_ATOL, "grads")
+    assert abs(red - l_o.sum()) <= 1e-5 * abs(l_o.sum())
+    assert unsettled(keep, B, T, V, S) == 0
+    assert (keep["failed_redos"] > 0) == (scale == 4.0)
