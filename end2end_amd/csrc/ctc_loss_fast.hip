@@ -381,10 +381,13 @@ struct ChainF64L : ChainF64 {
 #ifndef E2E_W_PRODUCERS
 #define E2E_W_PRODUCERS 4
 #endif
+#ifndef E2E_W_RING                 // (tools/diag; round 5, whole call at B=256 T=1000 V=128 S<=100: 4 blocks 247 us, 6: 244, 8: 240 -- and
+#define E2E_W_RING 4               //  beyond ~150 columns more than four do not fit the LDS: not worth an instance of its own)
+#endif
 struct ChainF64W : ChainF64 {
   typedef float R;
   static constexpr bool kBigV = true;
-  static constexpr int kRing = 4, kRingElem = 4, kRowElems = kRow32;
+  static constexpr int kRing = E2E_W_RING, kRingElem = 4, kRowElems = kRow32;
   // the producers are what bounds these chains (28 columns per lane and block: ~700 instructions): four per direction, 16 waves,
   // 128 registers -- the plain block loop, as ChainF64L
   static constexpr int kProducers = E2E_W_PRODUCERS;

@@ -9,7 +9,7 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.
 L = _lib.load()
 d = torch.device("cuda", 0)
 gen = torch.Generator().manual_seed(0)
-B, T, V, S = 256, 1000, 29, int(sys.argv[1]) if len(sys.argv) > 1 else 200
+B, T, V, S = 256, 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 29, int(sys.argv[1]) if len(sys.argv) > 1 else 200      # argv: S [V]
 x = torch.randn(B, T, V, generator=gen).to(d); tg = torch.randint(1, V, (B, S), generator=gen).to(d)
 tl = torch.randint(S // 2, S + 1, (B,), generator=gen).to(d); xl = torch.full((B,), T).to(d)
 losses = torch.empty(B, device=d); grads = torch.empty(B, T, V, device=d)
