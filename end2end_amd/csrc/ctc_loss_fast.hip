@@ -875,7 +875,16 @@ __global__ __launch_bounds__(256) void ctc_fast_prob_kernel(FastParams p) {
       for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
       float ssum = 0.f;
 #pragma unroll
-      for (int k = 0; k < NK; k++) { y[k] = exp_le0(x[r][k] - m); ssum += y[k]; }
+      for (int k = 0; k < NK; k++) {
+        // x - m with its rounding error (two-sum): at |x - m| up to 80 half an ulp of the difference is 3.8e-6 -- 4e-6 relative in
+        // the probability, and alignments that compete for a frame differ in dozens of such factors (7e-6 on single gradient
+        // elements at logits of scale 8..12, tools/diag/ext_case_row.py).  This kernel waits for HBM: the six operations are free.
+        const float a = x[r][k], d = a - m, bb = d - a;
+        const float err = (a - (d - bb)) + (-m - bb);
+        const float e0 = exp_le0(d);
+        y[k] = a > ninf ? fmaf(e0, err, e0) : 0.f;
+        ssum += y[k];
+      }
       ssum = wave_sum(ssum);
       float inv = __builtin_amdgcn_rcpf(ssum);
       inv = fmaf(fmaf(-ssum, inv, 1.0f), inv, inv);        // one Newton step: ~0.5 ulp

@@ -471,7 +471,13 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
 #pragma unroll
       for (int k = 0; k < NV; k++) {
         const float d = xv[k] - m;
+#ifdef E2E_H1_TWOSUM            // (off: 0.8 us of the headline call -- 127.6 against 126.8 us -- for 4e-6 relative in probabilities below e^-64)
+        const float bb = d - xv[k], err = (xv[k] - (d - bb)) + (-m - bb);    // the subtraction's rounding error (see ctc_fast_prob_kernel)
+        const float e0 = exp_le0(d);
+        y[k] = xv[k] > ninf ? fmaf(e0, err, e0) : 0.f; ssum += y[k];
+#else
         y[k] = exp_le0(d); ssum += y[k];
+#endif
         if (DIR == 0) lpmin = fminf(lpmin, xv[k] > ninf ? d : 0.f);          // (>= the log-probability)
       }
       ssum = row8_sum(ssum);

@@ -48,7 +48,9 @@ for case in range(n_cases):
     xt = torch.from_numpy(x)
     lp = torch.log_softmax(xt, -1)
     l_o, g_o = O.ctc_loss(lp.numpy(), tg, xl, tl, blank)
-    if logprobs: arg = lp.float()
+    if logprobs:
+        arg = lp.float()
+        l_o, g_o = O.ctc_loss(arg.double().numpy(), tg, xl, tl, blank)       # (the oracle on what the call is given: the ROUNDED log-probabilities)
     else:
         arg = xt.float()
         lp32 = torch.log_softmax(arg.double(), -1); l_o, g_o = O.ctc_loss(lp32.numpy(), tg, xl, tl, blank)
@@ -66,7 +68,8 @@ for case in range(n_cases):
         #  |x - max| up to 80 its half ulp is 3.8e-6 in the exponent, i.e. 4e-6 relative in a probability, and two alignments that
         #  compete for a frame's posterior differ in dozens of such factors -- tools/diag/ext_case_row.py shows the mass moved between
         #  two columns of a row whose sum is 1 to 1e-7.  The reference reads f32 log-probabilities, which carry the same rounding;
-        #  the oracle here takes the softmax in f64.)
+        #  the oracle here takes the softmax in f64.  The wide-row table kernel carries the subtraction's error along since the end
+        #  of round 5 (two-sum); the narrow chains' producers do not.)
         try:
             U.assert_same(la, l_o, 1e-4, 2e-5, "losses"); U.assert_same(ga, g_o, 1e-4, 1e-5, "grads"); marginal += 1
         except AssertionError:
