@@ -329,8 +329,11 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
 
 // One utterance's chains on this workgroup.  Ends with the utterance's flag word carrying kExtDone (and kExtBad if the
 // partition sum is not a positive number or the two sides disagree), after a release fence.
-// (out of line: inside the flagged kernel -- 255 registers, its own spills -- the chains' loops spilled too; as a function of
-//  their own they get their own register allocation.  The dynamic LDS is found again through its own declaration.)
+// (Forced inline, like everything that takes the parameter block by reference.  Out of line -- tried for the chains' sake: a
+//  register allocation of their own -- the block's address escapes, the kernel keeps it on its stack, and EVERY wave of EVERY
+//  launch copies the 336 bytes per lane to scratch at the kernel's entry, in front of the early exit: the empty flagged launch
+//  9.6 instead of 5.3 us, the headline call +6.6 us.  profiles/r05_placement/; tests/test_host_cpu.py audits the built library
+//  for it.  The dynamic LDS is found again through its own declaration.)
 template <typename IO>
 __device__ __forceinline__ void ext_chains(const ExactParams& p, int b) {
   extern __shared__ __align__(16) unsigned char smem[];

@@ -47,6 +47,25 @@ def test_header_declares_every_exported_symbol():
     assert not any(n.startswith("e2e_debug_") for n in _declared(("e2e_ctc.h",)))
 
 
+def test_no_kernel_copies_its_parameter_block_to_scratch():
+    """The performance guard that needs no GPU.  A kernel whose parameter struct has its address taken -- handed by reference
+    to a function the compiler decides not to inline, which depends on how much code sits around it -- keeps the struct in
+    private memory: every wave stores the whole kernarg segment to scratch at its entry (84 dwords per lane for ExactParams,
+    before any early exit) and reads its fields back from there.  That is what made the flagged-utterance launch take 9.6 instead
+    of 5.3 us, the headline call 132.7 instead of 126.1, in some builds of round 5 (profiles/r05_placement/), with the source of the
+    executed path unchanged.  tools/perf/entry_audit.py disassembles the built library's device code and counts the dwords a
+    kernel stores to scratch in its first 200 instructions; a handful (a saved register) is normal, a parameter block is not."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools", "perf"))
+    import entry_audit
+    from end2end_amd import _lib
+    res = entry_audit.audit(_lib.LIB_PATH)
+    assert len(res) >= 60, "the audit found only %d kernels: is the library's device code still bundled the same way?" % len(res)
+    assert any("ctc_exact_kernel<float, true, false>" in k for k in res) and any("ctc_fast_segment_kernel<4, false, false>" in k for k in res)
+    bad = {k: v for k, v in res.items() if v[0] > 16}
+    assert not bad, "kernels that spill a block of state at their entry (dwords stored to scratch, scratch loads): %s" % bad
+
+
 def test_pybind_layer_loads_and_reports_errors():
     from end2end_amd import _C, _runtime
     assert _C.abi_version() == _C.ABI_VERSION == _runtime.ABI_VERSION
