@@ -55,10 +55,14 @@ def test_no_kernel_copies_its_parameter_block_to_scratch():
     of 5.3 us, the headline call 132.7 instead of 126.1, in some builds of round 5 (profiles/r05_placement/), with the source of the
     executed path unchanged.  tools/perf/entry_audit.py disassembles the built library's device code and counts the dwords a
     kernel stores to scratch in its first 200 instructions; a handful (a saved register) is normal, a parameter block is not."""
+    import shutil
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools", "perf"))
     import entry_audit
     from end2end_amd import _lib
+    tools = [os.path.join(entry_audit.LLVM, t) for t in ("llvm-objdump", "llvm-readelf", "clang-offload-bundler")]
+    if not all(os.path.exists(t) for t in tools) or not shutil.which("objcopy") or not shutil.which("c++filt"):
+        pytest.skip("the ROCm LLVM binutils are not on this machine")
     res = entry_audit.audit(_lib.LIB_PATH)
     assert len(res) >= 60, "the audit found only %d kernels: is the library's device code still bundled the same way?" % len(res)
     assert any("ctc_exact_kernel<float, true, false>" in k for k in res) and any("ctc_fast_segment_kernel<4, false, false>" in k for k in res)
