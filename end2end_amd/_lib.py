@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("E2E_CTC_LIB") or os.path.join(_HERE, "csrc", "libe2e_
 
 F32, F64, F16, BF16 = 0, 1, 2, 3
 ALGO_AUTO, ALGO_EXACT, ALGO_FAST = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 _lock = threading.Lock()
@@ -50,6 +50,9 @@ def load():
         L = C.CDLL(LIB_PATH)
         vp, i64, i64p = C.c_void_p, C.c_int64, C.c_void_p
         L.e2e_ctc_abi_version.restype = C.c_int
+        # (first of all: a library of another ABI may lack symbols bound below, and would fail with an AttributeError instead)
+        if L.e2e_ctc_abi_version() != ABI_VERSION:
+            raise ImportError("end2end_amd: %s has ABI %d, expected %d" % (LIB_PATH, L.e2e_ctc_abi_version(), ABI_VERSION))
         L.e2e_last_error.restype = C.c_char_p
         L.e2e_ctc_loss_workspace_bytes.restype = C.c_size_t
         L.e2e_ctc_loss_workspace_bytes.argtypes = [C.c_int] * 6
@@ -100,8 +103,6 @@ def load():
             assert (F32, F64, F16, BF16) == (_ext.F32, _ext.F64, _ext.F16, _ext.BF16), "dtype codes of _lib.py and include/e2e_ctc.h differ"
         except ImportError:
             pass
-        if L.e2e_ctc_abi_version() != ABI_VERSION:
-            raise ImportError("end2end_amd: %s has ABI %d, expected %d" % (LIB_PATH, L.e2e_ctc_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

@@ -22,7 +22,7 @@ except ImportError as e:                                   # pragma: no cover - 
 F32, F64 = _C.F32, _C.F64
 F16, BF16 = _C.F16, _C.BF16    # (read and written natively by the fast and wide loss paths)
 ALGO_AUTO, ALGO_EXACT, ALGO_FAST = _C.ALGO_AUTO, _C.ALGO_EXACT, _C.ALGO_FAST
-ABI_VERSION = 2
+ABI_VERSION = 3
 E2EError = _C.E2EError
 
 if _C.abi_version() != ABI_VERSION or _C.ABI_VERSION != ABI_VERSION:

@@ -972,6 +972,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
         if (s_go) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           ext_segment<IO>(p, ub, seg);
+          owes_release = true;          // (kExtBad can still be set by a waiter whose patience ran out: step 3 then rewrites these rows)
         }
         __syncthreads();
       }
@@ -987,7 +988,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
     const int me = (int)blockIdx.x * p.redo_waves + wid;
     unsigned char* wsmem = smem + (size_t)wid * retry_wave_lds_bytes(p.V, p.retry.PPL);
     int base = 0;
-    bool failed_here = false;
+    bool failed_here = false, wrote_here = false;
     for (int c0 = 0; c0 < p.B && wid < p.redo_waves; c0 += 64) {
       const int bb = c0 + lane;
       const int f = bb < p.B ? flag_of(bb) : 0;
@@ -1028,6 +1029,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
             else if (p.retry.PPL == 2) ok = retry_segment_f64<IO, 2>(p, wsmem, ub, seg, lane);
             else ok = retry_segment_f64<IO, 4>(p, wsmem, ub, seg, lane);
             if (!ok) { failed_here = true; if (lane == 0) { atomicOr(&p.flags[ub], kRedoFailed); atomicAdd(&p.ctl[5], 1); } }
+            else wrote_here = true;
           }
         }
       }
@@ -1035,6 +1037,10 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
     }
     const bool wg_failed = __syncthreads_or(failed_here ? 1 : 0) != 0;      // (and: the waves' LDS is taken over by what follows)
     if (wg_failed) owes_release = true;
+    // Rows of a successful redo have no reader inside the launch -- unless ANOTHER segment of the same utterance failed and nothing
+    // but step 3 is left to settle it (no extended-range redo in this launch, or its wait ran out: below): then the last workgroup
+    // rewrites those rows from its own XCD, and the first writer's dirty lines must have left this one's L2 by then.
+    if (wrote_here && !(E2E_EXT_ON && p.has_ext)) owes_release = true;
     stamp(1);
     if (E2E_EXT_ON && p.has_ext) {
       // Which round?  0 (known from the start): some utterance needs the chains -- alpha / beta log Z mismatch, a partition sum out
@@ -1066,6 +1072,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
             if (was == 0 && mine == 2) atomicAdd(&p.ctl[4], 1);       // (diagnostics: a wait ran out)
           }
           __syncthreads();
+          if (s_dec == 2 && wrote_here) owes_release = true;         // (step 3 may rewrite this workgroup's rows: see above)
           if (s_dec == 1) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // step 1's rows leave this XCD's L2 before round 1 writes them again
             __syncthreads();
@@ -1105,7 +1112,9 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
               if (!s_go) { atomicOr(&p.flags[s_xb[i]], kExtDone | kExtBad); atomicAdd(&p.ctl[4], 1); }      // left to step 3
             }
             __syncthreads();
-            if (!s_go) continue;
+            const bool go_now = s_go;
+            __syncthreads();                 // (everybody has read s_go before thread 0 writes it for the next utterance)
+            if (!go_now) continue;
           }
           ext_chains<IO>(p, s_xb[i]); owes_release = true;
         }
@@ -1218,8 +1227,12 @@ int launch_exact_flagged(const LossArgs& a, int* flags, int mode, const FastRetr
   const bool ext_ok = mode == 1 && retry && a.scaled_exact && (a.dtype == E2E_F32 || dtype_is_16bit(a.dtype)) &&
                       retry->PPL >= 1 && 2 * a.Smax + 2 <= retry->CELLS && ExtLds::bytes(a.V) <= 120 * 1024 && getenv("E2E_NO_EXT") == nullptr;
   if (ext_ok && ExtLds::bytes(a.V) > lds) lds = ExtLds::bytes(a.V);
-  if (lds > 146 * 1024) {
-    set_error("exact CTC kernel: V=%d, Smax=%d need %zu B of LDS (> 146 KiB beside its static 12.5)", a.V, a.Smax, lds);
+  // (the flagged launch keeps 12.5 KB of static LDS -- flag cache, extended-range lists -- beside the dynamic part; the
+  //  all-utterances kernel of mode 0 has none and may take the whole 160 KiB)
+  const size_t lds_cap = mode == 0 ? 160 * 1024 : 146 * 1024;
+  if (lds > lds_cap) {
+    set_error("exact CTC kernel: V=%d, Smax=%d need %zu B of LDS (> %zu KiB%s)", a.V, a.Smax, lds, lds_cap / 1024,
+              mode == 0 ? "" : " beside its static 12.5");
     return E2E_ERR_UNSUPPORTED;
   }
   const int slabs = mode == 0 ? a.B : (a.B < kFallbackSlabs ? a.B : kFallbackSlabs);

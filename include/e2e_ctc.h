@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define E2E_CTC_ABI_VERSION 2
+#define E2E_CTC_ABI_VERSION 3
 
 /* element types of the logits / log-prob tensor (losses and grads use the same) */
 #define E2E_F32 0

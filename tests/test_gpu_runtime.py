@@ -1,5 +1,7 @@
 """-m gpu: runtime contract of the C ABI (asynchronous on the caller's stream, no allocation / sync inside -> graph
 capturable) and an end-to-end training loop through the drop-in modules."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -121,13 +123,29 @@ def test_headline_call_is_not_pathologically_slow():
     13 ms -> < 40; the mislabelled-utterance regime of round 5 (0.45 ms) -> < 1.5."""
     import bench
     d = U.dev()
+    # The limits are absolute times of an idle MI355X; a shared or partitioned GPU, a profiler or another SKU slows everything
+    # down with no defect behind it (ADVICE r5).  The yardstick is timed in the same process: the library's streaming copy of
+    # 256 MiB each way (5-6 TB/s on an idle MI355X); the limits stretch by what it falls short of 4 TB/s.  E2E_PERF_GUARD=0 skips.
+    if os.environ.get("E2E_PERF_GUARD", "1") == "0":
+        pytest.skip("E2E_PERF_GUARD=0")
+    from end2end_amd import _lib
+    L = _lib.load()
+    n = 256 << 20
+    src = torch.empty(n, dtype=torch.uint8, device=d).zero_()
+    dst = torch.empty_like(src)
+    cp = lambda: _lib.check(L.e2e_debug_stream_copy(dst.data_ptr(), src.data_ptr(), n, _lib.stream_ptr(d)))
+    for _ in range(3):
+        cp()
+    tbs = 2 * n / (_events_ms(cp, 10) * 1e-3) / 1e12
+    slack = max(1.0, 4.0 / tbs)
+    del src, dst
     w = bench.WORKLOAD
     _, db = bench.make_batch(1000, w["B"], w["T"], w["V"], w["S"], d)
     hp = bench.HotPath(db)
     for _ in range(3):
         hp.call(hp.means[0, :1])
     ms = _events_ms(lambda: hp.call(hp.means[0, :1]), 20)
-    assert ms < 0.45, "configs[1] loss call: %.3f ms" % ms
+    assert ms < 0.45 * slack, "configs[1] loss call: %.3f ms" % ms
     del hp, db
     x, tg, xl, tl = bench.aligned_batch(10, w["B"], w["T"], w["V"], w["S"], 10.0)
     for k in range(8):
@@ -136,7 +154,7 @@ def test_headline_call_is_not_pathologically_slow():
     for _ in range(3):
         hp.call(hp.means[0, :1])
     ms = _events_ms(lambda: hp.call(hp.means[0, :1]), 10)
-    assert ms < 1.5, "configs[1] shape with 8 mislabelled utterances: %.3f ms" % ms
+    assert ms < 1.5 * slack, "configs[1] shape with 8 mislabelled utterances: %.3f ms" % ms
     assert torch.isfinite(hp.losses).all()
     del hp
     ww = bench.WIDE
@@ -145,7 +163,7 @@ def test_headline_call_is_not_pathologically_slow():
     for _ in range(2):
         hp.call()
     ms = _events_ms(hp.call, 5)
-    assert ms < 5.0, "configs[4] share: %.3f ms" % ms
+    assert ms < 5.0 * slack, "configs[4] share: %.3f ms" % ms
     del hp, wb
     torch.cuda.empty_cache()
     g = torch.Generator().manual_seed(2)
@@ -155,4 +173,4 @@ def test_headline_call_is_not_pathologically_slow():
     eng = CTCDecoder(beam_width=100, blank_idx=0, after_logsoftmax=True, labels=labels, wip=1.0)._decoder
     eng.decode(xb, xlb)
     ms = _events_ms(lambda: eng.decode(xb, xlb), 3)
-    assert ms < 40.0, "configs[3] beam search without LM: %.3f ms" % ms
+    assert ms < 40.0 * slack, "configs[3] beam search without LM: %.3f ms" % ms
