@@ -132,9 +132,29 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(copy_f4* __restrict__ 
   for (size_t i = npieces * kCopyPiece + (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+// Holds `gridDim.x` workgroups on the chip for `ticks` of the 100 MHz wall clock (tests: the flagged launch's bounded waits
+// with another stream's kernels resident; the dynamic LDS is only there to be taken).
+__global__ void occupy_kernel(long long ticks, int* sink) {
+  extern __shared__ int occ_lds[];
+  const unsigned long long t0 = wall_clock64();
+  int spins = 0;
+  while ((long long)(wall_clock64() - t0) < ticks && ++spins < (1 << 24)) __builtin_amdgcn_s_sleep(16);
+  if (sink && spins < 0) sink[0] = occ_lds[threadIdx.x];
+}
+
 }  // namespace e2e
 
 using namespace e2e;
+
+extern "C" int e2e_debug_occupy(int workgroups, int threads, int lds_bytes, long long nanoseconds, void* stream) {
+  if (workgroups < 1 || threads < 64 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || nanoseconds < 0 || nanoseconds > 100000000) {
+    set_error("e2e_debug_occupy: bad argument"); return E2E_ERR_ARG;
+  }
+  E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&occupy_kernel), lds_bytes), "hipFuncSetAttribute");
+  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(threads), lds_bytes, (hipStream_t)stream, nanoseconds / 10, (int*)nullptr);
+  E2E_HIP_CHECK(hipGetLastError(), "occupy_kernel launch");
+  return E2E_OK;
+}
 
 // diagnostics, not part of include/e2e_ctc.h: dst[0..bytes) = src[0..bytes), bytes a multiple of 16
 extern "C" int e2e_debug_stream_copy(void* dst, const void* src, size_t bytes, void* stream) {

@@ -19,6 +19,11 @@ extern "C" {
  * copy rate bench.py reports as roofline.peak_measured beside the 8 TB/s spec. */
 int e2e_debug_stream_copy(void* dst, const void* src, size_t bytes, void* stream);
 
+/* Keeps `workgroups` workgroups of `threads` threads, each holding `lds_bytes` of LDS, resident for `nanoseconds` (<= 0.1 s) on
+ * `stream`, doing nothing: tests/test_gpu_fuzz.py runs the loss call's flagged launch beside it (its bounded waits must end in
+ * right results whether they run out or not). */
+int e2e_debug_occupy(int workgroups, int threads, int lds_bytes, long long nanoseconds, void* stream);
+
 /* After an e2e_ctc_loss_fwd_bwd(ALGO_AUTO / ALGO_FAST) call that took the fast path: the per-utterance
  * flag words (0 = served by the fast path; bits: 1 bad lengths, 2 blank in targets, 4 infeasible,
  * 8 range / self-check, 16 non-finite, 32 log Z mismatch, 64 emissions near the end of f32) and the

@@ -29,3 +29,14 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Case counts of the oracle-checked fuzz slices (tests/test_gpu_fuzz.py), so that they show in the run's tail."""
+    mod = sys.modules.get("test_gpu_fuzz")
+    counts = getattr(mod, "COUNTS", None) if mod is not None else None
+    if counts:
+        loss = sum(v[0] for k, v in counts.items() if k != "align")
+        terminalreporter.write_line("fuzz slices against the oracle: %d loss cases (%s), %d alignment cases; beam: 220 cases x 2 kernels in test_gpu_beam.py"
+                                    % (loss, ", ".join("%s %d cases / %d utterances" % (k, v[0], v[1]) for k, v in sorted(counts.items()) if k != "align"),
+                                       counts.get("align", [0, 0])[0]))
