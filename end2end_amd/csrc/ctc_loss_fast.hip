@@ -1842,7 +1842,11 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
   // the lean halo chains of ctc_loss_fast_h1.hip.  E2E_F1_LEAN=0 / 1: never / wherever they fit (A/B, tests)
   static const char* lean_env = getenv("E2E_F1_LEAN");
   const bool no_h1 = lean_env && lean_env[0] == '0', force_h1 = lean_env && lean_env[0] == '1';
-  if (!no_h1 && !force_single && (kLeanDefault ? PPL == 4 || force_h1 : force_h1) && h1_supported(p.V, p.Smax, PPL)) {
+  // (targets of 64..127 labels, round 6: the lean chains win while every utterance has a CU to itself -- B=256, T=1000, S<=100: 108.3
+  //  against 116.9 us per call, S<=127: 115.4 against 117.6 -- and lose beyond, where two workgroups of the single-wave kernel share
+  //  a CU and one of the lean kernel fills it: B=512, T=256, S<=64 73.8 against 59.3 us; tools/diag/lean_ab.sh)
+  const bool lean_pays = PPL == 4 || (PPL == 2 && p.B <= 256);
+  if (!no_h1 && !force_single && (kLeanDefault ? lean_pays || force_h1 : force_h1) && h1_supported(p.V, p.Smax, PPL)) {
     const int rc = launch_fast_h1_chain(p, PPL, stream);
     if (rc != E2E_OK) return rc;
     return launch_segments<PPL>(p, lds2, stream);

@@ -30,13 +30,16 @@ namespace {
 #ifndef E2E_HX_ABL                  // tools/diag: timing builds with parts of the chain waves' work switched off (results meaningless)
 #define E2E_HX_ABL 0               //  1: probabilities read once, 2: no waiting for the producers, 4: no halo exchange, 8: no frame, 16: no checkpoints
 #endif
+#ifndef E2E_HX_SLIM                 // 1: eight waves (NP = 2) -- one producer per direction, frame and checkpoint roles of a direction on ONE
+#define E2E_HX_SLIM 0              //    wave, the lattice description written by the alpha producer when its rows are done: a third of every
+#endif                             //    SIMD's registers stays free for waves of another kernel (the segment kernel's polling form)
 constexpr int kHxHalo = 8;                    // halo lanes (NP pairs each: the edge lanes are exchanged every NP-th block)
 constexpr int kHxOwnLanes = 64 - kHxHalo;     // 56
-constexpr int kHxProducers = 2;
+constexpr int kHxProducers = E2E_HX_SLIM ? 1 : 2;
 template <int NP> struct Hx {
   static constexpr int kOwn = NP * kHxOwnLanes;                     // pairs a wave owns
   static constexpr int kMaxW = 4 / NP;                              // chain waves per direction: 224 pairs, S <= 223
-  static constexpr int kWaves = 2 * kMaxW + 2 + 2 * kHxProducers + 2;
+  static constexpr int kWaves = E2E_HX_SLIM ? 2 * kMaxW + 2 * kHxProducers + 2 : 2 * kMaxW + 2 + 2 * kHxProducers + 2;
 };
 
 struct HxLds {
@@ -46,8 +49,10 @@ struct HxLds {
   int blk_bytes;
   int filled;      // [2][kRingBlks] ints; used: [dir][f] = the next block producer f of the direction has not finished yet
   int sortcnt;     // [130] ints (cellinfo_wave)
-  int bnd;         // [2][8][kHaloSlots][kHxHalo] x 4 doubles: wave w's edge lanes after block n (wave slots that hold no
-                   //  cells stay zero: what the first / last wave of a direction reads as its neighbour's)
+  int bnd;         // [2][bw][kHaloSlots][kHxHalo] x 4 doubles: wave w's edge lanes after block n (wave slots that hold no
+                   //  cells stay zero: what the first / last wave of a direction reads as its neighbour's); bw = 8 wave slots
+                   //  with one pair per lane, 4 with two (waves 0, 1; slot 2: beta's "wave above the last", 3: alpha's "below the first")
+  int bw;
   int dump;        // 12 KB nobody reads: where lanes that have nothing to publish store
   int zacc;        // [8] doubles
   int prog;        // [2][8] ints
@@ -56,13 +61,14 @@ struct HxLds {
   int ckb;         // [2][2][kCkCells] doubles: a checkpoint row's true cells in lattice order, double-buffered
   int ckdone;      // [2] ints
   int total;
-  __host__ __device__ HxLds(int V) {
+  __host__ __device__ HxLds(int V, int np = 2) {
+    bw = np == 1 ? 8 : 4;
     ring = 0;
     blk_bytes = ((V + 1) * kRow + 16) * 8;
     filled = ring + 2 * kRingBlks * blk_bytes;
     sortcnt = filled + 2 * kRingBlks * 4;
     bnd = (sortcnt + 130 * 4 + 15) & ~15;
-    dump = bnd + 2 * 8 * kHaloSlots * kHxHalo * 32;
+    dump = bnd + 2 * bw * kHaloSlots * kHxHalo * 32;
     zacc = dump + 12288;
     prog = zacc + 64;
     exw = prog + 2 * 8 * 4;
@@ -73,10 +79,17 @@ struct HxLds {
   }
 };
 
+#ifdef E2E_FAST_PROFILE
+#define HX_TL(k) { if (w == 0 && lane == 0 && b < 256) { unsigned long long* g = g_tl + ((size_t)b * 2 + DIR) * 12 + 2 * (k); \
+    g[0] = __builtin_amdgcn_s_memtime(); g[1] = wall_clock64(); } }
+#else
+#define HX_TL(k)
+#endif
 template <int DIR, int NP>
 __device__ __forceinline__ void hx_chain_wave(const FastParams& p, int b, int T, int S, unsigned char* smem, const HxLds hl,
                                               int lane, int w, int W) {
   lds_u8* L0 = (lds_u8*)smem;
+  HX_TL(1)
   const int V = p.V, blank = p.blank, L = 2 * S + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
   const int M = (T - 1) >> 3;
@@ -121,9 +134,10 @@ __device__ __forceinline__ void hx_chain_wave(const FastParams& p, int b, int T,
   const int a_sync = hl.prog;                                                      // (uniform) the words of both directions
   const int o_prog = DIR * 32, o_exw = hl.exw - hl.prog + DIR * (kHaloSlots * 4), o_ckdone = hl.ckdone - hl.prog + 4 * DIR;
   const int a_mxl = hl.mxl + ((DIR * kHaloSlots * 4 + w) * 64 + lane) * 4;         // + slot * 1024
-  const int a_bnd_up = hl.bnd + ((DIR * 8 + up) * kHaloSlots * kHxHalo + (lane & (kHxHalo - 1))) * 32;     // + slot * 256
+  const int up_rec = DIR == 0 ? (w > 0 ? w - 1 : hl.bw - 1) : w + 1;          // (its edge records: the last wave slot is alpha's empty one)
+  const int a_bnd_up = hl.bnd + ((DIR * hl.bw + up_rec) * kHaloSlots * kHxHalo + (lane & (kHxHalo - 1))) * 32;     // + slot * 256
   // own edge record: the edge lanes' cells; the other lanes write to a dump row of their own (no exec mask around the store)
-  const int a_bnd_my = edge ? hl.bnd + ((DIR * 8 + w) * kHaloSlots * kHxHalo + (lane & (kHxHalo - 1))) * 32
+  const int a_bnd_my = edge ? hl.bnd + ((DIR * hl.bw + w) * kHaloSlots * kHxHalo + (lane & (kHxHalo - 1))) * 32
                             : hl.dump + lane * 32;                                  // (+ slot * 256 < 4 KB)
   // checkpoint cells of slot 0 (label cell first for beta: cells 2 gi - 1, 2 gi; alpha: cells 2 gi, 2 gi + 1); halo lanes: dump
   const int a_ck = halo ? hl.dump + 4096 + lane * 32
@@ -313,6 +327,7 @@ __device__ __forceinline__ void hx_chain_wave(const FastParams& p, int b, int T,
   {
     typedef std::integral_constant<int, -1> Any;
     need_blocks(1);
+    HX_TL(2)
     load_half(0, std::integral_constant<int, 0>{});
     const int steady_end = DIR == 0 ? T / kBlk : nblk;         // blocks [1, steady_end - 1) are steady (live, with a successor)
     run_block(0, std::false_type{}, Any{}, Any{});
@@ -336,6 +351,7 @@ __device__ __forceinline__ void hx_chain_wave(const FastParams& p, int b, int T,
     for (; n < steady_end - 1; n++) run_block(n, std::true_type{}, Any{}, Any{});
     for (; n < nblk; n++) run_block(n, std::false_type{}, Any{}, Any{});
   }
+  HX_TL(3)
 #ifdef E2E_FAST_PROFILE
   if (lane == 0 && b < 256) { unsigned long long* g = g_prof3 + ((size_t)b * 16 + DIR * 8 + w) * 4;
     g[0] = __builtin_amdgcn_s_memtime() - prof_t0; g[1] = prof_fill; g[2] = prof_nb; g[3] = prof_lag; }
@@ -375,6 +391,7 @@ __device__ __forceinline__ void hx_chain_wave(const FastParams& p, int b, int T,
       p.logz[2 * b + 1] = log(z) + (double)e_total * 0.693147180559945309417 - (double)(L - 1) * log((double)r_tilt);
     }
   }
+  HX_TL(4)
 }
 
 // The probability rows of one chain, leaner than prep_wave (fast_common.h), which it follows: a block is one pass, each
@@ -576,6 +593,83 @@ __device__ __forceinline__ void hx_ckpt_wave(const FastParams& p, int b, int T, 
   }
 }
 
+// E2E_HX_SLIM: the frame wave and the checkpoint wave of a direction as ONE wave.  Both follow the chain waves block by block
+// (the same progress words); the frame's word is wanted two blocks later, the checkpoint row's buffer 16 steps later, so per
+// block the frame comes first (at the chains' priority) and a checkpoint row, every other block, behind it.
+template <int DIR, int F2PPL>
+__device__ __forceinline__ void hx_frame_ckpt_wave(const FastParams& p, int b, int T, int S, lds_u8* L0, const HxLds hl, int lane, int W, int npairs) {
+  static_assert(F2PPL == 1 || F2PPL == 2 || F2PPL == 4, "groups of up to four lanes (one DPP quad)");
+  constexpr int LAG = kHaloLag, maxw = 4, kExMax = 1000;
+  const int nblk = (T + kBlk - 1) / kBlk;
+  const int nres = DIR == 0 ? T / kBlk : nblk;
+  const int M = (T - 1) >> 3;
+  int* cum = (DIR == 0 ? p.cumA : p.cumB) + (size_t)b * p.NB;
+  int* trk = (DIR == 0 ? p.trkA : p.trkB) + (size_t)b * p.NB;
+  lds_u8* prog = L0 + hl.prog + DIR * 32;
+  lds_u8* exw = L0 + hl.exw + DIR * (kHaloSlots * 4);
+  lds_u8* mxl = L0 + hl.mxl + (DIR * kHaloSlots * maxw * 64 + lane) * 4;
+  float* ck = (DIR == 0 ? p.ckA : p.ckQ) + (size_t)b * p.NS * p.CELLS;
+  if (lane == 0) {
+    if (DIR == 0) { cum[0] = 0; trk[0] = 0; }
+    else { cum[M + 1] = 0; cum[M + 2] = 0; trk[M + 1] = 0; trk[M + 2] = 0; }
+    for (int n = 0; n < LAG && n < nres; n++) cum[DIR == 0 ? n + 1 : M - n] = 0;
+  }
+  int through = 0, ex1 = 0, ex2 = 0, absolute = 0, done = 0;
+  for (int n = 0; n < nres; n++) {
+    __builtin_amdgcn_s_setprio(3);
+    HALO_WAIT(__builtin_amdgcn_readfirstlane(lds_min8(prog)) >= n + 1);
+    // ---- the frame (halo_frame_wave<DIR, false, kHaloLag, true>) ----
+    int m = 0;
+    for (int w = 0; w < W; w++) m = max(m, *(volatile lds_int*)(mxl + ((n & (kHaloSlots - 1)) * maxw + w) * 256));
+    m = wave_max(m);
+    if (m > 0) {
+      const int e = ((m >> 20) & 0x7ff) - 1023;
+      absolute = e + (through - ex1 - ex2);
+    }
+    if (lane == 0) trk[DIR == 0 ? n + 1 : M - n] = absolute;
+    if (n + LAG < nres) {
+      const int ex = m > 0 ? max(min(absolute - through, kExMax), -kExMax) : 0;
+      through += ex; ex2 = ex1; ex1 = ex;
+      const int nn = n + LAG;
+      *(volatile lds_int*)(exw + 4 * (nn & (kHaloSlots - 1))) = (nn << 12) | (ex + 2048);
+      if (lane == 0) cum[DIR == 0 ? nn + 1 : M - nn] = through;
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // ---- the checkpoint row that block n ended in, if any (hx_ckpt_wave<DIR, F2PPL>) ----
+    const int kk = DIR == 0 ? 8 * (n + 1) : 8 * (M - n);
+    if (!((kk & (kSeg - 1)) == 0 && kk > 0 && kk < T)) continue;
+    const int slot = kk / kSeg;
+    const int base = hl.ckb + ((DIR * 2 + (slot & 1)) * HxLds::kCkCells + HxLds::kCkPad) * 8;
+    h_d2 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int i = 64 * q + lane;
+      c[q] = h_d2{0.0, 0.0};
+      if (64 * q < npairs) c[q] = *(volatile lds_d2*)(L0 + base + 16 * min(i, npairs - 1));
+      if (i >= S) c[q].y = 0.0;
+      if (i > S) c[q].x = 0.0;
+    }
+    *(volatile lds_int*)(L0 + hl.ckdone + 4 * DIR) = ++done;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (64 * q >= npairs) break;
+      const int i = 64 * q + lane;
+      int mm = max(__double2hiint(c[q].x), __double2hiint(c[q].y));
+      if (F2PPL >= 2) mm = max(mm, dpp_i<0xB1>(0, mm));
+      if (F2PPL >= 4) mm = max(mm, dpp_i<0x4E>(0, mm));
+      const int own = ((mm >> 20) & 0x7ff) - 1023;
+      const int st = mm > 0 ? own : -30000;
+      if (i < npairs && (i & ~(F2PPL - 1)) <= S) {
+        float2 o;
+        o.x = mm > 0 ? (float)ldexp(c[q].x, -own) : 0.f; o.y = mm > 0 ? (float)ldexp(c[q].y, -own) : 0.f;
+        *reinterpret_cast<float2*>(ck + (size_t)slot * p.CELLS + 2 * i) = o;
+        short* cke = p.ckE + (((size_t)b * p.NS + slot) * 2 + DIR) * 64;
+        if ((i & (F2PPL - 1)) == 0) cke[i / F2PPL] = (short)st;
+      }
+    }
+  }
+}
+
 // Waves: 2 * kMaxW chain waves (alpha0, beta0, alpha1, beta1, ...: waves of a workgroup land on the SIMDs in the order 0,2,1,3),
 // the two frame waves, four probability-row waves (alternating alpha side / beta side), the two checkpoint waves (the second
 // writes the lattice description first).
@@ -584,7 +678,10 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(Hx<NP>::kWaves * 64) void ctc_fast
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V;
-  const HxLds hl(V);
+  const HxLds hl(V, NP);
+#ifdef E2E_FAST_PROFILE
+  if (tid < 128 && lane == 0 && b < 256) { unsigned long long* g = g_tl + ((size_t)b * 2 + (tid >> 6)) * 12; g[0] = __builtin_amdgcn_s_memtime(); g[1] = wall_clock64(); }
+#endif
 
   if (b == 0 && tid < 32) p.ctl[tid] = 0;
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
@@ -607,7 +704,8 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(Hx<NP>::kWaves * 64) void ctc_fast
     reinterpret_cast<double*>(smem + hl.ring + (i / kBlk) * hl.blk_bytes)[V * kRow + (i % kBlk)] = 0;
   __syncthreads();
 
-  constexpr int kChains = 2 * Hx<NP>::kMaxW, kFrame = kChains, kProd = kChains + 2, kCkpt = kProd + 2 * kHxProducers;
+  constexpr int kChains = 2 * Hx<NP>::kMaxW, kFrame = E2E_HX_SLIM ? kChains + 2 * kHxProducers : kChains,
+                kProd = E2E_HX_SLIM ? kChains : kChains + 2, kCkpt = kProd + 2 * kHxProducers;
   const int wave = __builtin_amdgcn_readfirstlane(wid);
   lds_u8* L0 = (lds_u8*)smem;
   if (wave < kChains) {
@@ -615,6 +713,9 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(Hx<NP>::kWaves * 64) void ctc_fast
     if (w >= W) return;
     if (d == 0) hx_chain_wave<0, NP>(p, b, T, S, smem, hl, lane, w, W);
     else hx_chain_wave<1, NP>(p, b, T, S, smem, hl, lane, w, W);
+  } else if (E2E_HX_SLIM && wave >= kFrame) {
+    if (wave == kFrame) hx_frame_ckpt_wave<0, PPL>(p, b, T, S, L0, hl, lane, W, Hx<NP>::kOwn * W);
+    else hx_frame_ckpt_wave<1, PPL>(p, b, T, S, L0, hl, lane, W, Hx<NP>::kOwn * W);
   } else if ((E2E_HX_ABL & 8) && (wave == kFrame || wave == kFrame + 1)) { return;
   } else if ((E2E_HX_ABL & 16) && (wave == kCkpt || wave == kCkpt + 1)) { return;
   } else if ((E2E_HX_ABL & 2) && wave >= kProd && wave < kCkpt) { return;
@@ -631,12 +732,15 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(Hx<NP>::kWaves * 64) void ctc_fast
 #define HX_PREP(NVV) { if (d == 0) hx_prep_wave<NVV, 0>(p, b, T, first, smem, hl, lane, rr2); else hx_prep_wave<NVV, 1>(p, b, T, first, smem, hl, lane, rr2); }
     if (V <= 16) HX_PREP(2) else if (V <= 32) HX_PREP(4) else if (V <= 48) HX_PREP(6) else if (V <= 64) HX_PREP(8) else HX_PREP(12)
 #undef HX_PREP
+    // (eight waves: the lattice description -- only the segment kernel reads it -- by the alpha producer, whose rows are all in
+    //  the ring a ring's depth of blocks before the chains end)
+    if (E2E_HX_SLIM && d == 0 && first == 0) cellinfo_wave<PPL>(p, b, T, S, reinterpret_cast<int*>(smem + hl.sortcnt), lane);
   }
 }
 
 template <int PPL, int NP>
 int launch_hx(const FastParams& p, hipStream_t stream) {
-  const HxLds hl(p.V);
+  const HxLds hl(p.V, NP);
   E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_hx_kernel<PPL, NP>), hl.total), "hipFuncSetAttribute");
   hipLaunchKernelGGL((ctc_fast_chain_hx_kernel<PPL, NP>), dim3(p.B), dim3(Hx<NP>::kWaves * 64), hl.total, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hx_kernel launch");
@@ -662,6 +766,9 @@ int launch_fast_h1_chain(const FastParams& p, int ppl, hipStream_t stream) {
 }  // namespace e2e
 
 #ifdef E2E_FAST_PROFILE
+extern "C" int e2e_debug_fast_timeline_h1(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(e2e::fastk::g_tl), sizeof(unsigned long long) * 256 * 2 * 12) == hipSuccess ? 0 : E2E_ERR_HIP;
+}
 extern "C" int e2e_debug_fast_profile3_h1(unsigned long long* host, int reset) {
   if (reset) { void* ptr; if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(e2e::fastk::g_prof3)) != hipSuccess) return E2E_ERR_HIP;
     return hipMemset(ptr, 0, sizeof(unsigned long long) * 256 * 16 * 4) == hipSuccess ? 0 : E2E_ERR_HIP; }

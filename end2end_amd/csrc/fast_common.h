@@ -250,6 +250,8 @@ static __device__ unsigned long long g_prof[256 * 4 * 4];    // [wg][wave][total
 static __device__ unsigned long long g_prof2[16384 * 8];     // F2 phase cycles per workgroup (first 16384)
 static __device__ unsigned long long g_prof3[256 * 16 * 4];  // halo chains: [wg][dir*8 + wave][total, probability-ring wait, neighbour wait, frame wait]
 static __device__ float g_zdev[16384];                        // F2 self-check: log2 deviation per workgroup
+static __device__ unsigned long long g_tl[256 * 2 * 12];     // lean halo chains, first wave of a direction: [wg][dir][s_memtime, 100 MHz clock] x (kernel entry,
+                                                              //  behind the entry barrier, first block's probabilities there, last step done, exit)
 __shared__ unsigned long long s_prof_prev;
 __shared__ unsigned long long s_prof_acc[8];
 #define F2_STAMP(i) { unsigned long long _t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \

@@ -24,7 +24,32 @@ from ._runtime import _C
 def _as_long(t, device):
     if not torch.is_tensor(t):
         t = torch.as_tensor(t)
+    elif t.dtype == torch.long and t.device == device and t.is_contiguous():
+        return t                         # (the usual case on a training step: nothing to convert, no dispatcher round trips)
     return t.to(device=device, dtype=torch.long).contiguous()
+
+
+_REDUCTIONS = {None: _C.REDUCE_NONE, "sum": _C.REDUCE_SUM, "mean": _C.REDUCE_MEAN}
+_ws_bytes = {}                           # (B, T, V, Smax, dtype code, algo) -> e2e_ctc_loss_workspace_bytes
+
+
+def _on_device(dev):
+    """A context that makes `dev` the current GPU -- none at all when it already is (the context manager costs ~10 us of host time
+    per entry, which on a 130 us step is what decides whether the host stays ahead of the GPU)."""
+    if torch.cuda.current_device() == dev.index:
+        return _NULL_CTX
+    return torch.cuda.device(dev)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL_CTX = _NullCtx()
 
 
 class CTCLossEngine:
@@ -90,8 +115,11 @@ class CTCLossEngine:
             return out if reduction is None else out + (getattr(out[0], reduction)(),)
         reduced = torch.empty((), dtype=loss_dtype, device=dev) if reduction else None
         code = R.dtype_code(x.dtype)
-        with torch.cuda.device(dev):
-            nbytes = _C.ctc_loss_workspace_bytes(B, T, V, Smax, code, self.algo)
+        with _on_device(dev):
+            key = (B, T, V, Smax, code, self.algo)
+            nbytes = _ws_bytes.get(key)
+            if nbytes is None:
+                nbytes = _ws_bytes[key] = _C.ctc_loss_workspace_bytes(B, T, V, Smax, code, self.algo)
             ws = R.workspace(dev, nbytes)
             sB, sT, sV = x.stride()
             _C.ctc_loss_fwd_bwd(x.data_ptr(), code, bool(input_is_logprobs), sB, sT, sV,
@@ -100,7 +128,7 @@ class CTCLossEngine:
                                 losses.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(),
                                 self.algo, R.stream_handle(dev), float(grad_scale),
                                 reduced.data_ptr() if reduction else 0,
-                                {None: _C.REDUCE_NONE, "sum": _C.REDUCE_SUM, "mean": _C.REDUCE_MEAN}[reduction],
+                                _REDUCTIONS[reduction],
                                 _C.CHAINS_F32 if self.f32_chains else _C.CHAINS_F64)
         if src_device != dev or src_dtype != losses.dtype:
             losses = losses.to(src_device, src_dtype)
@@ -117,12 +145,13 @@ class CTCLossEngine:
         CUDA tensor, `scale` a (B,) tensor -- or a single element, which then scales the whole tensor."""
         if not (grads.is_cuda and grads.is_contiguous()):
             raise ValueError("scale_grads_ needs a contiguous GPU tensor")
-        scale = scale.detach().to(device=grads.device, dtype=grads.dtype).contiguous().view(-1)
+        if scale.device != grads.device or scale.dtype != grads.dtype or not scale.is_contiguous():
+            scale = scale.detach().to(device=grads.device, dtype=grads.dtype).contiguous()
         B = grads.shape[0] if scale.numel() != 1 else 1
         if scale.numel() != B:
             raise ValueError("scale must have one entry per utterance (or a single one)")
         if grads.numel():
-            with torch.cuda.device(grads.device):
+            with _on_device(grads.device):
                 _C.ctc_scale_grads(grads.data_ptr(), R.dtype_code(grads.dtype), scale.data_ptr(), B,
                                    grads.numel() // B, R.stream_handle(grads.device))
         return grads
