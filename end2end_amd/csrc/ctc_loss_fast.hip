@@ -43,12 +43,12 @@ namespace {
 //     B~' = B~ * yb + L^prev                         (yb: blank probability of the frame just processed)
 //     L^' = (L^ + (r^2 yb) * B~ + skip * L^prev) * y'[label]
 // -- the same recurrence, with the blank emission applied one step late.  Checkpoints and log Z convert back.
-template <int PPL, int DIR>
+template <int PPL, int DIR, int RB = kRingBlks>
 __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, int S, const F1Lds& lds, int lane) {
   constexpr int NC = 2 * PPL;
   const int V = p.V, blank = p.blank, L = 2 * S + 1;
   const int nblk = (T + kBlk - 1) / kBlk;
-  const double* myring = lds.ring + (size_t)DIR * kRingBlks * lds.blk_elems;
+  const double* myring = lds.ring + (size_t)DIR * RB * lds.blk_elems;
   volatile int* myfilled = lds.filled + DIR * kRingBlks;
   __builtin_amdgcn_s_setprio(3);
   unsigned long long prof_spin = 0, prof_t0 = __builtin_amdgcn_s_memtime(), prof_steps = 0;
@@ -81,7 +81,7 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
   d2 eraw[PPL][4], braw[4];
   auto load_half = [&](int n, auto half_tag) {
     constexpr int H = decltype(half_tag)::value;
-    const double* blk = myring + (size_t)(n % kRingBlks) * lds.blk_elems;
+    const double* blk = myring + (size_t)(n % RB) * lds.blk_elems;
 #pragma unroll
     for (int r = 0; r < PPL; r++) {
       const d2* src = reinterpret_cast<const d2*>(blk + lc.lab[r] * kRow);
@@ -99,7 +99,7 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
     publish(lds.took + DIR, n + 1);
     const bool want_next = n + 1 < nblk;
     int next_filled = 0;
-    if (want_next) next_filled = peek(&myfilled[(n + 1) % kRingBlks]);
+    if (want_next) next_filled = peek(&myfilled[(n + 1) % RB]);
     double yb[kBlk], e[kBlk][PPL];
     const int tbase = block_time(DIR, n, 0, T);          // t of tt = 0; t = tbase +/- tt
 #ifdef E2E_FAST_PROFILE
@@ -115,7 +115,7 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
         // the halves for steps 0..3 are dead by now.  The producers normally run several blocks ahead; if not, the
         // wave waits here.  (Behind the last block the read fetches a stale slot that nobody uses.)
         if (want_next && __builtin_amdgcn_readfirstlane(next_filled) != n + 2) {
-          PROF_SPIN_BEGIN spin_until(&myfilled[(n + 1) % kRingBlks], n + 2); PROF_SPIN_END(prof_spin)
+          PROF_SPIN_BEGIN spin_until(&myfilled[(n + 1) % RB], n + 2); PROF_SPIN_END(prof_spin)
         }
         load_half(n + 1, std::integral_constant<int, 0>{});
       }
@@ -248,12 +248,16 @@ __device__ __forceinline__ void chain_wave(const FastParams& p, int b, int T, in
 // description for F2 and retires, wave 5 retires at once.
 // (Splitting a chain's lanes over two pipelined waves was tried and does not pay: the per-block bookkeeping does not
 // shrink with the cells, and a lone wave's speed is its instruction count.)
-template <int PPL>
+// RB: the probability ring's depth.  Eight blocks by default; FOUR where eight would keep a second workgroup off the CU although the
+// batch has more utterances than the chip has CUs (round 6: one GPU's share of BASELINE configs[4], 512 utterances on 65 compact
+// columns -- 84.5 KB of ring per workgroup, i.e. two ROUNDS of 256 workgroups, 61 us for 256 steps; with 42 KB the two rounds
+// run side by side on SIMDs that a lone chain wave leaves half idle).
+template <int PPL, int RB = kRingBlks>
 __global__ E2E_KERNEL_ALIGN __launch_bounds__(512) void ctc_fast_chain_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V;
-  const F1Lds lds(smem, V);
+  const F1Lds lds(smem, V, RB);
 
   if (b == 0 && tid < 32) p.ctl[tid] = 0;     // (this kernel ends before the fallback launch, which counts there, starts)
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
@@ -266,27 +270,27 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(512) void ctc_fast_chain_kernel(Fa
   if (tid == 0) p.flags[b] = 0;    // (the barrier below orders this before the waves' atomicOr; saves a memset launch)
   for (int i = tid; i < p.MW; i += blockDim.x) p.segmask[(size_t)b * p.MW + i] = 0u;
   if (tid < F1Lds::kSyncInts) lds.filled[tid] = 0;
-  for (int i = tid; i < 2 * kRingBlks * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
+  for (int i = tid; i < 2 * RB * kBlk; i += blockDim.x)      // the zero rows (label index V) of every block
     lds.ring[(size_t)(i / kBlk) * lds.blk_elems + V * kRow + (i % kBlk)] = 0.0;
   __syncthreads();
 
   const int wave = __builtin_amdgcn_readfirstlane(wid);
-  if (wave == 0) chain_wave<PPL, 0>(p, b, T, S, lds, lane);
-  else if (wave == 1) chain_wave<PPL, 1>(p, b, T, S, lds, lane);
+  if (wave == 0) chain_wave<PPL, 0, RB>(p, b, T, S, lds, lane);
+  else if (wave == 1) chain_wave<PPL, 1, RB>(p, b, T, S, lds, lane);
   else if (wave == 4) cellinfo_wave<PPL>(p, b, T, S, lds.sortcnt, lane);
   else if (wave == 5) return;
   else {
     const int d = (wave == 2 || wave == 6) ? 0 : 1;     // waves 2,6 -> alpha rows, waves 3,7 -> beta rows
     const int first = wave >= 6 ? 1 : 0;                 // the two producers of a direction take alternate blocks
-    unsigned char* ring = reinterpret_cast<unsigned char*>(lds.ring + (size_t)d * kRingBlks * lds.blk_elems);
+    unsigned char* ring = reinterpret_cast<unsigned char*>(lds.ring + (size_t)d * RB * lds.blk_elems);
     const int bb = lds.blk_elems * 8;
     volatile int* fl = lds.filled + d * kRingBlks;
     volatile int* tk = lds.took + d;
-    if (V <= 16) prep_wave<2>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
-    else if (V <= 32) prep_wave<4>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
-    else if (V <= 48) prep_wave<6>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
-    else if (V <= 64) prep_wave<8>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
-    else prep_wave<12>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
+    if (V <= 16) prep_wave<2, 0, RB>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
+    else if (V <= 32) prep_wave<4, 0, RB>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
+    else if (V <= 48) prep_wave<6, 0, RB>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
+    else if (V <= 64) prep_wave<8, 0, RB>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
+    else prep_wave<12, 0, RB>(p, b, T, d, first, 2, ring, bb, fl, tk, lane);
   }
 }
 
@@ -1751,9 +1755,12 @@ __device__ __forceinline__ void segment_wave(const P& p, unsigned char* smem) {
 #define E2E_F2_MINW 2
 #endif
 #define E2E_F2_MINW4 (E2E_F2_HALF ? 3 : E2E_F2_MINW)     // four pairs per lane: three waves per SIMD with half the alpha rows kept
+#ifndef E2E_F2_MINW2                // two pairs per lane: 134 registers by themselves = three waves per SIMD; held to 128 (five spilled, 24 bytes
+#define E2E_F2_MINW2 4              // of scratch) four fit -- round 6: B=256, T=1000, S<=100 111.3 -> 102.8 us per call, the compact lattice of
+#endif                              // configs[4] (B=512, T=256, 65 columns) 78.5 -> 75.6
 // (eight pairs per lane: 16 alpha rows of 16 cells are 256 registers by themselves -- one wave per SIMD, no spills)
 template <int PPL, bool O16, bool BIG = false>
-__global__ E2E_KERNEL_ALIGN __launch_bounds__(64 * E2E_F2_WPB, PPL == 8 ? 1 : PPL == 4 ? E2E_F2_MINW4 : E2E_F2_MINW) void ctc_fast_segment_kernel(FastParams p) {
+__global__ E2E_KERNEL_ALIGN __launch_bounds__(64 * E2E_F2_WPB, PPL == 8 ? 1 : PPL == 4 ? E2E_F2_MINW4 : PPL == 2 ? E2E_F2_MINW2 : E2E_F2_MINW) void ctc_fast_segment_kernel(FastParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   SegParams<O16, BIG> q;
   static_cast<FastParams&>(q) = p;
@@ -1861,7 +1868,14 @@ int launch_fast_ppl(const FastParams& p, hipStream_t stream) {
     E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_hf_kernel launch");
     return launch_segments<PPL>(p, lds2, stream);
   }
-  hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
+  // (the ring at half its depth where the full one keeps a second workgroup off a CU that the batch has work for)
+  static const char* rb_env = getenv("E2E_F1_RING");               // (A/B: 4 / 8 forces the depth)
+  const bool shallow = rb_env ? rb_env[0] == '4' : (p.B > 256 && lds1 > 80 * 1024 && F1Lds::bytes(p.V, 4) <= 80 * 1024);
+  if (shallow) {
+    const size_t lds4 = F1Lds::bytes(p.V, 4);
+    E2E_HIP_CHECK(allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_fast_chain_kernel<PPL, 4>), (int)lds4), "hipFuncSetAttribute");
+    hipLaunchKernelGGL((ctc_fast_chain_kernel<PPL, 4>), dim3(p.B), dim3(512), lds4, stream, p);
+  } else hipLaunchKernelGGL(ctc_fast_chain_kernel<PPL>, dim3(p.B), dim3(512), lds1, stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "ctc_fast_chain_kernel launch");
   FastParams q = p; q.trkA = p.cumA; q.trkB = p.cumB;          // (its frame follows the maximum itself)
   return launch_segments<PPL>(q, lds2, stream);

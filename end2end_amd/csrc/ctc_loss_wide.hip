@@ -46,6 +46,26 @@ __device__ __forceinline__ float exp_acc(float x) {        // ~1 ulp, x <= ~88
   return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 
+// exp(x) for x <= 0 where 1e-6 relative is plenty (the dense rows' exp(x - max): the result is a probability <= 1 that ends up in
+// a gradient held to 2e-6 absolute, or in a 16-bit number): the product's rounding, |x| log2(e) 2^-24, is the whole error.
+// Two instructions instead of exp_acc's eight.  What it buys, in one process (tools/diag/ab_time.py, B=512, T=256, V=8000): nothing for f32
+// and bf16 rows (1740 / 985 us per call either way: those kernels wait for HBM) and 1535 -> 995 us for f16 rows, whose kernel no longer
+// spills (86 registers instead of 168 + 41 spilled).
+#ifndef E2E_WIDE_FAST_EXP
+#define E2E_WIDE_FAST_EXP 1
+#endif
+// exp(x - M) with mM = -M log2(e) worked out once per row: one multiply-add and v_exp_f32 (exp2(-inf) = 0: padding lanes need no clamp;
+// the rounding of mM is common to the whole row and cancels in the normalisation)
+__device__ __forceinline__ float exp_row(float x, float M, float mM) {
+#if E2E_WIDE_FAST_EXP
+  (void)M;
+  return __builtin_amdgcn_exp2f(fmaf(x, 1.44269504088896340736f, mM));
+#else
+  (void)mM;
+  return exp_acc(x - M);
+#endif
+}
+
 __device__ __forceinline__ float wave_max_f(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
 __device__ __forceinline__ float wave_sum_f(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
 
@@ -356,7 +376,7 @@ __device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
 #pragma unroll
       for (int e = 0; e < EPC; e++) m = fmaxf(m, f[e]);
     }
-    const float M = wave_max_f(m);
+    const float M = wave_max_f(m), mM = -M * 1.44269504088896340736f;
     float sum = 0.f;
 #pragma unroll
     for (int u = 0; u < NCH; u++) {
@@ -364,7 +384,7 @@ __device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
         fv f = as_f32(v[u]);
         float part = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPC; e++) { f[e] = exp_acc(f[e] - M); part += f[e]; }
+        for (int e = 0; e < EPC; e++) { f[e] = exp_row(f[e], M, mM); part += f[e]; }
         v[u] = to_held(f * kHeld);
         sum += (64 * u + 64 <= n4 || part_in) ? part : 0.f;
       }
@@ -419,6 +439,8 @@ void wide_rows_dense_kernel(WideParams p) { wide_rows_dense_body<NV4, E>(p); }
 template <int NV4, typename E>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(3)))
 void wide_rows_dense_kernel_16(WideParams p) { wide_rows_dense_body<NV4, E>(p); }
+// (Two 16-bit rows per wave -- both asked for before either is looked at: 384 KB in flight per CU instead of 192 -- were built in round 6
+//  and are slower, 1131 against 985 us per call for bf16 in one process (tools/diag/ab_time.py with AB_DTYPE): removed.)
 
 // after the lattice: the label columns of the live frames; the slab of an utterance that turned out infeasible
 template <typename E>

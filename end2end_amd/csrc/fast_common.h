@@ -370,14 +370,15 @@ struct F1Lds {
   int* sortcnt;      // [130] counting-sort scratch of the cell-info wave (V <= 96 here: two chunks of 64 labels + 2)
   int blk_elems;
   static constexpr int kSyncInts = 2 * kRingBlks + 2;
-  __device__ F1Lds(unsigned char* smem, int V) {
+  // rb: the ring's depth in blocks -- kRingBlks, or 4 where that lets a second workgroup onto the CU (ctc_fast_chain_kernel's RB)
+  __device__ F1Lds(unsigned char* smem, int V, int rb = kRingBlks) {
     blk_elems = (V + 1) * kRow;
     ring = reinterpret_cast<double*>(smem);
-    filled = reinterpret_cast<int*>(ring + 2 * kRingBlks * blk_elems);
+    filled = reinterpret_cast<int*>(ring + 2 * rb * blk_elems);
     took = filled + 2 * kRingBlks;
     sortcnt = took + 2;
   }
-  __host__ __device__ static size_t bytes(int V) { return sizeof(double) * 2 * kRingBlks * (V + 1) * kRow + sizeof(int) * (kSyncInts + 130); }
+  __host__ __device__ static size_t bytes(int V, int rb = kRingBlks) { return sizeof(double) * 2 * rb * (V + 1) * kRow + sizeof(int) * (kSyncInts + 130); }
 };
 
 // Block geometry shared by prep and chain.  Both directions work in blocks of 8 steps that are ALIGNED in
@@ -406,7 +407,7 @@ __device__ __forceinline__ float exp_le0(float x) {
 // producers share their SIMDs with the chain waves, so their instruction count is the chains' speed too.)
 // MODE 0: f64 ring read by one chain wave (`took`); 1 / 2: f64 / f32 ring of ctc_fast_chain_hf_kernel -- label rows and one
 // row of (blank probability, tilted blank probability) pairs, read by several waves whose progress words replace `took`.
-template <int NV, int MODE = 0>
+template <int NV, int MODE = 0, int RB = kRingBlks>
 __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int dir, int first, int stride,
                                           unsigned char* myring_bytes, int blk_bytes, volatile int* myfilled, volatile int* took,
                                           int lane, lds_u8* prog = nullptr, double rr2 = 0.0) {
@@ -458,17 +459,17 @@ __device__ __forceinline__ void prep_wave(const FastParams& p, int b, int T, int
 #pragma unroll
       for (int k = 0; k < NV; k++) xv[k] = (row_in && col_live[k]) ? xraw[k] : ninf;
     }
-    const int slot = n % kRingBlks;
-    if (n >= kRingBlks) {
+    const int slot = n % RB;
+    if (n >= RB) {
       PROF_SPIN_BEGIN
       if (HALO) {
         // (the readers' progress is looked at again only when the last look does not cover this block)
-        while (consumed < n - kRingBlks + 1) {
+        while (consumed < n - RB + 1) {
           consumed = __builtin_amdgcn_readfirstlane(lds_min8(prog));
-          if (consumed < n - kRingBlks + 1) __builtin_amdgcn_s_sleep(1);
+          if (consumed < n - RB + 1) __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
-      } else spin_until_ge(took, n - kRingBlks + 1);
+      } else spin_until_ge(took, n - RB + 1);
       PROF_SPIN_END(prof_spin)
     }
     double* blk = reinterpret_cast<double*>(myring_bytes + (size_t)slot * blk_bytes);
