@@ -113,19 +113,22 @@ __global__ __launch_bounds__(256) void wide_compact_kernel(WideParams p) {
 }
 
 // log-sum-exp of every live frame + its compact log-probs.  One wave per frame.
-template <bool VEC4>
+// E: the logits' element type.  16-bit logits take the element-wise form (VEC4 = false) -- rows of more than 8192 or of unaligned
+// columns, which the single-read kernels below do not hold: round 6; until then such a call was refused and the host up-cast it.
+template <bool VEC4, typename E = float>
 __global__ __launch_bounds__(64 * kWaves) void wide_rows_kernel(WideParams p) {
+  static_assert(!VEC4 || sizeof(E) == 4, "16-byte accesses: f32 rows");
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * kWaves + w;
   if (row >= (int64_t)p.B * p.T) return;
   int b, t; split_frame(row, p.T, b, t);
   const int64_t Tq = p.x_len[b];
   if (t >= Tq) return;
-  const float* xr = p.x + (int64_t)b * p.sB + (int64_t)t * p.sT;
+  const E* xr = reinterpret_cast<const E*>(p.x) + (int64_t)b * p.sB + (int64_t)t * p.sT;
   float lse = 0.f;
   if (!p.logprobs) {
     float m = -__builtin_huge_valf(), s = 0.f;
-    if (VEC4) {
+    if constexpr (VEC4) {
       const float4* x4 = reinterpret_cast<const float4*>(xr);
       const int n4 = p.V >> 2;
       int i = lane;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_rows_kernel(WideParams p) {
       }
     } else {
       for (int i = lane; i < p.V; i += 64) {
-        const float v = xr[(int64_t)i * p.sV];
+        const float v = (float)xr[(int64_t)i * p.sV];
         if (v > m) { s *= exp_acc(m - v); m = v; }
         s += exp_acc(v - m);
       }
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_rows_kernel(WideParams p) {
   float cm = -__builtin_huge_valf();
   for (int k = lane; k < p.VC; k += 64) {
     const int l = cl[k];
-    const float v = l >= 0 ? xr[(int64_t)l * p.sV] - lse : -__builtin_huge_valf();
+    const float v = l >= 0 ? (float)xr[(int64_t)l * p.sV] - lse : -__builtin_huge_valf();
     xc[k] = v;
     cm = fmaxf(cm, v);
   }
@@ -193,15 +196,16 @@ __global__ __launch_bounds__(64) void wide_loss_fix_kernel(WideParams p) {
 }
 
 // dense gradient rows.  One wave per frame.
-template <bool VEC4>
+template <bool VEC4, typename E = float>
 __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
+  static_assert(!VEC4 || sizeof(E) == 4, "16-byte accesses: f32 rows");
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * kWaves + w;
   if (row >= (int64_t)p.B * p.T) return;
   int b, t; split_frame(row, p.T, b, t);
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
-  const float* xr = p.x + (int64_t)b * p.sB + (int64_t)t * p.sT;
-  float* gr = p.grads + (size_t)row * p.V;
+  const E* xr = reinterpret_cast<const E*>(p.x) + (int64_t)b * p.sB + (int64_t)t * p.sT;
+  E* gr = reinterpret_cast<E*>(p.grads) + (size_t)row * p.V;
   const bool bad_len = Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax;
   const float loss = p.losses[b];
   const bool poison = bad_len || !(loss < __builtin_huge_valf());      // invalid lengths / infeasible (Q2) / NaN
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
       if (k < p.VC) {
         const int l = cl[k];
         if (l >= 0 && live) {
-          const float xl = xr[(int64_t)l * p.sV] - lse;
+          const float xl = (float)xr[(int64_t)l * p.sV] - lse;
           fix[u] = (exp_acc(xl) - (exp_acc(xl - sh) - gc[k])) * p.gscale;
           fixcol[u] = l;
         } else if (l >= 0 && gc[k] == -__builtin_huge_valf()) {
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
       }
     }
   }
-  if (VEC4) {
+  if constexpr (VEC4) {
     typedef float vf4 __attribute__((ext_vector_type(4)));
     const vf4* x4 = reinterpret_cast<const vf4*>(xr);
     vf4* g4 = reinterpret_cast<vf4*>(gr);
@@ -278,14 +282,14 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
     }
     for (int i = (n4 << 2) + lane; i < p.V; i += 64) gr[i] = poison ? qnan : (zero ? 0.f : exp_acc(xr[i] - lse) * p.gscale);
   } else {
-    for (int i = lane; i < p.V; i += 64) gr[i] = poison ? qnan : (zero ? 0.f : exp_acc(xr[(int64_t)i * p.sV] - lse) * p.gscale);
+    for (int i = lane; i < p.V; i += 64) gr[i] = (E)(poison ? qnan : (zero ? 0.f : exp_acc((float)xr[(int64_t)i * p.sV] - lse) * p.gscale));
   }
   if (live || inf_pattern) {
     // the dense row above and these columns are written by different lanes of this wave: order them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);
 #pragma unroll
-    for (int u = 0; u < kMaxFix; u++) if (fixcol[u] >= 0) gr[fixcol[u]] = fix[u];
+    for (int u = 0; u < kMaxFix; u++) if (fixcol[u] >= 0) gr[fixcol[u]] = (E)fix[u];
     // compact columns beyond the 128 fetched up front (targets of more than 127 distinct labels)
     const float* gc = p.gc + (size_t)row * p.VC;
     const int* cl = p.clabel + (size_t)b * p.VC;
@@ -293,10 +297,10 @@ __global__ __launch_bounds__(64 * kWaves) void wide_emit_kernel(WideParams p) {
     for (int k = lane + 64 * kMaxFix; k < p.VC; k += 64) {
       const int l = cl[k];
       if (l >= 0 && live) {
-        const float xl = xr[(int64_t)l * p.sV] - lse;
-        gr[l] = (exp_acc(xl) - (exp_acc(xl - sh) - gc[k])) * p.gscale;
+        const float xl = (float)xr[(int64_t)l * p.sV] - lse;
+        gr[l] = (E)((exp_acc(xl) - (exp_acc(xl - sh) - gc[k])) * p.gscale);
       } else if (l >= 0 && gc[k] == -__builtin_huge_valf()) {
-        gr[l] = -__builtin_huge_valf();
+        gr[l] = (E)(-__builtin_huge_valf());
       }
     }
   }
@@ -559,10 +563,6 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
   const bool vec4 = a.sV == 1 && (a.sT % epc == 0) && (a.sB % epc == 0) && (reinterpret_cast<uintptr_t>(a.x) % 16 == 0) &&
                     (a.V % epc == 0) && (reinterpret_cast<uintptr_t>(a.grads) % 16 == 0);
   const bool dense = vec4 && a.V <= 8192;          // the row fits a wave's registers: logits read once
-  if (io16 && !dense) {
-    set_error("16-bit logits on the wide path need contiguous rows of a multiple of 8 (<= 8192) columns, 16-byte aligned");
-    return E2E_ERR_UNSUPPORTED;
-  }
   hipLaunchKernelGGL(wide_compact_kernel, dim3(a.B), dim3(256), sizeof(int) * 3 * (a.Smax > 0 ? a.Smax : 1), a.stream, p);
   E2E_HIP_CHECK(hipGetLastError(), "wide_compact_kernel launch");
 
@@ -590,7 +590,9 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
         }
       };
       if (a.dtype == E2E_F16) rows(f16_t{}); else if (a.dtype == E2E_BF16) rows(bf16_t{}); else rows(float{});
-    } else if (vec4) hipLaunchKernelGGL(wide_rows_kernel<true>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+    } else if (a.dtype == E2E_F16) hipLaunchKernelGGL((wide_rows_kernel<false, f16_t>), grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+    else if (a.dtype == E2E_BF16) hipLaunchKernelGGL((wide_rows_kernel<false, bf16_t>), grid_rows, dim3(64 * kWaves), 0, s_rows, q);
+    else if (vec4) hipLaunchKernelGGL(wide_rows_kernel<true>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
     else hipLaunchKernelGGL(wide_rows_kernel<false>, grid_rows, dim3(64 * kWaves), 0, s_rows, q);
     E2E_HIP_CHECK(hipGetLastError(), "wide rows kernel launch");
     return E2E_OK;
@@ -636,6 +638,8 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
       else if (a.dtype == E2E_BF16) hipLaunchKernelGGL(wide_fix_kernel<bf16_t>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
       else hipLaunchKernelGGL(wide_fix_kernel<float>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
     }
+    else if (a.dtype == E2E_F16) hipLaunchKernelGGL((wide_emit_kernel<false, f16_t>), grid_rows, dim3(64 * kWaves), 0, s_lat, q);
+    else if (a.dtype == E2E_BF16) hipLaunchKernelGGL((wide_emit_kernel<false, bf16_t>), grid_rows, dim3(64 * kWaves), 0, s_lat, q);
     else if (vec4) hipLaunchKernelGGL(wide_emit_kernel<true>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
     else hipLaunchKernelGGL(wide_emit_kernel<false>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
     E2E_HIP_CHECK(hipGetLastError(), "wide emit kernel launch");

@@ -86,8 +86,10 @@ size_t e2e_ctc_loss_workspace_bytes(int B, int T, int V, int Smax, int dtype, in
 
 /* 1 if a loss call with these logits runs as it is; 0 if the caller has to up-cast them to f32 first (then the call would
  * return E2E_ERR_UNSUPPORTED).  Always 1 for E2E_F32 / E2E_F64.  16-bit logits are read natively by the lattice kernels
- * (alphabets of <= 448 columns, targets of <= 447 labels: any strides) and by the wide-alphabet path when its rows can be
- * read in one pass: contiguous (sV == 1), V % 8 == 0, V <= 8192, strides of whole 16-byte pieces, x and grads 16-byte aligned. */
+ * (alphabets of <= 448 columns, targets of <= 447 labels: any strides) and by the wide-alphabet path -- in one pass when its rows
+ * are contiguous (sV == 1), V % 8 == 0, V <= 8192, strides of whole 16-byte pieces, x and grads 16-byte aligned; element by
+ * element in two passes otherwise (since ABI 3).  What is left for 0: shapes only the exact kernel takes (E2E_ALGO_EXACT, or
+ * targets beyond 447 labels on an alphabet the wide path does not compact). */
 int e2e_ctc_loss_takes_dtype(int dtype, int algo, int T, int V, int Smax, int64_t sB, int64_t sT, int64_t sV,
                              const void* x, const void* grads);
 

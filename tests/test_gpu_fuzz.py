@@ -206,7 +206,7 @@ def test_scaled_and_exact_families_against_the_oracle(family, seed, n, wide):
 # ---------------------------------------------------------------------------------------------------------------------
 def _fast_case(rng):
     B = int(rng.integers(1, 9))
-    V = int(rng.choice([2, 5, 29, 29, 32, 33, 64, 96, 120, 224, 448, 1000, 8000]))
+    V = int(rng.choice([2, 5, 29, 29, 32, 33, 64, 96, 120, 224, 448, 1000, 1001, 8000]))     # (1001: the wide path's two-pass rows, 16-bit too)
     T = int(rng.choice([1, 3, 15, 16, 17, 33, 100, 256, 511, 1000]))
     Smax = int(rng.integers(1, min(447, max(1, (T + 1) // 2)) + 1))
     if V >= 1000:

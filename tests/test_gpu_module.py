@@ -258,8 +258,9 @@ def test_half_precision_logits_go_forward_and_backward(dtype, reduce):
     U.assert_same(got_l, l_o.mean() if reduce else l_o, 4 * eps, 4 * eps, "loss")
 
 
-@pytest.mark.parametrize("shape", [(8, 200, 48, 30), (4, 64, 8000, 20), (4, 200, 150, 120), (2, 200, 8000, 150)],
-                         ids=["fast_path_V48", "wide_path_V8000", "fast_path_V150", "wide_path_V8000_151_columns"])
+@pytest.mark.parametrize("shape", [(8, 200, 48, 30), (4, 64, 8000, 20), (4, 200, 150, 120), (2, 200, 8000, 150), (2, 40, 9000, 20), (3, 50, 8001, 15)],
+                         ids=["fast_path_V48", "wide_path_V8000", "fast_path_V150", "wide_path_V8000_151_columns",
+                              "wide_two_pass_V9000", "wide_two_pass_V8001_unaligned"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_half_precision_logits_are_read_and_written_natively(dtype, shape):
     """No f32 copy of the (B,T,V) logits or of the gradient is made for 16-bit inputs: the allocator's peak over a
