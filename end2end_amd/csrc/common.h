@@ -92,7 +92,7 @@ struct FastRetry {
   // the extended-range redo (ctc_ext.h): per-cell exponents of the checkpoint rows it writes over ckA / ckQ for the
   // utterances it takes, and their partition sums
   int* ckXA; int* ckXQ;            // [B][NS][CELLS]
-  double* extz;                    // [B][2]  Z = extz[0] * 2^extz[1]
+  double* extz;                    // [B][2]  Z = extz[0] * 2^extz[1]; behind them [B][2 sides][4]: the sides' cells of Z when alpha and beta ran on two workgroups
 };
 
 size_t exact_workspace_bytes(int B, int T, int V, int Smax);            // every utterance (algo EXACT)

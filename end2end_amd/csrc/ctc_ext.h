@@ -34,6 +34,8 @@ constexpr int kXHalo = 8, kXOwnLanes = 64 - kXHalo;
 constexpr int kExtDone = 2048;                // flag bit: the extended-range chains of the utterance are done (checkpoints, Z, loss)
 constexpr int kExtBad = 4096;                 // flag bit: ... and could not settle it (no alignment, a wait that timed out): exact kernel
 constexpr int kExtMaxList = 1024;             // utterances of one call the extended-range redo takes (the rest: exact kernel)
+constexpr int kExtHalfA = 8192, kExtHalfB = 16384;   // flag bits: the alpha / the beta chains of the utterance have finished ON A WORKGROUP OF THEIR OWN
+                                              // (few flagged utterances: see ext_chains); the side that finds the other one's bit combines
 
 __device__ __forceinline__ int x_fix(double m, int e) { return m != 0.0 ? e : kXZero; }
 __device__ __forceinline__ void x_norm(double& m, int& e) {          // mantissa back to [0.5, 1); zero stays (0, kXZero)
@@ -148,6 +150,9 @@ struct XTileFetch {
 // lasts 8 NP steps: at NP = 2 it is refreshed twice as often as it must be), stage the next tile, ask for the one after.
 template <int DIR, int NP, typename LT>
 __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned char* smem, int b, int T, int S, int w, int lane) {
+  // (w >= 4: a wave of a workgroup that runs ONE direction on all its eight waves -- it holds no cell, keeps the barriers and leaves
+  //  the tiles to the first four)
+  const bool stager = __builtin_amdgcn_readfirstlane(w < 4 ? 1 : 0) != 0;
   constexpr int kOwn = NP * kXOwnLanes;                             // pairs a wave owns
   const FastRetry& rt = p.retry;
   const int V = p.V, blank = p.blank, L = 2 * S + 1, Tmax = p.T;
@@ -192,8 +197,7 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
 
   // tile 0 of the walk into buffer 0
   XTileFetch<DIR> fetch;
-  fetch.load(rt, b, tile_of(0), Tmax, V, d_tid);
-  fetch.store(rt, tiles, V, d_tid);
+  if (stager) { fetch.load(rt, b, tile_of(0), Tmax, V, d_tid); fetch.store(rt, tiles, V, d_tid); }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   // STEADY: a tile strictly inside the walk -- all 8 rows live, none of them the chain's first
@@ -227,8 +231,8 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
     // ---- the tile after this one is asked for now and staged at this tile's end (into the other buffer: its readers left it
     //      before the barrier above): one tile -- 8 steps, ~2 us -- hides the round trip, and no loaded register lives across
     //      the loop's back edge (where the compiler waits for everything outstanding) ----
-    if (!(E2E_EXT_ABL & 1)) fetch.load(rt, b, tile_of(q + 1), Tmax, V, d_tid);
-    if (!active) { if (!(E2E_EXT_ABL & 1)) fetch.store(rt, tiles + ((q + 1) & 1) * tile_b, V, d_tid); return; }
+    if (!(E2E_EXT_ABL & 1) && stager) fetch.load(rt, b, tile_of(q + 1), Tmax, V, d_tid);
+    if (!active) { if (!(E2E_EXT_ABL & 1) && stager) fetch.store(rt, tiles + ((q + 1) & 1) * tile_b, V, d_tid); return; }
     // ---- checkpoints: alpha row t = 16 k - 1 -> slot k, beta-with-emission row t = 16 k -> slot k (0 < 16 k < T), cells in lattice
     //      order (blank g = cell 2 g, label g = cell 2 g + 1), the mantissa as f32.  The row is the one the tile before ended
     //      with (freshly normalised; the halo refill above does not touch the lanes that store).  Stored HERE, behind the
@@ -334,13 +338,18 @@ __device__ __forceinline__ void ext_chain_wave(const ExactParams& p, unsigned ch
 //  launch copies the 336 bytes per lane to scratch at the kernel's entry, in front of the early exit: the empty flagged launch
 //  9.6 instead of 5.3 us, the headline call +6.6 us.  profiles/r05_placement/; tests/test_host_cpu.py audits the built library
 //  for it.  The dynamic LDS is found again through its own declaration.)
+// half: -1 = both directions on this workgroup (waves (alpha w, beta w): every SIMD carries a wave of either direction); 0 / 1 = only
+// the alpha / only the beta chains, the other direction on ANOTHER workgroup (round 6, when the call has so few flagged utterances
+// that the launch has workgroups to spare -- 8 mislabelled utterances used 8 of 256 CUs): a chain wave then has its SIMD to itself.
+// The two sides leave their cells of Z in the workspace and meet through two bits of the utterance's flag word; whichever comes
+// second finishes the utterance.
 template <typename IO>
-__device__ __forceinline__ void ext_chains(const ExactParams& p, int b) {
+__device__ __forceinline__ void ext_chains(const ExactParams& p, int b, int half = -1) {
   extern __shared__ __align__(16) unsigned char smem[];
   typedef typename LossOf<IO>::type LT;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = (int)p.x_len[b], S = (int)p.t_len[b];
-  const int dir = wid & 1, w = wid >> 1;
+  const int dir = half < 0 ? (wid & 1) : half, w = half < 0 ? (wid >> 1) : wid;
   if (tid < 8) {
     double* z = reinterpret_cast<double*>(smem + ExtLds::zrec);
     z[tid] = (tid & 1) ? (double)kXZero : 0.0;
@@ -357,7 +366,21 @@ __device__ __forceinline__ void ext_chains(const ExactParams& p, int b) {
   __threadfence();
   __syncthreads();
   if (tid == 0) {
-    const double* z = reinterpret_cast<const double*>(smem + ExtLds::zrec);
+    double* z = reinterpret_cast<double*>(smem + ExtLds::zrec);
+    bool finish = true;
+    if (half >= 0) {
+      // this side's cells of Z into the workspace ([B][2] final values, then [B][2 sides][4]); then the ticket
+      double* zh = p.retry.extz + 2 * (size_t)p.B + 8 * (size_t)b;
+      for (int k = 0; k < 4; k++) zh[4 * half + k] = z[4 * half + k];
+      __threadfence();
+      const int old = atomicOr(&p.flags[b], half == 0 ? kExtHalfA : kExtHalfB);
+      finish = (old & (half == 0 ? kExtHalfB : kExtHalfA)) != 0;
+      if (finish) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int k = 0; k < 4; k++) z[4 * (half ^ 1) + k] = __hip_atomic_load(&zh[4 * (half ^ 1) + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (finish) {
     auto sum2 = [&](const double* c, double& m, int& e) {
       const int e0 = (int)c[1], e1 = (int)c[3];
       e = max(e0, e1);
@@ -375,6 +398,7 @@ __device__ __forceinline__ void ext_chains(const ExactParams& p, int b) {
     }
     __threadfence();
     atomicOr(&p.flags[b], ok ? kExtDone : (kExtDone | kExtBad));
+    }
   }
   __syncthreads();
 }

@@ -822,6 +822,9 @@ __device__ __forceinline__ void ctc_exact_one(const ExactParams& p, unsigned cha
 
 constexpr int kFlagCache = 2048;    // utterances whose flag words and segment counts a workgroup keeps in LDS
 constexpr int kRedoFailed = 512;    // flag bit set by the segment redo
+#ifndef E2E_EXT_NOSPLIT             // (tools/diag A/B: 1 = both directions of a flagged utterance always on one workgroup)
+#define E2E_EXT_NOSPLIT 0
+#endif
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
@@ -1100,7 +1103,10 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
       if (round >= 0) {
         build_list(round);
         const int nx = s_next;
-        for (int i = blockIdx.x; i < nx; i += gridDim.x) {
+        // (few utterances: alpha and beta of an utterance on two workgroups, item 2 i + side)
+        const bool split = 2 * nx <= (int)gridDim.x && !E2E_EXT_NOSPLIT;
+        for (int i2 = blockIdx.x; i2 < (split ? 2 * nx : nx); i2 += gridDim.x) {
+          const int i = split ? i2 >> 1 : i2;
           if (round == 1) {
             // (every workgroup has released what step 1 wrote before any chain of this round reports itself done -- and only then
             //  does a segment of the round write a row; the chains take > 100 us, the releases a few: nobody waits here in practice)
@@ -1116,7 +1122,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
             __syncthreads();                 // (everybody has read s_go before thread 0 writes it for the next utterance)
             if (!go_now) continue;
           }
-          ext_chains<IO>(p, s_xb[i]); owes_release = true;
+          ext_chains<IO>(p, s_xb[i], split ? (i2 & 1) : -1); owes_release = true;
         }
         stamp(3);
         if (nx > 0) ext_segments_of_list(nx);

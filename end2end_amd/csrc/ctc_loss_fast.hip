@@ -1931,7 +1931,7 @@ FastLayout fast_layout(int B, int T, int V, int Smax) {
   // the extended-range redo of the flagged-utterance launch (ctc_ext.h): one exponent per checkpoint cell, both directions
   l.ckXA = o; o += align_up((size_t)B * l.NS * l.CELLS * sizeof(int), 256);
   l.ckXQ = o; o += align_up((size_t)B * l.NS * l.CELLS * sizeof(int), 256);
-  l.extz = o; o += align_up((size_t)B * 2 * sizeof(double), 256);
+  l.extz = o; o += align_up((size_t)B * 10 * sizeof(double), 256);     // [B][2] Z, then [B][2 sides][4] the sides' cells of Z (ext_chains)
   l.total = o;
   return l;
 }
