@@ -128,7 +128,17 @@ __global__ __launch_bounds__(kThreads) void ctc_greedy_kernel(GreedyParams p) {
 // symbols of a super-tile and its compacted output live in LDS as bytes (V <= 64); the output is written coalesced.
 // LDS per workgroup stays below 40 KB so that four workgroups share a CU: B = 1024 utterances then run in one round.
 constexpr int kChunk = 64;           // frames per wave and chunk
-constexpr int kSuper = 1024;         // frames per super-tile
+#ifndef E2E_GREEDY_SUPER
+#define E2E_GREEDY_SUPER 2048
+#endif
+#ifndef E2E_GREEDY_DEPTH
+#define E2E_GREEDY_DEPTH 1
+#endif
+constexpr int kSuper = E2E_GREEDY_SUPER;   // frames per super-tile (round 6: 2048 -- BASELINE configs[2]'s 1500 frames are ONE super-tile, so a
+                                     // wave's stream of chunk loads is not cut in the middle by a collapse phase and a fresh round trip)
+constexpr int kDepth = E2E_GREEDY_DEPTH;   // chunks a wave has asked for beyond the one it works on.  (Round 6, one process, B=1024, T=1500, V=29: one
+                                     // chunk ahead 34.6 us, two 35.2, three 39.8; with the old super-tile of 1024 frames 35.6 -- the kernel moves its
+                                     // 190 MB at 5.4-5.5 TB/s, the box's streaming rate, and a deeper pipeline has nothing to hide.)
 constexpr int kStreamWaves = 4;
 constexpr int kMaxPf = 16;           // 16-byte loads per lane and chunk (V <= 64 floats, or V <= 32 doubles)
 
@@ -158,30 +168,32 @@ __global__ __launch_bounds__(64 * kStreamWaves) void ctc_greedy_stream_kernel(Gr
     // ---- phase 1: per-frame arg-max, one wave per chunk, the next chunk's loads in flight ----
     // (every load is a whole 16-byte piece at a clamped index: pieces past the chunk, or past the utterance's slab of
     // Tmax frames, re-read the slab's last piece -- frames past the utterance's end never reach sym[])
-    i4 pf[NPF];
+    // (kDepth register sets rotate through a loop unrolled kDepth times: a set is never copied, a copy would wait for its loads)
+    i4 pf[kDepth][NPF];
     const int slab_pieces = (int)(((int64_t)Tmax * V) / EPV);
     const i4* const xp = reinterpret_cast<const i4*>(x);
-    auto request = [&](int c) {
+    auto request = [&](int c, i4 (&dst)[NPF]) {
       const int p0 = (s0 + c * kChunk) * V / EPV;                 // (64 * V is a multiple of EPV)
 #pragma unroll
-      for (int u = 0; u < NPF; u++) pf[u] = __builtin_nontemporal_load(&xp[min(p0 + lane + 64 * u, slab_pieces - 1)]);
+      for (int u = 0; u < NPF; u++) dst[u] = __builtin_nontemporal_load(&xp[min(p0 + lane + 64 * u, slab_pieces - 1)]);
     };
-    if (wid < nchunks) request(wid);
-    for (int c = wid; c < nchunks; c += kStreamWaves) {
+#pragma unroll
+    for (int d = 0; d < kDepth; d++) if (wid + d * kStreamWaves < nchunks) request(wid + d * kStreamWaves, pf[d]);
+    auto work = [&](int c, i4 (&cur)[NPF]) {
       // park the chunk in the tile (row stride ldv: element i of the chunk lands at i + i / V when V is even)
 #pragma unroll
       for (int u = 0; u < NPF; u++) {
         const int e = (lane + 64 * u) * EPV;
         if (e < kChunk * V) {
-          if (ldv == V) *reinterpret_cast<i4*>(&tile[e]) = pf[u];
+          if (ldv == V) *reinterpret_cast<i4*>(&tile[e]) = cur[u];
           else {
-            const IO* q = reinterpret_cast<const IO*>(&pf[u]);
+            const IO* q = reinterpret_cast<const IO*>(&cur[u]);
 #pragma unroll
             for (int k = 0; k < EPV; k++) tile[e + k + (int)(((unsigned)(e + k) * vmagic) >> 20)] = q[k];
           }
         }
       }
-      if (c + kStreamWaves < nchunks) request(c + kStreamWaves);
+      if (c + kDepth * kStreamWaves < nchunks) request(c + kDepth * kStreamWaves, cur);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (wave-private tile: no barrier)
       const int t = c * kChunk + lane;                            // frame within the super-tile
       const IO* row = tile + lane * ldv;
@@ -203,6 +215,10 @@ __global__ __launch_bounds__(64 * kStreamWaves) void ctc_greedy_stream_kernel(Gr
       }
       if (t < sn) sym[t] = (unsigned char)bi;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the tile is rewritten by the next chunk
+    };
+    for (int c = wid; c < nchunks; c += kDepth * kStreamWaves) {
+#pragma unroll
+      for (int d = 0; d < kDepth; d++) if (c + d * kStreamWaves < nchunks) work(c + d * kStreamWaves, pf[d]);
     }
     __syncthreads();
     // ---- phase 2: collapse (emit iff sym != blank && sym != previous frame's sym, ctc_decoder.cpp:475-481) ----
@@ -254,16 +270,20 @@ int launch_greedy(const void* x, int dtype, int64_t sB, int64_t sT, int64_t sV, 
     if (sV == 1 && sT == V && aligned && V >= 1 && (size_t)V * esz <= 16 * kMaxPf && lds_stream <= 60 * 1024) {
       const int npf = (int)((64 * (size_t)V * esz + 1023) / 1024);
       if (dtype == E2E_F32) {
-        if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<float, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        if (npf <= 4) hipLaunchKernelGGL((ctc_greedy_stream_kernel<float, 4>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        else if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<float, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
         else hipLaunchKernelGGL((ctc_greedy_stream_kernel<float, 16>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
       } else if (dtype == E2E_F16) {          // (16-bit logits: compared as they are -- the ordering of the source dtype, as torch.argmax sees it)
-        if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<f16_t, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        if (npf <= 4) hipLaunchKernelGGL((ctc_greedy_stream_kernel<f16_t, 4>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        else if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<f16_t, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
         else hipLaunchKernelGGL((ctc_greedy_stream_kernel<f16_t, 16>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
       } else if (dtype == E2E_BF16) {
-        if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<bf16_t, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        if (npf <= 4) hipLaunchKernelGGL((ctc_greedy_stream_kernel<bf16_t, 4>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        else if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<bf16_t, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
         else hipLaunchKernelGGL((ctc_greedy_stream_kernel<bf16_t, 16>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
       } else {
-        if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<double, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        if (npf <= 4) hipLaunchKernelGGL((ctc_greedy_stream_kernel<double, 4>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
+        else if (npf <= 8) hipLaunchKernelGGL((ctc_greedy_stream_kernel<double, 8>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
         else hipLaunchKernelGGL((ctc_greedy_stream_kernel<double, 16>), dim3(B), dim3(64 * kStreamWaves), lds_stream, stream, p);
       }
       E2E_HIP_CHECK(hipGetLastError(), "ctc_greedy_stream_kernel launch");

@@ -195,3 +195,19 @@ def test_range_flags_beside_an_utterance_flagged_for_its_inputs(scale, seed):
     assert abs(red - l_o.sum()) <= 1e-5 * abs(l_o.sum())
     assert unsettled(keep, B, T, V, S) == 0
     assert (keep["failed_redos"] > 0) == (scale == 4.0)
+
+
+def test_more_flagged_utterances_than_spare_workgroups_keep_both_directions_together():
+    """With at most 128 utterances for the extended-range redo, the alpha and the beta chains of an utterance run on two workgroups
+    of the flagged launch (round 6); beyond, on one, as before.  160 short utterances of sharp unrelated emissions take the second
+    route (every other test of this file, and the fuzz slices, take the first)."""
+    rng = np.random.default_rng(160)
+    B, T, V, S = 160, 96, 29, 24
+    x = (rng.standard_normal((B, T, V)) * 8.0).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, S))
+    tl = rng.integers(S // 2, S + 1, size=B)
+    xl = rng.integers(T // 2 + S, T + 1, size=B)
+    xl[0] = T
+    lf, _ = U.c_abi_loss(torch.from_numpy(x), tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    assert np.isnan(lf).sum() > 128, "only %d utterances left the f32 lattice: the test needs more than 128" % np.isnan(lf).sum()
+    check(x, tg, xl, tl, want_unsettled=None)
