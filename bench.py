@@ -307,7 +307,7 @@ def decode_numbers(dev, with_cpu):
         if phases and lm_key in phases:
             leg["serial_bound"]["cycles_per_step"] = phases[lm_key].get("cycles_per_step")
             leg["serial_bound"]["phase_cycles"] = phases[lm_key].get("phase_cycles")
-            leg["serial_bound"]["source"] = "profiles/r05_beam_phases.json (tools/diag/beam_phase_profile.py, s_memtime stamps of workgroup 0)"
+            leg["serial_bound"]["source"] = "profiles/r06_beam_phases.json (tools/diag/beam_phase_profile.py, s_memtime stamps of workgroup 0)"
         return leg
 
     eng = CTCDecoder(beam_width=100, blank_idx=0, after_logsoftmax=True, labels=labels, wip=1.0)._decoder
@@ -487,7 +487,7 @@ def shape_cliff_numbers(dev):
 def recorded_beam_phases():
     """Per-phase s_memtime cycles of the fast beam kernel from the committed record (tools/diag/beam_phase_profile.py), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_beam_phases.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_beam_phases.json")) as f:
             return json.load(f)
     except Exception:
         return None
@@ -495,7 +495,7 @@ def recorded_beam_phases():
 
 def recorded_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
