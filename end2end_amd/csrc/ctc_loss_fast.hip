@@ -274,6 +274,8 @@ __global__ E2E_KERNEL_ALIGN __launch_bounds__(512) void ctc_fast_chain_kernel(Fa
     lds.ring[(size_t)(i / kBlk) * lds.blk_elems + V * kRow + (i % kBlk)] = 0.0;
   __syncthreads();
 
+  // (RB == 4, two workgroups per CU: giving the launch's second half its roles two waves on -- its chains on SIMDs 1 and 3 instead
+  //  of 0 and 2 again -- was measured in round 6 and is not faster, 70.2 against 68.8 us per call for configs[4]'s compact lattice)
   const int wave = __builtin_amdgcn_readfirstlane(wid);
   if (wave == 0) chain_wave<PPL, 0, RB>(p, b, T, S, lds, lane);
   else if (wave == 1) chain_wave<PPL, 1, RB>(p, b, T, S, lds, lane);

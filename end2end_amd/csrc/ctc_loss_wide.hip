@@ -456,7 +456,17 @@ __global__ __launch_bounds__(64 * kWaves) void wide_fix_kernel(WideParams p) {
   const int64_t Tq = p.x_len[b], Sq = p.t_len[b];
   if (Tq < 1 || Tq > p.T || Sq < 0 || Sq > p.Smax) return;         // (poisoned by wide_rows_dense_kernel already)
   E* gr = reinterpret_cast<E*>(p.grads) + (size_t)row * p.V;
-  if (!(p.losses[b] < __builtin_huge_valf())) {                      // infeasible (Q2) / NaN: the whole slab
+  const float loss_b = p.losses[b];
+  if (t == 0) {
+    // the utterance's first frame also corrects its loss (wide_loss_fix_kernel's job, folded in here in round 6: a launch of its own
+    // was 5 us behind the lattice): loss_true = loss_shifted - sum_t shift_t.  The other frames of the utterance read the loss only to
+    // tell a number from +inf / NaN, which the correction does not change.
+    double sacc = 0.0;
+    for (int u = lane; u < (int)Tq; u += 64) sacc += (double)p.shift[(size_t)b * p.T + u];
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+    if (lane == 0) p.losses[b] = (float)((double)loss_b - sacc);
+  }
+  if (!(loss_b < __builtin_huge_valf())) {                           // infeasible (Q2) / NaN: the whole slab
     constexpr int EPC = 16 / (int)sizeof(E);
     typedef E ev __attribute__((ext_vector_type(EPC)));
     ev o;
@@ -631,8 +641,10 @@ int launch_wide(const LossArgs& a, bool fallback_to_exact) {
       const int rc = launch_fast(c, fallback_to_exact);
       if (rc != E2E_OK) return rc;
     }
-    hipLaunchKernelGGL(wide_loss_fix_kernel, dim3(nb), dim3(64), 0, s_lat, q);
-    E2E_HIP_CHECK(hipGetLastError(), "wide_loss_fix_kernel launch");
+    if (!dense) {                      // (the dense path's fix-up corrects the losses itself)
+      hipLaunchKernelGGL(wide_loss_fix_kernel, dim3(nb), dim3(64), 0, s_lat, q);
+      E2E_HIP_CHECK(hipGetLastError(), "wide_loss_fix_kernel launch");
+    }
     if (dense) {
       if (a.dtype == E2E_F16) hipLaunchKernelGGL(wide_fix_kernel<f16_t>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
       else if (a.dtype == E2E_BF16) hipLaunchKernelGGL(wide_fix_kernel<bf16_t>, grid_rows, dim3(64 * kWaves), 0, s_lat, q);
