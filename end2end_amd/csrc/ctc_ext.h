@@ -406,42 +406,96 @@ __device__ __forceinline__ void ext_chains(const ExactParams& p, int b, int half
 // ---- the segments ----------------------------------------------------------------------------------------------------
 // One (utterance, 16-step segment) on this workgroup: wave c takes the label pairs 32 c .. 32 c + 31 (its lanes hold the
 // pairs 32 c - 16 .. 32 c + 47: what the 16 steps can reach from either side), c = wid, wid + 8, ...
+//
+// Round 6.  What an item cost was not its lattice -- with the chunk loop compiled out the call took as long as with only its LDS
+// atomics removed (sharp_unrelated: 1 325 against 1 504 us; tools/diag: -DE2E_EXT_ABL=128 / 64) -- but the dependent round trips to
+// memory around it, on a CU that holds nothing else to run meanwhile: the wait for the utterance's flag and the acquire fence
+// behind it, Z, the targets, the probability rows behind the targets, the checkpoints, the probabilities again for the gradient
+// rows; ~15 us of a 17 us item.  So a workgroup now takes a CONTIGUOUS run of the list's items -- mostly segments of ONE utterance
+// -- and keeps what belongs to the utterance (XSegUtt: lengths, Z, its waves' labels and skip flags) across them; an item asks
+// for everything it reads from memory at its top, in one round trip; the posterior rows are cleared by the pass that reads them.
+struct XSegChunk { int g, lab; bool own, lvalid; double skp, skn; };
+struct XSegUtt {
+  int b, T, S; double Zinv; int Ze;
+  XSegChunk ch[2];                    // the wave's chunks c = wid, wid + 8 (targets of up to 447 labels: 14 chunks)
+};
 template <typename IO>
-__device__ __forceinline__ void ext_segment(const ExactParams& p, int b, int seg) {
+__device__ __forceinline__ void ext_segment_setup(const ExactParams& p, int b, XSegUtt& u) {
+  const FastRetry& rt = p.retry;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int V = p.V, blank = p.blank;
+  u.b = b; u.T = (int)p.x_len[b]; u.S = (int)p.t_len[b];
+  u.Zinv = 1.0 / rt.extz[2 * b]; u.Ze = (int)rt.extz[2 * b + 1];
+  const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
+  const int S = u.S;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int c = wid + 8 * k;
+    XSegChunk& q = u.ch[k];
+    q.g = 32 * c - 16 + lane;
+    q.own = lane >= 16 && lane < 48 && q.g <= S;
+    q.lvalid = q.g >= 0 && q.g < S;
+    const int lv = q.lvalid ? (int)tg[q.g] : 0;
+    q.lab = min(max(lv, 0), V - 1);
+    const int lpv = q.g >= 1 && q.g < S ? (int)tg[q.g - 1] : -1, lnv = q.g >= 0 && q.g + 1 < S ? (int)tg[q.g + 1] : -1;
+    q.skp = (q.lvalid && q.g >= 1 && lv != blank && lpv != lv) ? 1.0 : 0.0;           // ctc_loss.cpp:53-57
+    q.skn = (q.lvalid && q.g + 1 < S && lv != blank && lnv != lv) ? 1.0 : 0.0;         // ctc_loss.cpp:91-96
+  }
+}
+
+// `post` ([16][V + 1] doubles in LDS) is all zero on entry and on exit; the caller puts a barrier between two items.
+template <typename IO>
+__device__ __forceinline__ void ext_segment(const ExactParams& p, const XSegUtt& u, int seg) {
   extern __shared__ __align__(16) unsigned char smem[];
   const FastRetry& rt = p.retry;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int V = p.V, blank = p.blank, Tmax = p.T;
-  const int T = (int)p.x_len[b], S = (int)p.t_len[b], L = 2 * S + 1;
+  const int b = u.b, T = u.T, S = u.S, L = 2 * S + 1;
   const int t0 = seg * kFastSeg, n = min(kFastSeg, T - t0);
   const bool cond = (T > 1 || L == 1);
   double* post = reinterpret_cast<double*>(smem);                   // [16][V + 1]
-  for (int i = tid; i < 16 * (V + 1); i += kThreads) post[i] = 0.0;
-  __syncthreads();
-  const double Zinv = 1.0 / rt.extz[2 * b];
-  const int Ze = (int)rt.extz[2 * b + 1];
-  const int64_t* tg = p.targets + (int64_t)b * p.tgt_stride;
+  const double Zinv = u.Zinv;
+  const int Ze = u.Ze;
+  // the probabilities of the gradient rows this thread will write (alphabets of up to 64 columns: two per thread), asked for now
+  constexpr int kEarly = 2;
+  const bool early = n * V <= kEarly * kThreads;
+  float yv[kEarly];
+  auto y_at = [&](int i) -> float {
+    const int tt = i / V, v = i - tt * V;
+    return rt.ytab_segments ? rt.ytab[(((size_t)b * rt.NS + seg) * V + v) * kFastSeg + tt] : rt.ytab[((size_t)b * Tmax + t0 + tt) * V + v];
+  };
+#pragma unroll
+  for (int k = 0; k < kEarly; k++) yv[k] = (early && tid + k * kThreads < n * V) ? y_at(tid + k * kThreads) : 0.f;
   const int nchunk = (S + 32) / 32;                                 // pairs 0 .. S
-  for (int c = wid; c < nchunk; c += kThreads / 64) {
-    const int g = 32 * c - 16 + lane;
-    const bool own = lane >= 16 && lane < 48 && g <= S;
-    const bool lvalid = g >= 0 && g < S;
-    const int lv = lvalid ? (int)tg[g] : 0;
-    const int lab = min(max(lv, 0), V - 1);
-    const int lpv = g >= 1 && g < S ? (int)tg[g - 1] : -1, lnv = g >= 0 && g + 1 < S ? (int)tg[g + 1] : -1;
-    const double skp = (lvalid && g >= 1 && lv != blank && lpv != lv) ? 1.0 : 0.0;           // ctc_loss.cpp:53-57
-    const double skn = (lvalid && g + 1 < S && lv != blank && lnv != lv) ? 1.0 : 0.0;         // ctc_loss.cpp:91-96
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int c = wid + 8 * k;
+    if (c >= ((E2E_EXT_ABL & 128) ? 0 : nchunk)) continue;
+    const XSegChunk& q = u.ch[k];
+    const int g = q.g, lab = q.lab;
+    const bool own = q.own, lvalid = q.lvalid;
+    const double skp = q.skp, skn = q.skn;
     float yb[16], yl[16];
     x_load_rows(rt, b, seg, Tmax, V, blank, yb);
     x_load_rows(rt, b, seg, Tmax, V, lab, yl);
+    // both checkpoint rows, asked for before either is used
+    double Bm = 0.0, Lm = 0.0; int Be = kXZero, Le = kXZero;
+    double qBm = 0.0, qLm = 0.0; int qBe = kXZero, qLe = kXZero;
+    {
+      const bool in = g >= 0 && g <= S;
+      const bool hasA = seg > 0 && in, hasQ = t0 + n < T && in;
+      const size_t ca = ((size_t)b * rt.NS + seg) * rt.CELLS + 2 * (in ? g : 0), cq = ca + rt.CELLS;
+      float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f; int ea0 = kXZero, ea1 = kXZero, eq0 = kXZero, eq1 = kXZero;
+      if (hasA) { a0 = rt.ckA[ca]; a1 = rt.ckA[ca + 1]; ea0 = rt.ckXA[ca]; ea1 = rt.ckXA[ca + 1]; }
+      if (hasQ) { q0 = rt.ckQ[cq]; q1 = rt.ckQ[cq + 1]; eq0 = rt.ckXQ[cq]; eq1 = rt.ckXQ[cq + 1]; }
+      if (hasA) { Bm = (double)a0; Lm = (double)a1; Be = x_fix(Bm, ea0); Le = x_fix(Lm, ea1); }
+      if (hasQ) {
+        qBm = (double)q0; qLm = (double)q1; qBe = x_fix(qBm, eq0); qLe = x_fix(qLm, eq1);
+        if (g == S) { qLm = 0.0; qLe = kXZero; }                    // (label S does not exist; its checkpoint cell is never written)
+      }
+    }
     // ---- alpha rows t0 .. t0 + n - 1 ----
     double aBm[16], aLm[16]; int aBe[16], aLe[16];
-    double Bm = 0.0, Lm = 0.0; int Be = kXZero, Le = kXZero;
-    if (seg > 0 && g >= 0 && g <= S) {
-      const size_t cb = ((size_t)b * rt.NS + seg) * rt.CELLS + 2 * g;
-      Bm = (double)rt.ckA[cb]; Be = rt.ckXA[cb]; Lm = (double)rt.ckA[cb + 1]; Le = rt.ckXA[cb + 1];
-      Be = x_fix(Bm, Be); Le = x_fix(Lm, Le);
-    }
 #pragma unroll
     for (int tt = 0; tt < 16; tt++) {
       if (tt < n) {
@@ -458,13 +512,6 @@ __device__ __forceinline__ void ext_segment(const ExactParams& p, int b, int seg
       aBm[tt] = Bm; aBe[tt] = Be; aLm[tt] = Lm; aLe[tt] = Le;
     }
     // ---- beta back through the segment (q = beta with its emission; unshifted pairing: slot (blank g, label g)) ----
-    double qBm = 0.0, qLm = 0.0; int qBe = kXZero, qLe = kXZero;
-    if (t0 + n < T && g >= 0 && g <= S) {
-      const size_t cb = ((size_t)b * rt.NS + seg + 1) * rt.CELLS + 2 * g;
-      qBm = (double)rt.ckQ[cb]; qBe = rt.ckXQ[cb]; qLm = (double)rt.ckQ[cb + 1]; qLe = rt.ckXQ[cb + 1];
-      qBe = x_fix(qBm, qBe); qLe = x_fix(qLm, qLe);
-      if (g == S) { qLm = 0.0; qLe = kXZero; }                      // (label S does not exist; its checkpoint cell is never written)
-    }
 #pragma unroll
     for (int tt = 15; tt >= 0; tt--) {
       if (tt >= n) continue;
@@ -487,9 +534,11 @@ __device__ __forceinline__ void ext_segment(const ExactParams& p, int b, int seg
       const double pB = ldexp(aBm[tt] * bBm * Zinv, aBe[tt] + bBe - Ze);
       const double pL = ldexp(aLm[tt] * bLm * Zinv, aLe[tt] + bLe - Ze);
       double pb = own ? pB : 0.0;
-      pb = wave_sum_lane63(pb);
-      if (lane == 63 && pb != 0.0) atomicAdd(&post[tt * (V + 1) + blank], pb);
-      if (own && lvalid && pL != 0.0) atomicAdd(&post[tt * (V + 1) + lab], pL);
+      if (!(E2E_EXT_ABL & 32)) pb = wave_sum_lane63(pb);
+      if (!(E2E_EXT_ABL & 64)) {
+        if (lane == 63 && pb != 0.0) atomicAdd(&post[tt * (V + 1) + blank], pb);
+        if (own && lvalid && pL != 0.0) atomicAdd(&post[tt * (V + 1) + lab], pL);
+      }
       // q of row t
       const double ybt = (double)yb[tt], ylt = lvalid ? (double)yl[tt] : 0.0;
       qBm = bBm * ybt; qBe = ybt != 0.0 ? bBe : kXZero;
@@ -498,13 +547,25 @@ __device__ __forceinline__ void ext_segment(const ExactParams& p, int b, int seg
     }
   }
   __syncthreads();
-  // ---- the rows: y - posterior (ctc_loss.cpp:102-117) ----
+  // ---- the rows: y - posterior (ctc_loss.cpp:102-117); what is read of `post` is cleared for the next item ----
   IO* grads = reinterpret_cast<IO*>(p.grads) + (size_t)b * (size_t)Tmax * (size_t)V;
-  for (int i = tid; i < n * V; i += kThreads) {
-    const int tt = i / V, v = i - tt * V;
-    const float y = rt.ytab_segments ? rt.ytab[(((size_t)b * rt.NS + seg) * V + v) * kFastSeg + tt]
-                                     : rt.ytab[((size_t)b * Tmax + t0 + tt) * V + v];
-    grads[(size_t)(t0 + tt) * V + v] = (IO)(((double)y - post[tt * (V + 1) + v]) * p.gscale);
+  if (early) {
+#pragma unroll
+    for (int k = 0; k < kEarly; k++) {
+      const int i = tid + k * kThreads;
+      if (i < n * V) {
+        const int tt = i / V, v = i - tt * V;
+        const double po = post[tt * (V + 1) + v];
+        post[tt * (V + 1) + v] = 0.0;
+        grads[(size_t)(t0 + tt) * V + v] = (IO)(((double)yv[k] - po) * p.gscale);
+      }
+    }
+  } else {
+    for (int i = tid; i < n * V; i += kThreads) {
+      const int tt = i / V, v = i - tt * V;
+      const double po = post[tt * (V + 1) + v];
+      post[tt * (V + 1) + v] = 0.0;
+      grads[(size_t)(t0 + tt) * V + v] = (IO)(((double)y_at(i) - po) * p.gscale);
+    }
   }
-  __syncthreads();
 }

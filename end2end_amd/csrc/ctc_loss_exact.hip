@@ -958,27 +958,46 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
       __syncthreads();
     };
     auto ext_segments_of_list = [&](int nx) {
-      // item j of the running list on workgroup j mod grid, once its utterance's chains are done
+      // A contiguous run of the list's items per workgroup (item j = segment j - s_xoff[i] of the list's i-th utterance): mostly
+      // segments of ONE utterance, whose flag is waited for, whose Z / lengths / labels are fetched and behind whose flag the
+      // acquire fence is paid once per run instead of once per item (ext_segment's header says what an item cost).
       const int nitems = s_xoff[nx];
-      for (int j = blockIdx.x; j < nitems; j += gridDim.x) {
-        int lo = 0, hi = nx - 1;                                    // the utterance of item j: last i with s_xoff[i] <= j
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_xoff[mid] <= j) lo = mid; else hi = mid - 1; }
+      const int G = (int)gridDim.x;
+      const int j0 = (int)((long long)blockIdx.x * nitems / G), j1 = (int)((long long)(blockIdx.x + 1) * nitems / G);
+      if (j0 >= j1) return;
+      {
+        double* post = reinterpret_cast<double*>(smem);              // ext_segment's rows: all zero between items
+        for (int i = tid; i < 16 * (p.V + 1); i += kThreads) post[i] = 0.0;
+      }
+      int lo = 0, hi = nx - 1;                                      // the utterance of item j0: last i with s_xoff[i] <= j0
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_xoff[mid] <= j0) lo = mid; else hi = mid - 1; }
+      XSegUtt utt; utt.b = -1;
+      bool go = false;
+      for (int j = j0; j < j1; j++) {
+        while (lo + 1 < nx && s_xoff[lo + 1] <= j) lo++;
         const int ub = s_xb[lo], seg = j - s_xoff[lo];
-        if (tid == 0) {
-          int f, spins = 0;
-          while (((f = __hip_atomic_load(&p.flags[ub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kExtDone) == 0 && ++spins < (1 << 16))
-            __builtin_amdgcn_s_sleep(8);
-          if ((f & kExtDone) == 0) { atomicOr(&p.flags[ub], kExtBad); atomicAdd(&p.ctl[4], 1); f |= kExtBad; }
-          s_go = (f & kExtBad) == 0;
+        if (ub != utt.b) {
+          if (tid == 0) {
+            int f, spins = 0;
+            while (((f = __hip_atomic_load(&p.flags[ub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kExtDone) == 0 && ++spins < (1 << 16))
+              __builtin_amdgcn_s_sleep(8);
+            if ((f & kExtDone) == 0) { atomicOr(&p.flags[ub], kExtBad); atomicAdd(&p.ctl[4], 1); f |= kExtBad; }
+            s_go = (f & kExtBad) == 0;
+          }
+          __syncthreads();
+          go = s_go != 0;
+          if (go) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            ext_segment_setup<IO>(p, ub, utt);
+          } else utt.b = ub;
         }
-        __syncthreads();
-        if (s_go) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          ext_segment<IO>(p, ub, seg);
+        __syncthreads();                 // (s_go has been read by everybody; the rows of the item before are cleared)
+        if (go) {
+          ext_segment<IO>(p, utt, seg);
           owes_release = true;          // (kExtBad can still be set by a waiter whose patience ran out: step 3 then rewrites these rows)
         }
-        __syncthreads();
       }
+      __syncthreads();
     };
     if (E2E_EXT_ON && p.has_ext) {
       bool mine = false;
