@@ -10,6 +10,8 @@ def bind(path):
     L.e2e_ctc_loss_workspace_bytes.restype = C.c_size_t; L.e2e_ctc_loss_workspace_bytes.argtypes = [C.c_int] * 6
     L.e2e_ctc_loss_fwd_bwd.restype = C.c_int
     L.e2e_ctc_loss_fwd_bwd.argtypes = _lib.load().e2e_ctc_loss_fwd_bwd.argtypes
+    L.e2e_ctc_loss_fwd_bwd_opt.restype = C.c_int
+    L.e2e_ctc_loss_fwd_bwd_opt.argtypes = _lib.load().e2e_ctc_loss_fwd_bwd_opt.argtypes
     return L
 libs = {os.path.basename(p): bind(os.path.join(root, p)) for p in sys.argv[1:]}
 d = torch.device("cuda", 0)
@@ -20,10 +22,18 @@ x = (torch.randn(B, T, V, generator=gen) * float(os.environ.get("AB_SCALE", "1")
 tl = torch.randint(S // 2, S + 1, (B,), generator=gen).to(d); xl = torch.full((B,), T).to(d)
 losses = torch.empty(B, device=d); grads = torch.empty(B, T, V, device=d, dtype=DT)
 n = max(L.e2e_ctc_loss_workspace_bytes(B, T, V, S, CODE, ALGO) for L in libs.values()); ws = torch.zeros(n, dtype=torch.uint8, device=d)
-def call(L):
+MEAN = os.environ.get("AB_MEAN") == "1"          # the call bench.py times: e2e_ctc_loss_fwd_bwd_opt with the batch mean written by the call's tail
+mean_out = torch.zeros(1, device=d, dtype=torch.float32)
+def call_mean(L):
+    o = _lib.LossOpts(1.0 / B, mean_out.data_ptr(), _lib.REDUCE_MEAN, 0)
+    rc = L.e2e_ctc_loss_fwd_bwd_opt(x.data_ptr(), CODE, 0, *x.stride(), tg.data_ptr(), tg.stride(0), xl.data_ptr(), tl.data_ptr(),
+                                    B, T, V, S, 0, losses.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(), ALGO, None, C.byref(o))
+    assert rc == 0
+def call_plain(L):
     rc = L.e2e_ctc_loss_fwd_bwd(x.data_ptr(), CODE, 0, *x.stride(), tg.data_ptr(), tg.stride(0), xl.data_ptr(), tl.data_ptr(),
                                 B, T, V, S, 0, losses.data_ptr(), grads.data_ptr(), ws.data_ptr(), ws.numel(), ALGO, None)
     assert rc == 0
+call = call_mean if MEAN else call_plain
 res = {k: [] for k in libs}
 for rnd in range(12):
     for k, L in libs.items():
