@@ -981,8 +981,19 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
             int f, spins = 0;
             while (((f = __hip_atomic_load(&p.flags[ub], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & kExtDone) == 0 && ++spins < (1 << 16))
               __builtin_amdgcn_s_sleep(8);
-            if ((f & kExtDone) == 0) { atomicOr(&p.flags[ub], kExtBad); atomicAdd(&p.ctl[4], 1); f |= kExtBad; }
-            s_go = (f & kExtBad) == 0;
+            if ((f & kExtDone) == 0) {
+              // patience ran out: the utterance is left to step 3 -- but only if its chains have STILL not reported.  kExtBad goes in
+              // by compare-and-swap against a word without kExtDone, so that it can never follow kExtDone: rows that a segment wrote
+              // behind a clean kExtDone are then final, nobody rewrites them, and they need no release (with every
+              // workgroup releasing behind its segments the launch's end was 256 L2 write-backs at once, ~25 us of label_noise)
+              for (;;) {
+                if (f & kExtDone) break;                            // (they made it after all)
+                const int old = atomicCAS(&p.flags[ub], f, f | kExtBad);
+                if (old == f) { f |= kExtBad; atomicAdd(&p.ctl[4], 1); break; }
+                f = old;
+              }
+            }
+            s_go = (f & kExtDone) != 0 && (f & kExtBad) == 0;
           }
           __syncthreads();
           go = s_go != 0;
@@ -992,10 +1003,7 @@ __global__ __launch_bounds__(kThreads) void ctc_exact_kernel(ExactParams p_in) {
           } else utt.b = ub;
         }
         __syncthreads();                 // (s_go has been read by everybody; the rows of the item before are cleared)
-        if (go) {
-          ext_segment<IO>(p, utt, seg);
-          owes_release = true;          // (kExtBad can still be set by a waiter whose patience ran out: step 3 then rewrites these rows)
-        }
+        if (go) ext_segment<IO>(p, utt, seg);       // (rows behind a clean kExtDone are final: see the wait above)
       }
       __syncthreads();
     };
