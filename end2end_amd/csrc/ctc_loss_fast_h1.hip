@@ -485,6 +485,10 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
       for (int k = 1; k < NV; k++) m = fmaxf(m, xv[k]);
       m = row8_max(m);
       float ssum = 0.f;
+#ifndef E2E_H1_FAST_EXP          // exp(x - m) as 2^(x log2(e) - m log2(e)): ONE rounding of the exponent (the fused multiply-add's; the
+#define E2E_H1_FAST_EXP 1        // rounding of m log2(e) is common to the row and cancels in the normalisation) and v_exp_f32 -- where exp_le0
+#endif                           // rounds x - m and then takes eight instructions for an exponential exact to an ulp of THAT.  Same error
+      const float mM = -m * 1.44269504088896340736f;               // bound (half an ulp of an exponent of up to 115), six instructions less per element
 #pragma unroll
       for (int k = 0; k < NV; k++) {
         const float d = xv[k] - m;
@@ -492,6 +496,8 @@ __device__ __forceinline__ void hx_prep_wave(const FastParams& p, int b, int T, 
         const float bb = d - xv[k], err = (xv[k] - (d - bb)) + (-m - bb);    // the subtraction's rounding error (see ctc_fast_prob_kernel)
         const float e0 = exp_le0(d);
         y[k] = xv[k] > ninf ? fmaf(e0, err, e0) : 0.f; ssum += y[k];
+#elif E2E_H1_FAST_EXP
+        y[k] = __builtin_amdgcn_exp2f(fmaf(xv[k], 1.44269504088896340736f, mM)); ssum += y[k];      // (2^-inf = 0: dead columns and rows)
 #else
         y[k] = exp_le0(d); ssum += y[k];
 #endif
