@@ -89,7 +89,9 @@ int launch_scale(void* grads, int dtype, const void* scale, int B, int64_t row_e
   if (B == 0 || row_elems == 0) return E2E_OK;
   // enough blocks to fill the chip whatever the split into rows is (B = 1: one scalar for the whole tensor)
   int64_t want = (row_elems + 1023) / 1024;
-  const int64_t cap = B >= 64 ? 64 : 4096 / B;
+  // (B = 1 -- the scalar grad_output of a reduced loss, which is 1 whenever the caller wrote loss.backward() -- : the launch usually ends
+  //  in every workgroup's first test, and 1024 of them end sooner than 4096; a real pass over 30 MB loses nothing with 256 K threads)
+  const int64_t cap = B >= 64 ? 64 : B == 1 ? 1024 : 4096 / B;
   if (want > cap) want = cap;
   const int gx = (int)(want < 1 ? 1 : want);
   if (dtype == E2E_F32)
