@@ -382,3 +382,26 @@ def test_flagged_batch_is_right_while_another_stream_holds_the_cus(lds):
         th.join()
     torch.cuda.synchronize()
     print("flagged launch under contention: (waits that ran out, failed redos) per repetition:", outcomes)
+
+
+@pytest.mark.parametrize("shape", [(300, 70, 66, 24), (520, 40, 90, 12)], ids=lambda s: "B%d_T%d_V%d_S%d" % s)
+def test_batches_beyond_the_cu_count_take_the_shallow_probability_ring(shape):
+    """More utterances than the chip has CUs on an alphabet whose f64 probability ring of eight blocks keeps a second workgroup off
+    the CU (61..96 columns): the single-wave chain kernel then runs with a ring of four (round 6; BASELINE configs[4]'s compact
+    lattice is the case that matters).  Ragged lengths, repeats, against the oracle."""
+    B, T, V, S = shape
+    rng = np.random.default_rng(B)
+    x = rng.standard_normal((B, T, V)).astype(np.float32)
+    tg = rng.integers(1, V, size=(B, S))
+    tg[:, 1::3] = tg[:, 0::3][:, :tg[:, 1::3].shape[1]]
+    tl = rng.integers(1, S + 1, size=B); tl[0] = S
+    xl = rng.integers(2 * S + 2, T + 1, size=B); xl[0] = T
+    lp = torch.log_softmax(torch.from_numpy(x).double(), -1).numpy()
+    l_o, g_o = O.ctc_loss(lp, tg, xl, tl, 0)
+    for b in range(B):
+        g_o[b, xl[b]:] = 0.0
+    la, ga = U.c_abi_loss(torch.from_numpy(x), tg, xl, tl, 0, False, _lib.ALGO_AUTO)
+    U.assert_same(la, l_o, 1e-4, 2e-5, "losses")
+    U.assert_same(ga, g_o, 1e-4, 2e-6, "grads")
+    lf, _ = U.c_abi_loss(torch.from_numpy(x), tg, xl, tl, 0, False, _lib.ALGO_FAST)
+    assert not np.isnan(lf).any(), "the fast path gave up on %s" % np.nonzero(np.isnan(lf))[0].tolist()
