@@ -21,7 +21,11 @@
 namespace e2e {
 namespace {
 
-constexpr int kWaves = 4;      // frames per workgroup
+#ifndef E2E_WIDE_KWAVES
+#define E2E_WIDE_KWAVES 4
+#endif
+constexpr int kWaves = E2E_WIDE_KWAVES;      // frames per workgroup (round 6, one process, B=512 T=256 V=8000: 1 / 2 / 4 / 8 frames -> f32 1825 / 1761 / 1715 / 1726 us,
+                                             //  bf16 982 / 956 / 946 / 1049 us per call)
 
 struct WideParams {
   const float* x; int64_t sB, sT, sV; int logprobs;   // (16-bit logits: the dense kernels' instances reinterpret x / grads)
