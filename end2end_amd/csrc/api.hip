@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(copy_f4* __restrict__ 
     for (int i = lane; i < kCopyPiece; i += 8 * 64) {
       copy_f4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(&s[i + 64 * u]);
+#ifndef E2E_COPY_NT_LOADS
+#define E2E_COPY_NT_LOADS 1
+#endif
+      for (int u = 0; u < 8; u++) v[u] = E2E_COPY_NT_LOADS ? __builtin_nontemporal_load(&s[i + 64 * u]) : s[i + 64 * u];
 #pragma unroll
       for (int u = 0; u < 8; u++) __builtin_nontemporal_store(v[u], &d[i + 64 * u]);
     }

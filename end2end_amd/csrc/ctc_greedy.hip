@@ -175,7 +175,11 @@ __global__ __launch_bounds__(64 * kStreamWaves) void ctc_greedy_stream_kernel(Gr
     auto request = [&](int c, i4 (&dst)[NPF]) {
       const int p0 = (s0 + c * kChunk) * V / EPV;                 // (64 * V is a multiple of EPV)
 #pragma unroll
-      for (int u = 0; u < NPF; u++) dst[u] = __builtin_nontemporal_load(&xp[min(p0 + lane + 64 * u, slab_pieces - 1)]);
+#ifndef E2E_GREEDY_NT_LOADS         // (round 6, one process, configs[2]: plain loads 32.5 us, non-temporal ones 33.2)
+#define E2E_GREEDY_NT_LOADS 0
+#endif
+      for (int u = 0; u < NPF; u++) dst[u] = E2E_GREEDY_NT_LOADS ? __builtin_nontemporal_load(&xp[min(p0 + lane + 64 * u, slab_pieces - 1)])
+                                                                 : xp[min(p0 + lane + 64 * u, slab_pieces - 1)];
     };
 #pragma unroll
     for (int d = 0; d < kDepth; d++) if (wid + d * kStreamWaves < nchunks) request(wid + d * kStreamWaves, pf[d]);

@@ -315,6 +315,23 @@ typedef float vf4 __attribute__((ext_vector_type(4)));
 // E: the logits' (and the gradient's) element type -- float, or f16_t / bf16_t read and written 16 bytes (8 elements) at a
 // time and converted in registers: 2*V*sizeof(E) bytes per frame.  NV4: float4-equivalents of registers per lane, rows of
 // up to 256*NV4 columns either way.
+// Cache policy of the dense row kernels (bit 0: non-temporal loads, bit 1: non-temporal stores).  Round 6, one process, B=512, T=256,
+// V=8000 (tools/diag/ab_time.py): both non-temporal -- the form until then -- f32 1743 / bf16 990 us per call; neither 1859 / 1037;
+// loads only 2007 / 1162; **stores only 1663 / 912**.  The row is read once, but not only once: the wave's tail gathers the
+// utterance's <= S+1 label columns out of it, and behind a non-temporal load those are a second trip to HBM instead of an L2 hit.
+#ifndef E2E_WIDE_NT
+#define E2E_WIDE_NT 2
+#endif
+#if E2E_WIDE_NT & 1
+#define DENSE_LD(p) __builtin_nontemporal_load(p)
+#else
+#define DENSE_LD(p) (*(p))
+#endif
+#if E2E_WIDE_NT & 2
+#define DENSE_ST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define DENSE_ST(v, p) (*(p) = (v))
+#endif
 template <int NV4, typename E>
 __device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
   constexpr int EPC = 16 / (int)sizeof(E);            // elements per 16-byte chunk
@@ -341,7 +358,7 @@ __device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
 #pragma unroll
     for (int e = 0; e < EPC; e++) of[e] = f;
     const ev o = __builtin_convertvector(of, ev);
-    for (int i = lane; i < n4; i += 64) __builtin_nontemporal_store(o, &g4[i]);
+    for (int i = lane; i < n4; i += 64) DENSE_ST(o, &g4[i]);
     return;
   }
   const float ninf = -__builtin_huge_valf();
@@ -366,8 +383,8 @@ __device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
   auto to_held = [](const fv& f) -> held { if constexpr (PACKED) return __builtin_convertvector(f, ev); else return f; };
 #pragma unroll
   for (int u = 0; u < NCH; u++) {
-    if (64 * u + 64 <= n4) { const ev r = __builtin_nontemporal_load(&x4[64 * u + lane]); if constexpr (PACKED) v[u] = r; else v[u] = __builtin_convertvector(r, fv); }
-    else if (64 * u < n4) { const ev r = __builtin_nontemporal_load(&x4[part_idx]); if constexpr (PACKED) v[u] = r; else v[u] = __builtin_convertvector(r, fv); }
+    if (64 * u + 64 <= n4) { const ev r = DENSE_LD(&x4[64 * u + lane]); if constexpr (PACKED) v[u] = r; else v[u] = __builtin_convertvector(r, fv); }
+    else if (64 * u < n4) { const ev r = DENSE_LD(&x4[part_idx]); if constexpr (PACKED) v[u] = r; else v[u] = __builtin_convertvector(r, fv); }
     else {
       fv none;
 #pragma unroll
@@ -404,8 +421,8 @@ __device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
     lse = M + logf(sum);
 #pragma unroll
     for (int u = 0; u < NCH; u++) {
-      if (64 * u + 64 <= n4) __builtin_nontemporal_store(__builtin_convertvector(as_f32(v[u]) * invg, ev), &g4[64 * u + lane]);
-      else if (64 * u < n4) __builtin_nontemporal_store(__builtin_convertvector(as_f32(v[u]) * invg, ev), &g4[part_idx]);
+      if (64 * u + 64 <= n4) DENSE_ST(__builtin_convertvector(as_f32(v[u]) * invg, ev), &g4[64 * u + lane]);
+      else if (64 * u < n4) DENSE_ST(__builtin_convertvector(as_f32(v[u]) * invg, ev), &g4[part_idx]);
       if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     if (lane == 0) p.lse[row] = lse;
@@ -417,8 +434,8 @@ __device__ __forceinline__ void wide_rows_dense_body(const WideParams& p) {
         fv o;
 #pragma unroll
         for (int e = 0; e < EPC; e++) o[e] = exp_acc(f[e]);
-        if (64 * u + 64 <= n4) __builtin_nontemporal_store(__builtin_convertvector(o * p.gscale, ev), &g4[64 * u + lane]);
-        else __builtin_nontemporal_store(__builtin_convertvector(o * p.gscale, ev), &g4[part_idx]);
+        if (64 * u + 64 <= n4) DENSE_ST(__builtin_convertvector(o * p.gscale, ev), &g4[64 * u + lane]);
+        else DENSE_ST(__builtin_convertvector(o * p.gscale, ev), &g4[part_idx]);
       }
       if (u & 1) __builtin_amdgcn_sched_barrier(0);
     }
